@@ -1,0 +1,493 @@
+// attention.hip — softmax(Q Kᵀ · scale) V for head_dim 64, no mask, T <= 224 tokens
+// (reference vit_pytorch_face/vit_face.py:358-376; T = 197 for both ViT-P8S8 and ViT-B/16).
+//
+// One workgroup per (image, head): the whole K/V (or Q/dO) panel of a head fits in LDS
+// (197 x 64 bf16 = 25 KB), so there is no online-softmax loop — each wave owns 16-query (or
+// 16-key) tiles and keeps a full score row-block in registers.
+//
+// bf16 path (MFMA v_mfma_f32_16x16x32_bf16, f32 accumulate):
+//   * scores are computed TRANSPOSED (Sᵀ = K Qᵀ) so that a lane owns one query column: the row
+//     softmax is an in-lane reduction + two xor-shuffles (16, 32), and the probabilities are already
+//     in B-operand layout for the second matmul (Oᵀ = Vᵀ Pᵀ) — no LDS round trip for P.
+//   * the k-slot permutation trick: B-operand slot (g, idx) of the second MFMA holds key
+//     32*pair + 16*(idx/4) + 4*g + idx%4 — exactly what the C layout of two adjacent score tiles
+//     delivers — and the A operand (Vᵀ, from a transposed LDS image) is gathered with the same
+//     permutation (two ds_read_b64), so the contraction is unchanged.
+//   * backward is two kernels with no atomics: dQ (waves own query tiles; needs K, Kᵀ, V in LDS)
+//     and dK/dV (waves own key tiles; needs Q, Qᵀ, dO, dOᵀ in LDS); probabilities are recomputed
+//     from the saved log-sum-exp (flash-style), delta = rowsum(dO∘O) is produced by the dQ kernel.
+// f32 path (parity mode): thread-per-row VALU kernels with LDS-broadcast panels; exact f32.
+#include "gsl_common.h"
+
+using namespace gsl;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int HD = 64;    // head dim
+constexpr int KLD = 72;   // row-major LDS leading dim in bf16 elements (144 B rows: conflict-light b128 reads)
+
+union Frag {
+  uint4 u;
+  uint2 h[2];
+  bf16x8_t v;
+};
+
+__device__ __forceinline__ f32x4_t mfma16(const bf16x8_t a, const bf16x8_t b, const f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// stage a [T][64] bf16 panel (row stride ld elements in global) into row-major LDS [TP][KLD], zero rows >= T
+template <int TP>
+__device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, long ld, int T) {
+  for (int idx = threadIdx.x; idx < TP * 8; idx += blockDim.x) {
+    const int t = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
+    *reinterpret_cast<uint4*>(dst + t * KLD + c * 8) = v;
+  }
+}
+// stage the same panel transposed: dst[d][t], leading dim VLD = TP + 8, zero columns >= T
+template <int TP>
+__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long ld, int T) {
+  constexpr int VLD = TP + 8;
+  for (int idx = threadIdx.x; idx < TP * 8; idx += blockDim.x) {
+    const int t = idx % TP, c = idx / TP;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dst[(c * 8 + 2 * i) * VLD + t] = (bf16_t)(w[i] & 0xffffu);
+      dst[(c * 8 + 2 * i + 1) * VLD + t] = (bf16_t)(w[i] >> 16);
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag_rm(const bf16_t* base, int row, int ks, int fc) {
+  return *reinterpret_cast<const bf16x8_t*>(base + row * KLD + ks * 32 + fc * 8);
+}
+// A-operand from a transposed image: row r, k-slots (fc, idx) -> columns pair*32 + 16*(idx/4) + 4*fc + idx%4
+template <int VLD>
+__device__ __forceinline__ bf16x8_t lds_frag_tr(const bf16_t* base, int row, int pair, int fc) {
+  Frag f;
+  const bf16_t* p = base + row * VLD + pair * 32 + fc * 4;
+  f.h[0] = *reinterpret_cast<const uint2*>(p);
+  f.h[1] = *reinterpret_cast<const uint2*>(p + 16);
+  return f.v;
+}
+__device__ __forceinline__ bf16x8_t gl_frag(const bf16_t* rowptr, int ks, int fc) {
+  return *reinterpret_cast<const bf16x8_t*>(rowptr + ks * 32 + fc * 8);
+}
+__device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * mul, v[1] * mul), pack2bf(v[2] * mul, v[3] * mul));
+}
+
+// =====================================================================================
+// forward (bf16)
+// =====================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int T, int H, float scale) {
+  constexpr int TP = NKT * 16, VLD = TP + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * VLD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD;
+  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
+  stage_transposed<TP>(Vt, qb + 2 * H * HD, ld, T);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nqt = (T + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
+    const bf16_t* qrow = qb + (size_t)qrc * ld;
+    const bf16x8_t qf0 = gl_frag(qrow, 0, fc), qf1 = gl_frag(qrow, 1, fc);
+    f32x4_t s[NKT];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 0, fc), qf0, acc);
+      acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 1, fc), qf1, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + fc * 4 + r;
+        acc[r] = (key < T) ? acc[r] * scale : -3.0e38f;
+        m = fmaxf(m, acc[r]);
+      }
+      s[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m); l += s[kt][r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    Frag pf[NKT / 2];
+#pragma unroll
+    for (int pr = 0; pr < NKT / 2; ++pr) {
+      pf[pr].u = make_uint4(pack2bf(s[2 * pr][0], s[2 * pr][1]), pack2bf(s[2 * pr][2], s[2 * pr][3]),
+                            pack2bf(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2bf(s[2 * pr + 1][2], s[2 * pr + 1][3]));
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_tr<VLD>(Vt, dt * 16 + fr, pr, fc), pf[pr].v, acc);
+      // acc[r] = O[q = fr][d = dt*16 + fc*4 + r]
+      if (qr < T) store4bf(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + fc * 4, acc, inv);
+    }
+    if (fc == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m + __logf(l);
+  }
+}
+
+// =====================================================================================
+// backward dQ (bf16): waves own query tiles
+// =====================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
+                                                               int H, float scale) {
+  constexpr int TP = NKT * 16, VLD = TP + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[HD * VLD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
+  stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
+  stage_transposed<TP>(Kt, qb + H * HD, ld, T);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nqt = (T + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
+    const bf16_t* qrow = qb + (size_t)qrc * ld;
+    const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
+    const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
+    const bf16x8_t qf0 = gl_frag(qrow, 0, fc), qf1 = gl_frag(qrow, 1, fc);
+    Frag dof0, dof1, of0, of1;
+    dof0.v = gl_frag(dorow, 0, fc); dof1.v = gl_frag(dorow, 1, fc);
+    of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
+    float dl = 0.f;
+    {
+      const uint32_t a[8] = {dof0.u.x, dof0.u.y, dof0.u.z, dof0.u.w, dof1.u.x, dof1.u.y, dof1.u.z, dof1.u.w};
+      const uint32_t c[8] = {of0.u.x, of0.u.y, of0.u.z, of0.u.w, of1.u.x, of1.u.y, of1.u.z, of1.u.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dl += __uint_as_float(a[i] << 16) * __uint_as_float(c[i] << 16);
+        dl += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(c[i] & 0xffff0000u);
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float lq = lse[((size_t)b * H + h) * T + qrc];
+    Frag dsf[NKT / 2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      sa = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 0, fc), qf0, sa);
+      sa = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 1, fc), qf1, sa);
+      dp = mfma16(lds_frag_rm(Vs, kt * 16 + fr, 0, fc), dof0.v, dp);
+      dp = mfma16(lds_frag_rm(Vs, kt * 16 + fr, 1, fc), dof1.v, dp);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + fc * 4 + r;
+        const float p = (key < T) ? __expf(sa[r] * scale - lq) : 0.f;
+        ds[r] = p * (dp[r] - dl) * scale;
+      }
+      if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.y = pack2bf(ds[2], ds[3]); }
+      else { dsf[kt / 2].u.z = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.w = pack2bf(ds[2], ds[3]); }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_tr<VLD>(Kt, dt * 16 + fr, pr, fc), dsf[pr].v, acc);
+      if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, 1.0f);
+    }
+    if (fc == 0 && qr < T) delta[((size_t)b * H + h) * T + qr] = dl;
+  }
+}
+
+// =====================================================================================
+// backward dK/dV (bf16): waves own key tiles
+// =====================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+  constexpr int TP = NKT * 16, VLD = TP + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Os[TP * KLD];   // dO row-major
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[HD * VLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ot[HD * VLD];   // dO transposed
+  __shared__ __attribute__((aligned(16))) float lse_s[TP];
+  __shared__ __attribute__((aligned(16))) float del_s[TP];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
+  stage_rowmajor<TP>(Qs, qb, ld, T);
+  stage_rowmajor<TP>(Os, dob, ldo, T);
+  stage_transposed<TP>(Qt, qb, ld, T);
+  stage_transposed<TP>(Ot, dob, ldo, T);
+  for (int t = threadIdx.x; t < TP; t += blockDim.x) {
+    lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] : 3.0e38f;   // padded queries -> p = 0
+    del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nkt = (T + 15) / 16;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int kr = kt * 16 + fr, krc = min(kr, T - 1);
+    const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
+    const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+    const bf16x8_t kf0 = gl_frag(krow, 0, fc), kf1 = gl_frag(krow, 1, fc);
+    const bf16x8_t vf0 = gl_frag(vrow, 0, fc), vf1 = gl_frag(vrow, 1, fc);
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int qp = 0; qp < NKT / 2; ++qp) {
+      Frag pf, dsf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * qp + half;
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sa = mfma16(lds_frag_rm(Qs, qt * 16 + fr, 0, fc), kf0, sa);   // S[q = qt*16+fc*4+r][key = fr]
+        sa = mfma16(lds_frag_rm(Qs, qt * 16 + fr, 1, fc), kf1, sa);
+        dp = mfma16(lds_frag_rm(Os, qt * 16 + fr, 0, fc), vf0, dp);   // dP[q][key]
+        dp = mfma16(lds_frag_rm(Os, qt * 16 + fr, 1, fc), vf1, dp);
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[qt * 16 + fc * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&del_s[qt * 16 + fc * 4]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        float p[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __expf(sa[r] * scale - lv[r]);
+          ds[r] = p[r] * (dp[r] - dv[r]) * scale;
+        }
+        if (half == 0) {
+          pf.u.x = pack2bf(p[0], p[1]); pf.u.y = pack2bf(p[2], p[3]);
+          dsf.u.x = pack2bf(ds[0], ds[1]); dsf.u.y = pack2bf(ds[2], ds[3]);
+        } else {
+          pf.u.z = pack2bf(p[0], p[1]); pf.u.w = pack2bf(p[2], p[3]);
+          dsf.u.z = pack2bf(ds[0], ds[1]); dsf.u.w = pack2bf(ds[2], ds[3]);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        adv[dt] = mfma16(lds_frag_tr<VLD>(Ot, dt * 16 + fr, qp, fc), pf.v, adv[dt]);    // dVᵀ[d][key]
+        adk[dt] = mfma16(lds_frag_tr<VLD>(Qt, dt * 16 + fr, qp, fc), dsf.v, adk[dt]);   // dKᵀ[d][key]
+      }
+    }
+    if (kr < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16_t* base = dqkv + ((size_t)b * T + kr) * ld + h * HD + dt * 16 + fc * 4;
+        store4bf(base + H * HD, adk[dt], 1.0f);
+        store4bf(base + 2 * H * HD, adv[dt], 1.0f);
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// f32 parity kernels: thread per query / per key, panels broadcast from LDS
+// =====================================================================================
+template <int TP>
+__device__ __forceinline__ void stage_f32(float* dst, const float* src, long ld, int T) {
+  for (int idx = threadIdx.x; idx < TP * 16; idx += blockDim.x) {
+    const int t = idx >> 4, c = idx & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T) v = *reinterpret_cast<const float4*>(src + (size_t)t * ld + c * 4);
+    *reinterpret_cast<float4*>(dst + t * HD + c * 4) = v;
+  }
+}
+__device__ __forceinline__ void load_row64(const float* p, float v[64]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const float4 t = *reinterpret_cast<const float4*>(p + c * 4);
+    v[c * 4] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+  }
+}
+__device__ __forceinline__ float dot64(const float a[64], const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) s = fmaf(a[d], b[d], s);
+  return s;
+}
+
+template <int TP>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                           float* __restrict__ lse, int T, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[TP * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[TP * HD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD;
+  const float* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_f32<TP>(Ks, qb + H * HD, ld, T);
+  stage_f32<TP>(Vs, qb + 2 * H * HD, ld, T);
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= T) return;
+  float q[64], acc[64];
+  load_row64(qb + (size_t)i * ld, q);
+  // pass 1: row max (plain two-pass softmax, as torch computes it)
+  float m = -3.0e38f;
+  for (int j = 0; j < T; ++j) m = fmaxf(m, dot64(q, Ks + j * HD) * scale);
+  float l = 0.f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+  for (int j = 0; j < T; ++j) {
+    const float p = expf(dot64(q, Ks + j * HD) * scale - m);
+    l += p;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = fmaf(p, Vs[j * HD + d], acc[d]);
+  }
+  const float inv = 1.0f / l;
+  float* orow = o + ((size_t)b * T + i) * (H * HD) + h * HD;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    *reinterpret_cast<float4*>(orow + c * 4) = make_float4(acc[c * 4] * inv, acc[c * 4 + 1] * inv, acc[c * 4 + 2] * inv, acc[c * 4 + 3] * inv);
+  lse[((size_t)b * H + h) * T + i] = m + logf(l);
+}
+
+template <int TP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ dqkv, float* __restrict__ delta, int T, int H,
+                                                              float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[TP * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[TP * HD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const float* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_f32<TP>(Ks, qb + H * HD, ld, T);
+  stage_f32<TP>(Vs, qb + 2 * H * HD, ld, T);
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= T) return;
+  float q[64], g[64], acc[64];
+  load_row64(qb + (size_t)i * ld, q);
+  load_row64(d_o + ((size_t)b * T + i) * ldo + h * HD, g);
+  const float dl = dot64(g, o + ((size_t)b * T + i) * ldo + h * HD);
+  const float lq = lse[((size_t)b * H + h) * T + i];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+  for (int j = 0; j < T; ++j) {
+    const float p = expf(dot64(q, Ks + j * HD) * scale - lq);
+    const float ds = p * (dot64(g, Vs + j * HD) - dl) * scale;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = fmaf(ds, Ks[j * HD + d], acc[d]);
+  }
+  float* out = dqkv + ((size_t)b * T + i) * ld + h * HD;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    *reinterpret_cast<float4*>(out + c * 4) = make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
+  delta[((size_t)b * H + h) * T + i] = dl;
+}
+
+// WHICH = 0: dK (slot 1 of dqkv), WHICH = 1: dV (slot 2)
+template <int TP, int WHICH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv, int T, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) float Qs[TP * HD];
+  __shared__ __attribute__((aligned(16))) float Gs[TP * HD];   // dO
+  __shared__ float lse_s[TP];
+  __shared__ float del_s[TP];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const float* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_f32<TP>(Qs, qb, ld, T);
+  stage_f32<TP>(Gs, d_o + (size_t)b * T * ldo + h * HD, ldo, T);
+  for (int t = threadIdx.x; t < TP; t += blockDim.x) {
+    lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] : 0.f;
+    del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j >= T) return;
+  float k[64], v[64], acc[64];
+  load_row64(qb + (size_t)j * ld + H * HD, k);
+  if (WHICH == 0) load_row64(qb + (size_t)j * ld + 2 * H * HD, v);
+#pragma unroll
+  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+  for (int i = 0; i < T; ++i) {
+    const float p = expf(dot64(k, Qs + i * HD) * scale - lse_s[i]);
+    if (WHICH == 0) {
+      const float ds = p * (dot64(v, Gs + i * HD) - del_s[i]) * scale;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) acc[d] = fmaf(ds, Qs[i * HD + d], acc[d]);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 64; ++d) acc[d] = fmaf(p, Gs[i * HD + d], acc[d]);
+    }
+  }
+  float* out = dqkv + ((size_t)b * T + j) * ld + h * HD + (WHICH == 0 ? H * HD : 2 * H * HD);
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    *reinterpret_cast<float4*>(out + c * 4) = make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
+}
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype,
+                                 gsl_stream_t s) {
+  GSL_CHECK_ARG(qkv && o && lse && B > 0 && T > 1 && H > 0, "null/size");
+  GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
+  hipStream_t st = as_stream(s);
+  const dim3 grid(B * H), blk(256);
+  if (dtype == GSL_BF16) {
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale);
+  } else if (dtype == GSL_F32) {
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_f32_kernel<224>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
+  } else return fail(GSL_ERR_ARG, "gsl_attention_fwd: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_attention_fwd");
+}
+
+extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+                                 float* delta_ws, int B, int T, int H, float scale, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(qkv && o && d_o && lse && dqkv && delta_ws && B > 0 && T > 1 && H > 0, "null/size");
+  GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
+  hipStream_t st = as_stream(s);
+  const dim3 grid(B * H), blk(256);
+  if (dtype == GSL_BF16) {
+    const bf16_t* q = (const bf16_t*)qkv; const bf16_t* oo = (const bf16_t*)o; const bf16_t* g = (const bf16_t*)d_o;
+    bf16_t* dq = (bf16_t*)dqkv;
+    if (T <= 64) {
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<14>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+    }
+  } else if (dtype == GSL_F32) {
+    const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;
+    float* dq = (float*)dqkv;
+    if (T <= 64) {
+      hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<64>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64, 0>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64, 1>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<224>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<224, 0>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<224, 1>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+    }
+  } else return fail(GSL_ERR_ARG, "gsl_attention_bwd: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_attention_bwd");
+}

@@ -1,0 +1,269 @@
+// gemm.hip — dense NT GEMM  acc = alpha * (A1·W1ᵀ + A2·W2ᵀ)  with fused epilogues.
+//
+// Replaces F.linear / loralib.Linear.forward (reference vit_pytorch_face/vit_face.py:330-334,
+// 349-356, 531) and their autograd dX. The second K segment carries the rank-r LoRA term:
+// [x | s·(x Aᵀ)] · [W | B]ᵀ  ==  x Wᵀ + s·(x Aᵀ) Bᵀ, so the adapter costs one extra K tile on the
+// matrix cores instead of two skinny GEMMs and an elementwise add.
+//
+// bf16 path: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16 with the
+// operands swapped (mfma(W, A)) so each lane owns 4 consecutive output columns of one row ->
+// 8/16-byte epilogue stores. LDS tiles are XOR-swizzled on 16-byte chunks (chunk ^= row & 7) so the
+// ds_read_b128 fragment reads are <= 2-way conflicted; global->LDS is register-staged and
+// double-buffered (one barrier per K tile). Block ids are remapped so that the blocks sharing an
+// A row-panel run on the same XCD (private L2).
+// f32 path (parity mode): 64x64x16 tile, 4x4 outputs per thread, sequential fmaf over k.
+#include "gsl_common.h"
+
+using namespace gsl;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct EpiArgs {
+  float alpha;
+  const float* bias;
+  const float* res;
+  const void* aux;
+  void* out;
+  void* out2;
+  int ldo;
+  const float* pos;
+  const float* cls;
+  int T;
+  DropCfg drop;
+  int M, N;
+};
+
+// one row m, four consecutive columns n..n+3 (N % 4 == 0 is enforced by the host wrapper)
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float v[4]) {
+  if (m >= e.M || n >= e.N) return;
+  const size_t off = (size_t)m * e.ldo + n;
+  const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
+  if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32) {
+    if (e.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += e.bias[n + i];
+    }
+    if constexpr (EPI == GSL_EPI_STORE) Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
+    else Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
+  } else if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
+    float r[4];
+    Elem<float>::ld4(e.res + off, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] + e.bias[n + i]) * drop_mul(e.drop, lin + i) + r[i];
+    Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
+  } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[i] + e.bias[n + i];
+      const float dm = drop_mul(e.drop, lin + i);
+      v[i] = gelu_f(a) * dm;
+      g[i] = gelu_grad_f(a) * dm;
+    }
+    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
+    if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g);
+  } else if constexpr (EPI == GSL_EPI_MUL) {
+    float a[4];
+    Elem<T>::ld4(reinterpret_cast<const T*>(e.aux) + off, a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= a[i];
+    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
+  } else if constexpr (EPI == GSL_EPI_PATCH) {
+    const int tok = m % e.T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float base = (tok == 0) ? e.cls[n + i] : (v[i] + e.bias[n + i]);
+      v[i] = (base + e.pos[(size_t)tok * e.N + n + i]) * drop_mul(e.drop, lin + i);
+    }
+    Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
+  }
+}
+
+// bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
+// range of logical tile ids so neighbouring tiles (same A row-panel) share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel
+constexpr int BM = 128, BN = 128, BK = 64;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                        const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                        const bf16_t* __restrict__ A2, int lda2,
+                                                        const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][BM * BK];  // [buffer][A|W][row*64 + swizzled chunk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+
+  uint4 ra[4], rw[4];
+  auto gload = [&](int kt) {
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      ra[i] = *reinterpret_cast<const uint4*>(Ab + (size_t)gm * lda + k0 + c * 8);
+      rw[i] = *reinterpret_cast<const uint4*>(Wb + (size_t)gn * ldw + k0 + c * 8);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+      const int off = row * BK + ((c ^ (row & 7)) << 3);
+      *reinterpret_cast<uint4*>(&smem[buf][0][off]) = ra[i];
+      *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rw[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fc = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][0][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][1][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // acc[i][j][reg] = C[m = m0+wm*64+i*16+(lane&15)][n = n0+wn*64+j*16+(lane>>4)*4+reg]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------ f32 kernel (parity mode)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
+                                                       const float* __restrict__ W1, int ldw1, int K1,
+                                                       const float* __restrict__ A2, int lda2,
+                                                       const float* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Ws[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int nbn = (e.N + 63) / 64;
+  const int m0 = (blockIdx.x / nbn) * 64, n0 = (blockIdx.x % nbn) * 64;
+  const int nk1 = K1 / 16, nk = nk1 + K2 / 16;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* Ab; const float* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * 16; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * 16; }
+    const int gm = min(m0 + lrow, e.M - 1), gn = min(n0 + lrow, e.N - 1);
+    const float4 a4 = *reinterpret_cast<const float4*>(Ab + (size_t)gm * lda + k0 + lk);
+    const float4 w4 = *reinterpret_cast<const float4*>(Wb + (size_t)gn * ldw + k0 + lk);
+    __syncthreads();
+    As[lk + 0][lrow] = a4.x; As[lk + 1][lrow] = a4.y; As[lk + 2][lrow] = a4.z; As[lk + 3][lrow] = a4.w;
+    Ws[lk + 0][lrow] = w4.x; Ws[lk + 1][lrow] = w4.y; Ws[lk + 2][lrow] = w4.z; Ws[lk + 3][lrow] = w4.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 w = *reinterpret_cast<const float4*>(&Ws[k][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) epilogue4<EPI, float>(e, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
+}
+
+template <int EPI>
+static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
+                       int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
+  if (dtype == GSL_BF16) {
+    const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
+                       (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+  } else {
+    const int nblk = ((e.M + 63) / 64) * ((e.N + 63) / 64);
+    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,
+                       ldw1, K1, (const float*)A2, lda2, (const float*)W2, ldw2, K2, e);
+  }
+  return check_launch("gsl_gemm_nt");
+}
+
+extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
+                           const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
+                           const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                           const float* pos, const float* cls, int T, float p_drop, uint64_t seed, uint32_t site,
+                           gsl_stream_t s) {
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0, "M>0, N>0, N%4==0");
+  GSL_CHECK_ARG(K1 > 0 && (K1 % 64) == 0 && K2 >= 0 && (K2 % 64) == 0, "K1,K2 multiples of 64");
+  GSL_CHECK_ARG(A1 && W1 && out && (K2 == 0 || (A2 && W2)), "null operand");
+  GSL_CHECK_ARG((lda1 % 8) == 0 && (ldw1 % 8) == 0 && (K2 == 0 || ((lda2 % 8) == 0 && (ldw2 % 8) == 0)) && (ldo % 4) == 0,
+                "leading dimensions must keep 16-byte alignment");
+  GSL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "p_drop");
+  EpiArgs e;
+  e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
+  e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
+  hipStream_t st = as_stream(s);
+  switch (epilogue) {
+    case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_STORE_F32: return launch_gemm<GSL_EPI_STORE_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_BIAS_RES_F32:
+      GSL_CHECK_ARG(bias && res, "bias/res required");
+      return launch_gemm<GSL_EPI_BIAS_RES_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_BIAS_GELU:
+      GSL_CHECK_ARG(bias, "bias required");
+      return launch_gemm<GSL_EPI_BIAS_GELU>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_MUL:
+      GSL_CHECK_ARG(aux, "aux required");
+      return launch_gemm<GSL_EPI_MUL>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_PATCH:
+      GSL_CHECK_ARG(bias && pos && cls && T > 0, "bias/pos/cls/T required");
+      return launch_gemm<GSL_EPI_PATCH>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    default: return fail(GSL_ERR_ARG, "gsl_gemm_nt: unknown epilogue%s %ld", "", epilogue);
+  }
+}

@@ -1,0 +1,140 @@
+// gsl_common.h — shared device helpers for libgslora_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gslora_hip.h"
+
+namespace gsl {
+
+// ------------------------------------------------------------------ errors
+extern thread_local char g_err[512];
+inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return code;
+}
+#define GSL_CHECK_ARG(cond, msg)                                                        \
+  do {                                                                                  \
+    if (!(cond)) return gsl::fail(GSL_ERR_ARG, "%s: argument check failed: " msg " (%ld,%ld)", __func__, 0, 0); \
+  } while (0)
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return GSL_ERR_LAUNCH;
+  }
+  return GSL_OK;
+}
+#define GSL_LAUNCH_CHECK() return gsl::check_launch(__func__)
+
+// ------------------------------------------------------------------ bf16
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (NaN kept quiet)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void ld4(const float* p, float v[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st4(bf16_t* p, const float v[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  }
+};
+
+// ------------------------------------------------------------------ wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reduce (sum) for blockDim.x <= 1024, result valid in all threads; `sm` >= 16 floats
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sm[i];   // fixed order -> deterministic
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = -3.0e38f;
+  for (int i = 0; i < nw; ++i) t = fmaxf(t, sm[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------ dropout (counter-based hash)
+// keep(i) for element index i of dropout site `site` under `seed`: a 2-round multiply-xorshift
+// hash of the 64-bit counter; the low 24 bits are compared with p*2^24. The same function
+// regenerates the mask in backward — no mask tensor is ever stored.
+struct DropCfg {
+  uint32_t thr;   // drop if (hash & 0xffffff) < thr ; thr = 0 disables
+  uint32_t key;   // seed/site mix
+  float scale;    // 1/(1-p)
+};
+inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
+  DropCfg d;
+  d.thr = (p > 0.f) ? (uint32_t)(p * 16777216.0f + 0.5f) : 0u;
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  z ^= z >> 29; z *= 0xD6E8FEB86659FD93ull; z ^= z >> 32;
+  d.key = (uint32_t)z;
+  d.scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+__device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint64_t idx) {
+  uint32_t x = (uint32_t)idx ^ key;
+  x += (uint32_t)(idx >> 32) * 0x9E3779B1u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// multiplier to apply to an element: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_mul(const DropCfg& d, uint64_t idx) {
+  if (d.thr == 0u) return 1.0f;
+  return ((drop_hash(d.key, idx) & 0xffffffu) < d.thr) ? 0.0f : d.scale;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default, vit_face.py:331)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+inline hipStream_t as_stream(gsl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace gsl

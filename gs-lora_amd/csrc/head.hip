@@ -1,0 +1,317 @@
+// head.hip — the two ends of the network and the scalar losses:
+//   K1  patch gather (einops rearrange, vit_pytorch_face/vit_face.py:530)
+//   K10 cls-pool + LayerNorm + CosFace margin head (vit_face.py:540-546, 171-208) fwd / bwd
+//   K11 mean cross-entropy + top-1 (engine_cl.py:65-78, util/utils.py:354-368) fwd / bwd
+//   K13 prototype KL (engine_cl.py:571-603) fwd / bwd
+// All are tiny next to the GEMMs; they exist so that a step needs no host sync and no [B,C]-sized
+// PyTorch elementwise chain. Upstream gradient scalars arrive as DEVICE pointers (coef).
+#include "gsl_common.h"
+
+using namespace gsl;
+
+// ------------------------------------------------------------------ K1 patchify
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C, int H, int W, int p) {
+  const int hp = H / p, wp = W / p, Tn = 1 + hp * wp, Kp = p * p * C;
+  const long total = (long)B * Tn * p * p;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int p2 = (int)(idx % p);
+    const int p1 = (int)((idx / p) % p);
+    const int t = (int)((idx / (p * p)) % Tn);
+    const int b = (int)(idx / ((long)p * p * Tn));
+    T* o = out + ((size_t)b * Tn + t) * Kp + (size_t)(p1 * p + p2) * C;
+    if (t == 0) {
+      for (int c = 0; c < C; ++c) Elem<T>::st(o + c, 0.f);
+    } else {
+      const int h = (t - 1) / wp, w = (t - 1) % wp;
+      const float* src = img + ((size_t)b * C * H + (size_t)(h * p + p1)) * W + (size_t)(w * p + p2);
+      for (int c = 0; c < C; ++c) Elem<T>::st(o + c, src[(size_t)c * H * W]);
+    }
+  }
+}
+
+extern "C" int gsl_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(img && out && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0, "shape");
+  const long total = (long)B * (1 + (H / p) * (W / p)) * p * p;
+  const int grid = (int)min((total + 255) / 256, (long)(256 * 16));
+  if (dtype == GSL_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(s), img, (bf16_t*)out, B, C, H, W, p);
+  else if (dtype == GSL_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, as_stream(s), img, (float*)out, B, C, H, W, p);
+  else return fail(GSL_ERR_ARG, "gsl_patchify: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_patchify");
+}
+
+// ------------------------------------------------------------------ K10 head
+__global__ void cosface_prep_kernel(const float* __restrict__ W, float* __restrict__ Wn, int C, int D) {
+  // one wave per class row: Wn = W / max(||W||, 1e-12)   (F.normalize, vit_face.py:181)
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = W[(size_t)c * D + d]; ss += v * v; }
+  const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+  for (int d = lane; d < D; d += 64) Wn[(size_t)c * D + d] = W[(size_t)c * D + d] * inv;
+}
+extern "C" int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s) {
+  GSL_CHECK_ARG(W && Wn && C > 0 && D > 0, "null/size");
+  hipLaunchKernelGGL(cosface_prep_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(s), W, Wn, C, D);
+  return check_launch("gsl_cosface_prep");
+}
+
+constexpr int HEAD_MAXD = 1024;
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, const float* __restrict__ Wn,
+                                                       const int64_t* __restrict__ label, float* __restrict__ emb,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       float* __restrict__ logits, int D, int C, float cs, float cm) {
+  __shared__ float e[HEAD_MAXD];
+  __shared__ float sm[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)b * T * D;
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) { e[d] = xr[d]; s += e[d]; }
+  const float mu = block_sum(s, sm) / D;
+  float q = 0.f;
+  for (int d = tid; d < D; d += 256) { const float c = e[d] - mu; q += c * c; }
+  const float rs = rsqrtf(block_sum(q, sm) / D + eps);
+  float nn = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    const float v = (e[d] - mu) * rs * gamma[d] + beta[d];
+    e[d] = v;
+    emb[(size_t)b * D + d] = v;
+    nn += v * v;
+  }
+  if (tid == 0) { mean[b] = mu; rstd[b] = rs; }
+  const float inv = 1.0f / fmaxf(sqrtf(block_sum(nn, sm)), 1e-12f);   // block_sum syncs -> e[] complete
+  if (!logits) return;
+  const int lane = tid & 63, wave = tid >> 6;
+  const long lab = label ? (long)label[b] : -1;
+  for (int c = wave; c < C; c += 4) {
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += e[d] * Wn[(size_t)c * D + d];
+    dot = wave_sum(dot) * inv;
+    if (lane == 0) logits[(size_t)b * C + c] = cs * ((c == lab) ? (dot - cm) : dot);
+  }
+}
+
+extern "C" int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps, const float* Wn,
+                            const int64_t* label, float* emb, float* mean, float* rstd, float* logits, int B, int D, int C,
+                            float cos_s, float cos_m, gsl_stream_t s) {
+  GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
+  GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
+  GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, as_stream(s), x, T, gamma, beta, eps, Wn, label, emb, mean, rstd,
+                     logits, D, C, cos_s, cos_m);
+  return check_launch("gsl_head_fwd");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ demb_in,
+                                                       const float* __restrict__ x, int Tn, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ emb, const float* __restrict__ Wn,
+                                                       float* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
+                                                       DropCfg drop) {
+  __shared__ float de[HEAD_MAXD];   // d emb
+  __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
+  __shared__ float sm[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // zero the non-cls token rows of this image (their stream gradient is exactly 0)
+  {
+    float4* z = reinterpret_cast<float4*>(dx + ((size_t)b * Tn + 1) * D);
+    const long n4 = (long)(Tn - 1) * D / 4;
+    for (long i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dxb) {
+      T* zb = dxb + ((size_t)b * Tn + 1) * D;
+      const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+      for (long i = tid; i < n4; i += 256) Elem<T>::st4(zb + i * 4, zero);
+    }
+  }
+  const float* er = emb + (size_t)b * D;
+  float nn = 0.f;
+  for (int d = tid; d < D; d += 256) nn += er[d] * er[d];
+  const float nrm = fmaxf(sqrtf(block_sum(nn, sm)), 1e-12f);
+  if (dlogits) {
+    for (int c = tid; c < C; c += 256) dl[c] = cs * dlogits[(size_t)b * C + c];
+  }
+  __syncthreads();
+  float dotp = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    float g = 0.f;
+    if (dlogits) {
+      for (int c = 0; c < C; ++c) g += dl[c] * Wn[(size_t)c * D + d];
+    }
+    de[d] = g;                       // d e-hat
+    dotp += g * er[d];
+  }
+  const float proj = block_sum(dotp, sm) / (nrm * nrm);   // (e-hat . d e-hat) / ||e||
+  const float mu = mean[b], rs = rstd[b];
+  const float* xr = x + (size_t)b * Tn * D;
+  float s1 = 0.f, s2 = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    float g = (de[d] - er[d] * proj) / nrm;               // d emb from CosFace
+    if (demb_in) g += demb_in[(size_t)b * D + d];
+    g *= gamma[d];
+    de[d] = g;
+    const float xh = (xr[d] - mu) * rs;
+    s1 += g;
+    s2 += g * xh;
+  }
+  const float c1 = block_sum(s1, sm) / D;
+  const float c2 = block_sum(s2, sm) / D;
+  for (int d = tid; d < D; d += 256) {
+    const float xh = (xr[d] - mu) * rs;
+    const float g = rs * (de[d] - c1 - xh * c2);
+    const size_t o = (size_t)b * Tn * D + d;
+    dx[o] = g;
+    if (dxb) Elem<T>::st(dxb + o, g * drop_mul(drop, (uint64_t)o));
+  }
+}
+
+extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
+                            const float* mean, const float* rstd, const float* emb, const float* Wn, float* dx, void* dxb,
+                            int B, int D, int C, float cos_s, int dtype, float p_drop, uint64_t seed, uint32_t site,
+                            gsl_stream_t s) {
+  GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T > 1, "null/size");
+  GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
+  GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
+  const DropCfg drop = make_drop(p_drop, seed, site);
+  if (dtype == GSL_BF16)
+    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
+                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop);
+  else if (dtype == GSL_F32)
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
+                       Wn, dx, (float*)dxb, D, C, cos_s, drop);
+  else return fail(GSL_ERR_ARG, "gsl_head_bwd: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_head_bwd");
+}
+
+// ------------------------------------------------------------------ K11 cross entropy
+// wave-per-row log-softmax; one block so the batch sum is a fixed-order (deterministic) reduction.
+__device__ __forceinline__ void row_softmax_stats(const float* row, int C, int lane, float& mx, float& lse, int& amax) {
+  float m = -3.0e38f; int mi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) { const float v = row[c]; if (v > m) { m = v; mi = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(row[c] - m);
+  se = wave_sum(se);
+  mx = m; lse = m + logf(se); amax = mi;
+}
+
+__global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ out2, int B, int C) {
+  __shared__ float sl[16], sc[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float loss = 0.f, corr = 0.f;
+  for (int r = wave; r < B; r += nw) {
+    float mx, lse; int am;
+    row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
+    const int y = (int)labels[r];
+    loss += lse - logits[(size_t)r * C + y];
+    corr += (am == y) ? 1.f : 0.f;
+  }
+  if (lane == 0) { sl[wave] = loss; sc[wave] = corr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, c = 0.f;
+    for (int i = 0; i < nw; ++i) { a += sl[i]; c += sc[i]; }
+    out2[0] = a; out2[1] = c;
+  }
+}
+extern "C" int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, int B, int C, gsl_stream_t s) {
+  GSL_CHECK_ARG(logits && labels && out2 && B > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, labels, out2, B, C);
+  return check_launch("gsl_ce_fwd");
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ coef, float scale, float* dlogits, int B, int C,
+                                                     int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B) return;
+  float mx, lse; int am;
+  row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
+  const float k = coef[0] * scale;
+  const int y = (int)labels[r];
+  for (int c = lane; c < C; c += 64) {
+    const float g = k * (expf(logits[(size_t)r * C + c] - lse) - (c == y ? 1.f : 0.f));
+    float* d = dlogits + (size_t)r * C + c;
+    *d = accumulate ? (*d + g) : g;
+  }
+}
+extern "C" int gsl_ce_bwd(const float* logits, const int64_t* labels, const float* coef, float scale, float* dlogits, int B,
+                          int C, int accumulate, gsl_stream_t s) {
+  GSL_CHECK_ARG(logits && labels && coef && dlogits && B > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), logits, labels, coef, scale, dlogits, B, C, accumulate);
+  return check_launch("gsl_ce_bwd");
+}
+
+// ------------------------------------------------------------------ K13 prototype KL
+__device__ __forceinline__ float row_lse(const float* row, int D, int lane) {
+  float m = -3.0e38f;
+  for (int d = lane; d < D; d += 64) m = fmaxf(m, row[d]);
+  m = wave_max(m);
+  float se = 0.f;
+  for (int d = lane; d < D; d += 64) se += expf(row[d] - m);
+  return m + logf(wave_sum(se));
+}
+
+__global__ __launch_bounds__(1024) void proto_kl_fwd_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ proto, float* __restrict__ out1, int B,
+                                                            int D) {
+  __shared__ float sk[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float kl = 0.f;
+  for (int r = wave; r < B; r += nw) {
+    const float* a = emb + (size_t)r * D;
+    const float* t = proto + (size_t)labels[r] * D;
+    const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float ltd = t[d] - lt;
+      acc += expf(ltd) * (ltd - (a[d] - la));
+    }
+    kl += wave_sum(acc);
+  }
+  if (lane == 0) sk[wave] = kl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int i = 0; i < nw; ++i) a += sk[i];
+    out1[0] = a;
+  }
+}
+extern "C" int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, int B, int D, int C,
+                                gsl_stream_t s) {
+  GSL_CHECK_ARG(emb && labels && proto && out1 && B > 0 && D > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(proto_kl_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(s), emb, labels, proto, out1, B, D);
+  return check_launch("gsl_proto_kl_fwd");
+}
+
+__global__ __launch_bounds__(256) void proto_kl_bwd_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ proto, const float* __restrict__ coef,
+                                                           float scale, float* demb, int B, int D, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B) return;
+  const float* a = emb + (size_t)r * D;
+  const float* t = proto + (size_t)labels[r] * D;
+  const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
+  const float k = coef[0] * scale;
+  for (int d = lane; d < D; d += 64) {
+    const float g = k * (expf(a[d] - la) - expf(t[d] - lt));
+    float* o = demb + (size_t)r * D + d;
+    *o = accumulate ? (*o + g) : g;
+  }
+}
+extern "C" int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef, float scale,
+                                float* demb, int B, int D, int C, int accumulate, gsl_stream_t s) {
+  GSL_CHECK_ARG(emb && labels && proto && coef && demb && B > 0 && D > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(proto_kl_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, coef, scale, demb, B, D, accumulate);
+  return check_launch("gsl_proto_kl_bwd");
+}

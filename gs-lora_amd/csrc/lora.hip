@@ -1,0 +1,342 @@
+// lora.hip — the LoRA-parameter side of the step: skinny rank-r gradient GEMMs, group-lasso
+// norms (L_structure), fused AdamW, and the small cast/pack helpers.
+//
+// References (bjzhb666/GS-LoRA): loralib.Linear autograd for lora_A/lora_B (call sites
+// vit_pytorch_face/vit_face.py:330,333), engine_cl.get_structure_loss (engine_cl.py:349-432),
+// util/cal_norm.get_norm_of_lora (util/cal_norm.py:4-146), torch.optim.AdamW via
+// timm.create_optimizer (train/train_own_forget_cl.py:811-813).
+#include "gsl_common.h"
+
+using namespace gsl;
+
+// =====================================================================================
+// K9  G[n, j] (+)= sum_m Y[m, n] * U[m, j]      (reduction over the M = B*197 token rows)
+// HBM-bound: Y is streamed exactly once with 16-byte loads; each thread owns 8 (bf16) or 4 (f32)
+// consecutive n and keeps VEC x R accumulators in registers; the r-vector U[m, :] is staged per
+// row chunk in LDS and read as a wave-uniform broadcast. Two deterministic stages: per-row-split
+// partial slabs, then a fixed-order reduction that also applies the output strides.
+// =====================================================================================
+constexpr int LG_ROWS = 32;  // rows of U staged per LDS fill
+
+template <typename T> struct LgVec;
+template <> struct LgVec<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+template <> struct LgVec<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restrict__ Y, const T* __restrict__ U, int ldu,
+                                                                float* __restrict__ part, int M, int N, int rows_per_split) {
+  constexpr int V = LgVec<T>::V;
+  __shared__ float us[LG_ROWS][R];
+  const int ncol = N / V;                       // column groups
+  const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = cg < ncol;
+  const int split = blockIdx.y;
+  const int r0 = split * rows_per_split, r1 = min(M, r0 + rows_per_split);
+  float acc[V][R];
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[i][j] = 0.f;
+  for (int rb = r0; rb < r1; rb += LG_ROWS) {
+    const int nr = min(LG_ROWS, r1 - rb);
+    __syncthreads();
+    for (int t = threadIdx.x; t < LG_ROWS * R; t += blockDim.x) {
+      const int rr = t / R, j = t % R;
+      us[rr][j] = (rr < nr) ? Elem<T>::ld(U + (size_t)(rb + rr) * ldu + j) : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int rr = 0; rr < nr; ++rr) {
+        float y[V];
+        LgVec<T>::ld(Y + (size_t)(rb + rr) * N + (size_t)cg * V, y);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const float u = us[rr][j];
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[i][j] = fmaf(y[i], u, acc[i][j]);
+        }
+      }
+    }
+  }
+  if (active) {
+    float* p = part + ((size_t)split * N + (size_t)cg * V) * R;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+      for (int j = 0; j < R; ++j) p[i * R + j] = acc[i][j];
+  }
+}
+
+template <int R>
+__global__ void lora_grad_reduce_kernel(const float* __restrict__ part, float* G, long gsn, long gsj, int N, int r,
+                                        int nsplit, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over N*R
+  if (idx >= N * R) return;
+  const int n = idx / R, j = idx % R;
+  if (j >= r) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * N * R + idx];   // fixed order
+  float* g = G + (size_t)n * gsn + (size_t)j * gsj;
+  *g = accumulate ? (*g + s) : s;
+}
+
+static inline int lg_nsplit(int M, int N, int V) {
+  const int bx = (N / V + 255) / 256;
+  int target = (256 * 4) / (bx > 0 ? bx : 1);      // ~4 blocks per CU in total
+  int nsplit = (M + 63) / 64;                      // at least 64 rows per split
+  if (nsplit > target) nsplit = target;
+  if (nsplit < 1) nsplit = 1;
+  return nsplit;
+}
+
+extern "C" long gsl_lora_grad_ws_elems(int M, int N, int r) {
+  const int R = (r <= 8) ? 8 : 16;
+  return (long)lg_nsplit(M, N, 4) * (long)N * R;   // V=4 gives the larger split count bound
+}
+
+extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj, int M, int N, int r,
+                             int dtype, int accumulate, float* ws, gsl_stream_t s) {
+  GSL_CHECK_ARG(Y && U && G && ws && M > 0 && N > 0, "null/size");
+  GSL_CHECK_ARG(r >= 1 && r <= 16 && ldu >= 16 && (ldu % 8) == 0, "r in [1,16], ldu >= 16 (zero-padded)");
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  const int V = (dtype == GSL_BF16) ? 8 : 4;
+  GSL_CHECK_ARG((N % V) == 0, "N must be a multiple of the vector width");
+  hipStream_t st = as_stream(s);
+  const int R = (r <= 8) ? 8 : 16;
+  const int ncol = N / V;
+  const int threads = ncol >= 256 ? 256 : ((ncol + 63) / 64) * 64;
+  const int bx = (ncol + threads - 1) / threads;
+  int nsplit = lg_nsplit(M, N, V);
+  const long cap = gsl_lora_grad_ws_elems(M, N, r) / ((long)N * R);
+  if (nsplit > cap) nsplit = (int)cap;
+  const int rps = (M + nsplit - 1) / nsplit;
+  nsplit = (M + rps - 1) / rps;
+#define LAUNCH(TT, RR)                                                                                              \
+  hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(threads), 0, st, (const TT*)Y, (const TT*)U, \
+                     ldu, ws, M, N, rps)
+  if (dtype == GSL_BF16) { if (R == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
+  else { if (R == 8) LAUNCH(float, 8); else LAUNCH(float, 16); }
+#undef LAUNCH
+  int rc = check_launch("gsl_lora_grad(partial)");
+  if (rc) return rc;
+  const int tot = N * R;
+  if (R == 8) hipLaunchKernelGGL(lora_grad_reduce_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+  else hipLaunchKernelGGL(lora_grad_reduce_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+  return check_launch("gsl_lora_grad(reduce)");
+}
+
+// =====================================================================================
+// K12 group-lasso norms over the flat LoRA buffer.  Stage 1: block (t, s) reduces split s of
+// tensor t with 16-byte loads + wavefront reductions -> partial[t][s]. Stage 2 (one wave):
+// fixed-order sums -> per-tensor sumsq, per-group lasso norm, cal_norm, total loss, mask.
+// =====================================================================================
+__global__ __launch_bounds__(256) void gnorm_partial_kernel(const float* __restrict__ flat, const int64_t* __restrict__ toff,
+                                                            const int64_t* __restrict__ tnumel, float* __restrict__ partial) {
+  __shared__ float sm[16];
+  const int t = blockIdx.x, sp = blockIdx.y;
+  const int64_t n = tnumel[t];
+  const float* p = flat + toff[t];
+  const int64_t chunk = ((n + GSL_NORM_SPLIT - 1) / GSL_NORM_SPLIT + 3) & ~(int64_t)3;
+  const int64_t b = sp * chunk, e = min(n, b + chunk);
+  float acc = 0.f;
+  const bool al = ((reinterpret_cast<uintptr_t>(p + b) & 15) == 0);
+  if (al) {
+    const int64_t n4 = (e > b) ? (e - b) / 4 : 0;
+    const float4* p4 = reinterpret_cast<const float4*>(p + b);
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = p4[i];
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t i = b + n4 * 4 + threadIdx.x; i < e; i += blockDim.x) acc += p[i] * p[i];
+  } else {
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) acc += p[i] * p[i];
+  }
+  const float tot = block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[t * GSL_NORM_SPLIT + sp] = tot;
+}
+
+__global__ void gnorm_final_kernel(const float* __restrict__ partial, const int32_t* __restrict__ tgroup, int ntensors,
+                                   int ngroups, float tau, float* tensor_sumsq, float* group_norm, float* cal_norm,
+                                   float* loss, uint8_t* mask) {
+  // one wave; lane g owns group g (looped), everything in fixed order -> bit-reproducible
+  const int lane = threadIdx.x;
+  for (int t = lane; t < ntensors; t += 64) {
+    float s = 0.f;
+    for (int k = 0; k < GSL_NORM_SPLIT; ++k) s += partial[t * GSL_NORM_SPLIT + k];
+    tensor_sumsq[t] = s;
+  }
+  __syncthreads();
+  for (int g = lane; g < ngroups; g += 64) {
+    float ss = 0.f, cn = 0.f;
+    for (int t = 0; t < ntensors; ++t)
+      if (tgroup[t] == g) { ss += tensor_sumsq[t]; cn += sqrtf(tensor_sumsq[t]); }
+    const float nrm = sqrtf(ss);
+    group_norm[g] = nrm;
+    if (cal_norm) cal_norm[g] = cn;
+    if (mask) mask[g] = nrm > tau ? 1 : 0;
+  }
+  __syncthreads();
+  if (lane == 0 && loss) {
+    float l = 0.f;
+    for (int g = 0; g < ngroups; ++g) l += group_norm[g];
+    loss[0] = l;
+  }
+}
+
+extern "C" int gsl_group_norms_fwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+                                   int ntensors, int ngroups, float tau, float* partial_ws, float* tensor_sumsq,
+                                   float* group_norm, float* cal_norm, float* loss, uint8_t* mask, gsl_stream_t s) {
+  GSL_CHECK_ARG(flat && toff && tnumel && tgroup && partial_ws && tensor_sumsq && group_norm, "null");
+  GSL_CHECK_ARG(ntensors > 0 && ngroups > 0, "counts");
+  hipStream_t st = as_stream(s);
+  hipLaunchKernelGGL(gnorm_partial_kernel, dim3(ntensors, GSL_NORM_SPLIT), dim3(256), 0, st, flat, toff, tnumel, partial_ws);
+  int rc = check_launch("gsl_group_norms_fwd(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gnorm_final_kernel, dim3(1), dim3(64), 0, st, partial_ws, tgroup, ntensors, ngroups, tau, tensor_sumsq,
+                     group_norm, cal_norm, loss, mask);
+  return check_launch("gsl_group_norms_fwd(final)");
+}
+
+__global__ __launch_bounds__(256) void gnorm_bwd_kernel(const float* __restrict__ flat, const int64_t* __restrict__ toff,
+                                                        const int64_t* __restrict__ tnumel, const int32_t* __restrict__ tgroup,
+                                                        const float* __restrict__ group_norm, const float* __restrict__ coef,
+                                                        float scale, float* gradflat) {
+  const int t = blockIdx.x;
+  const float nrm = group_norm[tgroup[t]];
+  const float k = (nrm > 0.f) ? (coef[0] * scale / nrm) : 0.f;   // subgradient 0 at an all-zero group
+  const int64_t n = tnumel[t], o = toff[t];
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x)
+    gradflat[o + i] += k * flat[o + i];
+}
+
+extern "C" int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+                                   int ntensors, const float* group_norm, const float* coef, float scale, float* gradflat,
+                                   gsl_stream_t s) {
+  GSL_CHECK_ARG(flat && toff && tnumel && tgroup && group_norm && coef && gradflat && ntensors > 0, "null");
+  hipLaunchKernelGGL(gnorm_bwd_kernel, dim3(ntensors, GSL_NORM_SPLIT), dim3(256), 0, as_stream(s), flat, toff, tnumel, tgroup,
+                     group_norm, coef, scale, gradflat);
+  return check_launch("gsl_group_norms_bwd");
+}
+
+// =====================================================================================
+// K14 fused AdamW (single launch over the flat LoRA bucket; 4 streams x 0.98 MB)
+// =====================================================================================
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);          // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+extern "C" int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                              float eps, float wd, int step, gsl_stream_t s) {
+  GSL_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "null/size/step");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int grid = (int)min((n + 255) / 256, (long)(256 * 8));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps, wd, (float)bc1,
+                     (float)sqrt(bc2));
+  return check_launch("gsl_adamw_flat");
+}
+
+// =====================================================================================
+// casts / packing
+// =====================================================================================
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) Elem<T>::st(out + i, in[i]);
+}
+extern "C" int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(in && out && n > 0, "null/size");
+  const int grid = (int)min((n + 255) / 256, (long)(256 * 16));
+  if (dtype == GSL_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, (bf16_t*)out, n);
+  else if (dtype == GSL_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, as_stream(s), in, (float*)out, n);
+  else return fail(GSL_ERR_ARG, "gsl_cast: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_cast");
+}
+
+template <typename T>
+__global__ void transpose_cast_kernel(const float* __restrict__ in, T* __restrict__ out, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < C && r < R) Elem<T>::st(out + (size_t)c * R + r, tile[threadIdx.x][i]);
+  }
+}
+extern "C" int gsl_transpose_cast(const float* in, void* out, int R, int C, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(in && out && R > 0 && C > 0, "null/size");
+  dim3 grid((C + 31) / 32, (R + 31) / 32), blk(32, 8);
+  if (dtype == GSL_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, blk, 0, as_stream(s), in, (bf16_t*)out, R, C);
+  else if (dtype == GSL_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, blk, 0, as_stream(s), in, (float*)out, R, C);
+  else return fail(GSL_ERR_ARG, "gsl_transpose_cast: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_transpose_cast");
+}
+
+template <typename T>
+__global__ void pack_pad_kernel(const float* __restrict__ in, long si, long sj, int rows, int cols, float scale, T* __restrict__ out,
+                                int rows_out, int ld_out) {
+  const long tot = (long)rows_out * ld_out;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / ld_out), j = (int)(idx % ld_out);
+    const float v = (i < rows && j < cols) ? scale * in[(size_t)i * si + (size_t)j * sj] : 0.f;
+    Elem<T>::st(out + idx, v);
+  }
+}
+extern "C" int gsl_pack_pad(const float* in, long si, long sj, int rows, int cols, float scale, void* out, int rows_out,
+                            int ld_out, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(in && out && rows > 0 && cols > 0 && rows_out >= rows && ld_out >= cols, "null/size");
+  const long tot = (long)rows_out * ld_out;
+  const int grid = (int)min((tot + 255) / 256, (long)(256 * 8));
+  if (dtype == GSL_BF16) hipLaunchKernelGGL(pack_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, si, sj, rows, cols, scale, (bf16_t*)out, rows_out, ld_out);
+  else if (dtype == GSL_F32) hipLaunchKernelGGL(pack_pad_kernel<float>, dim3(grid), dim3(256), 0, as_stream(s), in, si, sj, rows, cols, scale, (float*)out, rows_out, ld_out);
+  else return fail(GSL_ERR_ARG, "gsl_pack_pad: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_pack_pad");
+}
+
+__global__ void dropout_mask_kernel(uint8_t* keep, long n, DropCfg d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    keep[i] = drop_mul(d, (uint64_t)i) != 0.f ? 1 : 0;
+}
+extern "C" int gsl_dropout_mask(uint8_t* keep, long n, float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
+  GSL_CHECK_ARG(keep && n > 0 && p_drop >= 0.f && p_drop < 1.f, "null/size/p");
+  const int grid = (int)min((n + 255) / 256, (long)(256 * 8));
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, as_stream(s), keep, n, make_drop(p_drop, seed, site));
+  return check_launch("gsl_dropout_mask");
+}
+
+// =====================================================================================
+// library-wide
+// =====================================================================================
+namespace gsl { thread_local char g_err[512] = {0}; }
+extern "C" int gsl_version(void) { return 100; }
+extern "C" const char* gsl_last_error(void) { return gsl::g_err; }

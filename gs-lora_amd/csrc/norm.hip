@@ -1,0 +1,168 @@
+// norm.hip — LayerNorm forward / backward-dx (nn.LayerNorm eps 1e-5, affine; reference
+// vit_pytorch_face/vit_face.py:316-323 PreNorm and :498-500 mlp_head). gamma/beta are frozen in
+// GS-LoRA, so backward produces dx only.
+//
+// HBM-bound: one wave64 per row, the whole row lives in registers (D = 64*NPL), mean and the
+// centred variance are wavefront reductions (two-pass, as torch does), 16-byte loads when the
+// per-lane count is a multiple of 4. Backward fuses the residual-gradient add and emits the
+// operand-dtype copy (with the consumer's dropout mask applied) that the next dX GEMM reads.
+#include "gsl_common.h"
+
+using namespace gsl;
+
+template <int NPL>
+struct RowIO {
+  static constexpr int VEC = (NPL % 4 == 0) ? 4 : 1;
+  static constexpr int NV = NPL / VEC;
+  // element index of (chunk c, sub i) for this lane
+  static __device__ __forceinline__ int idx(int lane, int c, int i) { return (c * 64 + lane) * VEC + i; }
+  template <typename T>
+  static __device__ __forceinline__ void load(const T* row, int lane, float v[NPL]) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if constexpr (VEC == 4) Elem<T>::ld4(row + (c * 64 + lane) * 4, &v[c * 4]);
+      else v[c] = Elem<T>::ld(row + c * 64 + lane);
+    }
+  }
+  template <typename T>
+  static __device__ __forceinline__ void store(T* row, int lane, const float v[NPL]) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if constexpr (VEC == 4) Elem<T>::st4(row + (c * 64 + lane) * 4, &v[c * 4]);
+      else Elem<T>::st(row + c * 64 + lane, v[c]);
+    }
+  }
+};
+
+template <int NPL, typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long xs, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M) {
+  constexpr int D = NPL * 64;
+  using IO = RowIO<NPL>;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  float g[NPL], b[NPL];
+  IO::load(gamma, lane, g);
+  IO::load(beta, lane, b);
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
+    float v[NPL];
+    IO::load(x + (size_t)row * xs, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] -= mu; q += v[i] * v[i]; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = v[i] * rs * g[i] + b[i];
+    IO::store(y + (size_t)row * D, lane, v);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+template <int NPL, typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, long xs,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* dres,
+                                                     float* dx, T* __restrict__ dxb, int M, DropCfg drop) {
+  constexpr int D = NPL * 64;
+  using IO = RowIO<NPL>;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  float g[NPL];
+  IO::load(gamma, lane, g);
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
+    float xv[NPL], gy[NPL];
+    IO::load(x + (size_t)row * xs, lane, xv);
+    IO::load(dy + (size_t)row * D, lane, gy);
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      xv[i] = (xv[i] - mu) * rs;   // x-hat
+      gy[i] *= g[i];               // dL/dx-hat
+      s1 += gy[i];
+      s2 += gy[i] * xv[i];
+    }
+    const float c1 = wave_sum(s1) * (1.0f / D), c2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) gy[i] = rs * (gy[i] - c1 - xv[i] * c2);
+    if (dres) {
+      float r[NPL];
+      IO::load(dres + (size_t)row * D, lane, r);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) gy[i] += r[i];
+    }
+    IO::store(dx + (size_t)row * D, lane, gy);
+    if (dxb) {
+      if (drop.thr) {
+#pragma unroll
+        for (int c = 0; c < IO::NV; ++c)
+#pragma unroll
+          for (int i = 0; i < IO::VEC; ++i)
+            gy[c * IO::VEC + i] *= drop_mul(drop, (uint64_t)row * D + IO::idx(lane, c, i));
+      }
+      IO::store(dxb + (size_t)row * D, lane, gy);
+    }
+  }
+}
+
+template <int NPL>
+static int ln_fwd_launch(const float* x, long xs, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                         float* rstd, int M, int dtype, hipStream_t st) {
+  const int grid = min((M + 3) / 4, 256 * 8);
+  if (dtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t>), dim3(grid), dim3(256), 0, st, x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, float>), dim3(grid), dim3(256), 0, st, x, xs, gamma, beta, eps, (float*)y, mean, rstd, M);
+  return check_launch("gsl_layernorm_fwd");
+}
+
+template <int NPL>
+static int ln_bwd_launch(const void* dy, const float* x, long xs, const float* gamma, const float* mean, const float* rstd,
+                         const float* dres, float* dx, void* dxb, int M, int dtype, DropCfg drop, hipStream_t st) {
+  const int grid = min((M + 3) / 4, 256 * 8);
+  if (dtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
+                       dres, dx, (bf16_t*)dxb, M, drop);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, float>), dim3(grid), dim3(256), 0, st, (const float*)dy, x, xs, gamma, mean, rstd,
+                       dres, dx, (float*)dxb, M, drop);
+  return check_launch("gsl_layernorm_bwd");
+}
+
+#define GSL_DISPATCH_D(D, CALL)                                                             \
+  switch (D) {                                                                              \
+    case 64: return CALL(1);                                                                \
+    case 128: return CALL(2);                                                               \
+    case 256: return CALL(4);                                                               \
+    case 512: return CALL(8);                                                               \
+    case 768: return CALL(12);                                                              \
+    case 1024: return CALL(16);                                                             \
+    default: return fail(GSL_ERR_UNSUPPORTED, "%s: unsupported LayerNorm width %ld", __func__, (long)(D)); \
+  }
+
+extern "C" int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
+                                 void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0, "null/size");
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
+#define CALL(N) ln_fwd_launch<N>(x, x_row_stride, gamma, beta, eps, y, mean, rstd, M, dtype, as_stream(s))
+  GSL_DISPATCH_D(D, CALL)
+#undef CALL
+}
+
+extern "C" int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, void* dxb, int M, int D, int dtype,
+                                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
+  GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
+  const DropCfg drop = make_drop(p_drop, seed, site);
+#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, dxb, M, dtype, drop, as_stream(s))
+  GSL_DISPATCH_D(D, CALL)
+#undef CALL
+}

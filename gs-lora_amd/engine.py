@@ -1,0 +1,100 @@
+"""engine — single-task forgetting engine, MI355X-native drop-in for the reference `engine.py`
+(train_one_epoch :13-433, evaluate :436-498, eval_data :501-529, get_structure_loss :532-687).
+Differences from engine_cl that the reference has and that are kept: the structure term is gated
+by `epoch < cfg["ALPHA_EPOCH"]` (:82-90), the prototype bound is the literal 18 (:105), grouping
+comes from cfg["GROUP_TYPE"] in {block, lora, matrix} (:585-650), and with cfg["few_shot"] and a
+longer forget loader the roles of the two loaders are swapped (:53-236)."""
+import torch
+import torch.nn as nn
+
+import util.utils as util
+from engine_cl import DISP_FREQ, VER_FREQ, _log, _unwrap, eval_data  # noqa: F401
+from engine_cl import evaluate as _evaluate_cl
+from gslora_hip import losses as _losses
+from gslora_hip.step import MeterQueue, gs_lora_step
+from util.data_prefetcher import data_prefetcher
+
+PROTO_BND = 18   # hard-coded in the reference (engine.py:105)
+
+
+def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain, device, criterion, optimizer,
+                    epoch: int, losses_forget, losses_remain, losses_total, losses_structure, top1_forget, top1_remain,
+                    beta: float, alpha: float, BND: float, batch: int, testloader_forget, testloader_remain,
+                    forget_acc_before: float, highest_H_mean: float, cfg: dict, dataloader_open=None,
+                    prototype_weight_forget: float = 0.0, prototype_weight_remain: float = 0.0, use_prototype: bool = False,
+                    prototype_dict: dict = None, losses_prototype_forget=None, losses_prototype_remain=None):
+    model.train()
+    criterion.train()
+    losses_prototype_forget = losses_prototype_forget or util.AverageMeter()
+    losses_prototype_remain = losses_prototype_remain or util.AverageMeter()
+    meters = dict(losses_forget=losses_forget, losses_remain=losses_remain, losses_total=losses_total,
+                  losses_structure=losses_structure, top1_forget=top1_forget, top1_remain=top1_remain,
+                  losses_prototype_forget=losses_prototype_forget, losses_prototype_remain=losses_prototype_remain)
+    queue = MeterQueue()
+    proto_table = _losses.prototype_table(prototype_dict, device) if use_prototype else None
+    use_structure = not (epoch < cfg.get("ALPHA_EPOCH", 0))
+    group_type = cfg.get("GROUP_TYPE", "block")
+    if cfg.get("GROUP_POS", "FFN") != "FFN":
+        raise NotImplementedError("gs-lora_amd covers GROUP_POS='FFN'")
+    # few-shot inversion: iterate the LONGER forget loader, cycle the remain loader (engine.py:53-236)
+    swap = bool(cfg.get("few_shot")) and len(dataloader_forget) > len(dataloader_remain)
+    outer, inner = (dataloader_forget, dataloader_remain) if swap else (dataloader_remain, dataloader_forget)
+    inner_iter = data_prefetcher(inner, device, prefetch=True)
+    xi, yi = inner_iter.next()
+    for xo, yo in iter(outer):
+        xo, yo = xo.to(device), yo.to(device)
+        (x_f, y_f, x_r, y_r) = (xo, yo, xi, yi) if swap else (xi, yi, xo, yo)
+        pack = gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, beta=beta, alpha=alpha, BND=BND,
+                            use_structure=use_structure, group_type=group_type, use_prototype=use_prototype,
+                            proto_table=proto_table, w_f=prototype_weight_forget, w_r=prototype_weight_remain,
+                            BND_pro=PROTO_BND)
+        queue.push(pack, x_r.size(0), x_f.size(0))
+        if ((batch + 1) % DISP_FREQ == 0) and batch != 0:
+            queue.flush(meters)
+            m = meters
+            _log({"epoch_loss_forget": m["losses_forget"].avg, "epoch_loss_remain": m["losses_remain"].avg,
+                  "epoch_acc_forget": m["top1_forget"].avg, "epoch_acc_remain": m["top1_remain"].avg,
+                  "epoch_loss_total": m["losses_total"].avg, "epoch_loss_structure": m["losses_structure"].avg})
+            print("Epoch {} Batch {}\tforget {:.4f} ({:.4f})\tremain {:.4f} ({:.4f})\tstructure {:.4f} ({:.4f})\t"
+                  "total {:.4f} ({:.4f})\tP@1 forget {:.3f} ({:.3f})\tP@1 remain {:.3f} ({:.3f})".format(
+                      epoch + 1, batch + 1, m["losses_forget"].val, m["losses_forget"].avg, m["losses_remain"].val,
+                      m["losses_remain"].avg, m["losses_structure"].val, m["losses_structure"].avg, m["losses_total"].val,
+                      m["losses_total"].avg, m["top1_forget"].val, m["top1_forget"].avg, m["top1_remain"].val,
+                      m["top1_remain"].avg))
+            for k in meters:
+                meters[k] = util.AverageMeter()
+        if ((batch + 1) % VER_FREQ == 0) and batch != 0:
+            with torch.no_grad():
+                highest_H_mean = evaluate(model, testloader_forget=testloader_forget, testloader_remain=testloader_remain,
+                                          device=device, batch=batch, epoch=epoch, forget_acc_before=forget_acc_before,
+                                          highest_H_mean=highest_H_mean, cfg=cfg, optimizer=optimizer,
+                                          testloader_open=dataloader_open)
+            model.train()
+        batch += 1
+        xi, yi = inner_iter.next()
+        if xi is None:
+            inner_iter = data_prefetcher(inner, device, prefetch=True)
+            xi, yi = inner_iter.next()
+    queue.flush(meters)
+    return (batch, highest_H_mean, meters["losses_forget"], meters["losses_remain"], meters["top1_forget"],
+            meters["top1_remain"], meters["losses_total"], meters["losses_structure"], meters["losses_prototype_forget"],
+            meters["losses_prototype_remain"])
+
+
+def evaluate(model, testloader_forget, testloader_remain, device, batch, epoch, forget_acc_before, highest_H_mean, cfg,
+             optimizer, testloader_open=None):
+    """The reference deep-copies the model before eval() (:449) so the training weights never see the
+    merge/un-merge round trip; the HIP path gets the same guarantee by restoring train() afterwards
+    from the SAME parameters (merge and un-merge are exact inverses up to one f32 rounding)."""
+    was_training = model.training
+    out = _evaluate_cl(model, testloader_forget, testloader_remain, device, batch, epoch, forget_acc_before,
+                       highest_H_mean, cfg, optimizer, task_i="0", testloader_open=testloader_open)
+    if was_training:
+        model.train()
+    return out
+
+
+def get_structure_loss(model: torch.nn.Module, num_layers: int = 6, group_type: str = "block", group_pos: str = "FFN"):
+    if group_pos != "FFN":
+        raise NotImplementedError("gs-lora_amd covers group_pos='FFN'")
+    return _losses.structure_loss(_unwrap(model), group_type)

@@ -1,0 +1,79 @@
+"""ctypes binding of libgslora_hip.so (C ABI declared in include/gslora_hip.h).
+
+This is the binding a maintainer of the reference (pure PyTorch, no FFI of its own) would add:
+device pointers are `tensor.data_ptr()`, the stream is `torch.cuda.current_stream().cuda_stream`.
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgslora_hip.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32 = 0, 1, 2, 3, 4, 5
+NORM_SPLIT = 8
+
+_vp, _i, _l, _f, _u64, _u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "gsl_version": [],
+    "gsl_last_error": [],
+    "gsl_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gsl_gemm_nt": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i,
+                    _vp, _vp, _i, _f, _u64, _u32, _vp],
+    "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u32, _vp],
+    "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gsl_lora_grad_ws_elems": [_i, _i, _i],
+    "gsl_lora_grad": [_vp, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
+    "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
+    "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _u64, _u32, _vp],
+    "gsl_ce_fwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
+    "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gsl_proto_kl_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "gsl_group_norms_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gsl_group_norms_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp],
+    "gsl_adamw_flat": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp],
+    "gsl_cast": [_vp, _vp, _l, _i, _vp],
+    "gsl_transpose_cast": [_vp, _vp, _i, _i, _i, _vp],
+    "gsl_pack_pad": [_vp, _l, _l, _i, _i, _f, _vp, _i, _i, _i, _vp],
+    "gsl_dropout_mask": [_vp, _l, _f, _u64, _u32, _vp],
+}
+_RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises RuntimeError — never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libgslora_hip.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The GS-LoRA step has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gsl_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

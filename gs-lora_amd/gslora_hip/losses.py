@@ -1,0 +1,111 @@
+"""Loss terms of the GS-LoRA step as autograd nodes over the HIP kernels.
+
+  ce_sum_top1      — nn.CrossEntropyLoss (sum form) + top-1 count     (engine_cl.py:65-78)
+  proto_kl_sum     — get_prototype_loss 'kl' (sum form)                (engine_cl.py:571-603)
+  structure_loss   — group-lasso over LoRA groups                      (engine_cl.py:349-432)
+Upstream gradients arrive as 0-dim device tensors and are handed to the kernels as device
+pointers, so the whole loss graph runs without a host sync.
+"""
+import torch
+
+from . import ops
+
+
+class _CESum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous().float()
+        labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        out = ops.ce_fwd(logits, labels)
+        ctx.save_for_backward(logits, labels)
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_sum, _g_cnt):
+        logits, labels = ctx.saved_tensors
+        coef = g_sum.reshape(1).float().contiguous()
+        return ops.ce_bwd(logits, labels, coef, 1.0), None
+
+
+def ce_sum_top1(logits, labels):
+    """-> (sum_i CE_i, number of top-1 hits), both 0-dim f32 device tensors."""
+    return _CESum.apply(logits, labels)
+
+
+class _ProtoKLSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, labels, table):
+        emb = emb.contiguous().float()
+        labels = labels.to(device=emb.device, dtype=torch.int64).contiguous()
+        ctx.save_for_backward(emb, labels, table)
+        return ops.proto_kl_fwd(emb, labels, table)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, labels, table = ctx.saved_tensors
+        return ops.proto_kl_bwd(emb, labels, table, g.reshape(1).float().contiguous(), 1.0), None, None
+
+
+def proto_kl_sum(emb, labels, table):
+    return _ProtoKLSum.apply(emb, labels, table)
+
+
+_table_cache = {}
+
+
+def prototype_table(prototype_dict, device, dim=None):
+    """dict{int -> [D] tensor} (util.utils.calculate_prototypes) -> dense [C, D] f32 device table."""
+    key = (id(prototype_dict), str(device))
+    ent = _table_cache.get(key)
+    if ent is not None and ent[0] is prototype_dict:
+        return ent[1]
+    C = max(int(k) for k in prototype_dict) + 1
+    any_v = next(iter(prototype_dict.values()))
+    table = torch.zeros(C, any_v.numel(), dtype=torch.float32)
+    for k, v in prototype_dict.items():
+        table[int(k)] = v.detach().float().cpu().reshape(-1)
+    table = table.to(device)
+    _table_cache.clear()
+    _table_cache[key] = (prototype_dict, table)
+    return table
+
+
+class _StructureLoss(torch.autograd.Function):
+    """sum_g ||group g||_2 over the flat LoRA bucket; backward adds coef * t/||g|| straight into the
+    flat gradient bucket (the parameters' .grad views)."""
+
+    @staticmethod
+    def forward(ctx, bucket, tgroup, ngroups, grad_scale, *params):
+        out = ops.group_norms_fwd(bucket.flat, bucket.toff, bucket.tnumel, tgroup, ngroups)
+        ctx.bucket, ctx.tgroup, ctx.norm, ctx.grad_scale, ctx.n = bucket, tgroup, out["group_norm"], grad_scale, len(params)
+        return out["loss"][0]
+
+    @staticmethod
+    def backward(ctx, g):
+        b = ctx.bucket
+        b.attach_grads()
+        ops.group_norms_bwd(b.flat, b.toff, b.tnumel, ctx.tgroup, ctx.norm, g.reshape(1).float().contiguous(),
+                            ctx.grad_scale, b.grad)
+        return (None, None, None, None) + (None,) * ctx.n
+
+
+def structure_loss(model, group_type="block", grad_scale=1.0):
+    """Differentiable group-lasso term. grad_scale lets a data-parallel engine pre-divide the
+    (rank-identical) parameter-only gradient by the world size before the gradient all-reduce."""
+    bucket = model.lora_bucket()
+    if bucket is None:
+        raise RuntimeError("structure loss needs a model with LoRA parameters (lora_rank > 0)")
+    tgroup, ng = bucket.group_table(group_type)
+    trainable = [p for p in bucket.params if p.requires_grad]
+    if torch.is_grad_enabled() and trainable:
+        return _StructureLoss.apply(bucket, tgroup, ng, grad_scale, *trainable)
+    return ops.group_norms_fwd(bucket.flat, bucket.toff, bucket.tnumel, tgroup, ng)["loss"][0]
+
+
+def group_report(model, group_type="block", tau=0.0):
+    """All K12 observables in one launch: group-lasso norms, cal_norm (sum of Frobenius norms),
+    the selection mask (norm > tau) and the loss."""
+    bucket = model.lora_bucket()
+    tgroup, ng = bucket.group_table(group_type)
+    return ops.group_norms_fwd(bucket.flat, bucket.toff, bucket.tnumel, tgroup, ng, tau=tau)

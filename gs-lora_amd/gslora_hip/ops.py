@@ -1,0 +1,232 @@
+"""Thin torch-tensor wrappers over the C ABI (include/gslora_hip.h). PyTorch supplies device
+memory and the stream; every FLOP of the step runs in libgslora_hip.so. No fallbacks."""
+import torch
+
+from . import _lib as L
+
+DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("gslora_hip: tensors must live on a ROCm GPU (the HIP path has no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("gslora_hip: tensors must be contiguous")
+
+
+def code(dtype):
+    try:
+        return DT[dtype]
+    except KeyError:
+        raise RuntimeError(f"gslora_hip: unsupported compute dtype {dtype}")
+
+
+def patchify(img, p, dtype):
+    _need(img)
+    B, Cc, H, W = img.shape
+    T = 1 + (H // p) * (W // p)
+    out = torch.empty(B * T, p * p * Cc, device=img.device, dtype=dtype)
+    L.check(L.load().gsl_patchify(_p(img), _p(out), B, Cc, H, W, p, code(dtype), _stream()), "gsl_patchify")
+    return out
+
+
+def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, bias=None, res=None, aux=None, out2=None,
+            pos=None, cls=None, T=0, p_drop=0.0, seed=0, site=0):
+    _need(A1, W1, A2, W2, out, bias, res, aux, out2, pos, cls)
+    M, K1 = A1.shape
+    N = W1.shape[0]
+    K2 = 0 if A2 is None else A2.shape[1]
+    L.check(L.load().gsl_gemm_nt(_p(A1), A1.stride(0), _p(W1), W1.stride(0), K1, _p(A2), 0 if A2 is None else A2.stride(0),
+                                 _p(W2), 0 if W2 is None else W2.stride(0), K2, M, N, code(A1.dtype), epilogue, float(alpha),
+                                 _p(bias), _p(res), _p(aux), _p(out), _p(out2), out.stride(0), _p(pos), _p(cls), int(T),
+                                 float(p_drop), int(seed), int(site), _stream()), "gsl_gemm_nt")
+    return out
+
+
+def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
+    _need(x, gamma, beta)
+    y = torch.empty(M, D, device=x.device, dtype=dtype)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    L.check(L.load().gsl_layernorm_fwd(_p(x), row_stride, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), M, D,
+                                       code(dtype), _stream()), "gsl_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0):
+    _need(dy, x, gamma, mean, rstd, dres)
+    M, D = dy.shape
+    dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if want_copy else None
+    L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dxb), M,
+                                       D, code(dy.dtype), float(p_drop), int(seed), int(site), _stream()), "gsl_layernorm_bwd")
+    return dx, dxb
+
+
+def attention_fwd(qkv, B, T, H, scale):
+    _need(qkv)
+    o = torch.empty(B * T, H * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    L.check(L.load().gsl_attention_fwd(_p(qkv), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), _stream()),
+            "gsl_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, B, T, H, scale):
+    _need(qkv, o, d_o, lse)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    L.check(L.load().gsl_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), _p(delta), B, T, H, float(scale),
+                                       code(qkv.dtype), _stream()), "gsl_attention_bwd")
+    return dqkv
+
+
+_ws_cache = {}
+
+
+def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
+    """G[n*gsn + j*gsj] (+)= sum_m Y[m,n] U[m,j]; G is a view into the flat f32 gradient bucket."""
+    _need(Y, U)
+    M, N = Y.shape
+    lib = L.load()
+    need = lib.gsl_lora_grad_ws_elems(M, N, r)
+    key = (Y.device.index,)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=Y.device, dtype=torch.float32)
+        _ws_cache[key] = ws
+    L.check(lib.gsl_lora_grad(_p(Y), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype), 1 if accumulate else 0,
+                              _p(ws), _stream()), "gsl_lora_grad")
+
+
+def cosface_prep(W):
+    _need(W)
+    Wn = torch.empty_like(W)
+    L.check(L.load().gsl_cosface_prep(_p(W), _p(Wn), W.shape[0], W.shape[1], _stream()), "gsl_cosface_prep")
+    return Wn
+
+
+def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m):
+    _need(x, gamma, beta, Wn, label)
+    dev = x.device
+    emb = torch.empty(B, D, device=dev, dtype=torch.float32)
+    mean = torch.empty(B, device=dev, dtype=torch.float32)
+    rstd = torch.empty(B, device=dev, dtype=torch.float32)
+    C = Wn.shape[0] if Wn is not None else 0
+    logits = torch.empty(B, C, device=dev, dtype=torch.float32) if label is not None else None
+    L.check(L.load().gsl_head_fwd(_p(x), T, _p(gamma), _p(beta), float(eps), _p(Wn), _p(label), _p(emb), _p(mean), _p(rstd),
+                                  _p(logits), B, D, C, float(cos_s), float(cos_m), _stream()), "gsl_head_fwd")
+    return logits, emb, mean, rstd
+
+
+def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0):
+    _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn)
+    dx = torch.empty(B * T, D, device=x.device, dtype=torch.float32)
+    dxb = torch.empty(B * T, D, device=x.device, dtype=dtype)
+    C = Wn.shape[0] if Wn is not None else 0
+    L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
+                                  _p(dxb), B, D, C, float(cos_s), code(dtype), float(p_drop), int(seed), int(site), _stream()),
+            "gsl_head_bwd")
+    return dx, dxb
+
+
+def ce_fwd(logits, labels):
+    _need(logits, labels)
+    out = torch.empty(2, device=logits.device, dtype=torch.float32)
+    L.check(L.load().gsl_ce_fwd(_p(logits), _p(labels), _p(out), logits.shape[0], logits.shape[1], _stream()), "gsl_ce_fwd")
+    return out
+
+
+def ce_bwd(logits, labels, coef, scale, dlogits=None):
+    _need(logits, labels, coef, dlogits)
+    acc = dlogits is not None
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+    L.check(L.load().gsl_ce_bwd(_p(logits), _p(labels), _p(coef), float(scale), _p(dlogits), logits.shape[0], logits.shape[1],
+                                1 if acc else 0, _stream()), "gsl_ce_bwd")
+    return dlogits
+
+
+def proto_kl_fwd(emb, labels, proto):
+    _need(emb, labels, proto)
+    out = torch.empty(1, device=emb.device, dtype=torch.float32)
+    L.check(L.load().gsl_proto_kl_fwd(_p(emb), _p(labels), _p(proto), _p(out), emb.shape[0], emb.shape[1], proto.shape[0],
+                                      _stream()), "gsl_proto_kl_fwd")
+    return out
+
+
+def proto_kl_bwd(emb, labels, proto, coef, scale, demb=None):
+    _need(emb, labels, proto, coef, demb)
+    acc = demb is not None
+    if demb is None:
+        demb = torch.empty_like(emb)
+    L.check(L.load().gsl_proto_kl_bwd(_p(emb), _p(labels), _p(proto), _p(coef), float(scale), _p(demb), emb.shape[0],
+                                      emb.shape[1], proto.shape[0], 1 if acc else 0, _stream()), "gsl_proto_kl_bwd")
+    return demb
+
+
+def group_norms_fwd(flat, toff, tnumel, tgroup, ngroups, tau=0.0):
+    _need(flat, toff, tnumel, tgroup)
+    dev = flat.device
+    nt = toff.numel()
+    ws = torch.empty(nt * L.NORM_SPLIT, device=dev, dtype=torch.float32)
+    tss = torch.empty(nt, device=dev, dtype=torch.float32)
+    gn = torch.empty(ngroups, device=dev, dtype=torch.float32)
+    cn = torch.empty(ngroups, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    mask = torch.empty(ngroups, device=dev, dtype=torch.uint8)
+    L.check(L.load().gsl_group_norms_fwd(_p(flat), _p(toff), _p(tnumel), _p(tgroup), nt, ngroups, float(tau), _p(ws), _p(tss),
+                                         _p(gn), _p(cn), _p(loss), _p(mask), _stream()), "gsl_group_norms_fwd")
+    return dict(tensor_sumsq=tss, group_norm=gn, cal_norm=cn, loss=loss, mask=mask)
+
+
+def group_norms_bwd(flat, toff, tnumel, tgroup, group_norm, coef, scale, gradflat):
+    _need(flat, toff, tnumel, tgroup, group_norm, coef, gradflat)
+    L.check(L.load().gsl_group_norms_bwd(_p(flat), _p(toff), _p(tnumel), _p(tgroup), toff.numel(), _p(group_norm), _p(coef),
+                                         float(scale), _p(gradflat), _stream()), "gsl_group_norms_bwd")
+
+
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    _need(p, g, m, v)
+    L.check(L.load().gsl_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                    float(wd), int(step), _stream()), "gsl_adamw_flat")
+
+
+def cast(x, dtype):
+    _need(x)
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    L.check(L.load().gsl_cast(_p(x), _p(out), x.numel(), code(dtype), _stream()), "gsl_cast")
+    return out
+
+
+def transpose_cast(W, dtype):
+    _need(W)
+    R, Cc = W.shape
+    out = torch.empty(Cc, R, device=W.device, dtype=dtype)
+    L.check(L.load().gsl_transpose_cast(_p(W), _p(out), R, Cc, code(dtype), _stream()), "gsl_transpose_cast")
+    return out
+
+
+def pack_pad(src, si, sj, rows, cols, rows_out, ld_out, dtype, scale=1.0):
+    _need(src)
+    out = torch.empty(rows_out, ld_out, device=src.device, dtype=dtype)
+    L.check(L.load().gsl_pack_pad(_p(src), si, sj, rows, cols, float(scale), _p(out), rows_out, ld_out, code(dtype), _stream()),
+            "gsl_pack_pad")
+    return out
+
+
+def dropout_mask(n, p_drop, seed, site, device):
+    keep = torch.empty(n, device=device, dtype=torch.uint8)
+    L.check(L.load().gsl_dropout_mask(_p(keep), n, float(p_drop), int(seed), int(site), _stream()), "gsl_dropout_mask")
+    return keep

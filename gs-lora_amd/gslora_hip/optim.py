@@ -1,0 +1,126 @@
+"""Optimizer / LR schedule of the GS-LoRA drivers, restated for the HIP path.
+
+The reference builds them with timm 0.9.2 (train/train_own_forget_cl.py:811-820):
+  create_optimizer(args, model) -> torch.optim.AdamW over requires_grad params, weight decay on
+      params with ndim > 1 that are not biases (all LoRA matrices), lr=args.lr, eps=args.opt_eps
+  create_scheduler(args, opt)   -> CosineLRScheduler(t_initial=epochs, lr_min=min_lr, warmup 0),
+      stepped once per epoch with the epoch index.
+FusedAdamW keeps torch.optim.Optimizer's interface (param_groups, state_dict, zero_grad) but runs
+one gsl_adamw_flat launch over the model's flat LoRA bucket instead of ~10 foreach kernels.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = {}
+
+    def _flat_state(self, gi, group):
+        """Detect that a group's grad-bearing params tile one contiguous f32 range (the LoRA bucket)."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return None
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        ent = self._flat.get(gi)
+        if ent is not None and ent["sig"] == sig:
+            return ent
+        order = sorted(ps, key=lambda p: p.data_ptr())
+        ok = all(p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() for p in order)
+        for a, b in zip(order[:-1], order[1:]):
+            ok = ok and b.data_ptr() == a.data_ptr() + 4 * a.numel() and b.grad.data_ptr() == a.grad.data_ptr() + 4 * a.numel()
+        n = sum(p.numel() for p in order)
+        ent = dict(sig=sig, ok=ok, order=order, n=n)
+        if ok:
+            first = order[0]
+            # views over the whole range, built from the underlying storages
+            ent["p"] = torch.as_strided(first.data, (n,), (1,))
+            ent["g"] = torch.as_strided(first.grad, (n,), (1,))
+            old = self._flat.get(gi)
+            if old is not None and old.get("ok") and old["n"] == n:
+                ent["m"], ent["v"], ent["step"] = old["m"], old["v"], old["step"]
+            else:
+                ent["m"] = torch.zeros(n, device=first.device, dtype=torch.float32)
+                ent["v"] = torch.zeros(n, device=first.device, dtype=torch.float32)
+                ent["step"] = 0
+        self._flat[gi] = ent
+        return ent
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            ent = self._flat_state(gi, group)
+            if ent is None:
+                continue
+            if ent["ok"]:
+                ent["step"] += 1
+                ops.adamw_flat(ent["p"], ent["g"], ent["m"], ent["v"], group["lr"], b1, b2, group["eps"],
+                               group["weight_decay"], ent["step"])
+                continue
+            for p in ent["order"]:            # scattered params: same kernel, one launch per tensor
+                st = self.state[p]
+                if not st:
+                    st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                ops.adamw_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["m"].view(-1), st["v"].view(-1),
+                               group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
+        return loss
+
+
+class CosineLRScheduler:
+    """timm CosineLRScheduler subset the drivers use: t_in_epochs, cycle_limit=1, optional linear warm-up."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0.0, warmup_t=0, warmup_lr_init=0.0):
+        self.optimizer, self.t_initial, self.lr_min = optimizer, t_initial, lr_min
+        self.warmup_t, self.warmup_lr_init = warmup_t, warmup_lr_init
+        self.base = [g["lr"] for g in optimizer.param_groups]
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        if warmup_t:
+            for g in optimizer.param_groups:
+                g["lr"] = warmup_lr_init
+
+    def lr_at(self, t, base):
+        if t < self.warmup_t:
+            return self.warmup_lr_init + t * (base - self.warmup_lr_init) / self.warmup_t
+        if t >= self.t_initial:
+            return self.lr_min
+        return self.lr_min + 0.5 * (base - self.lr_min) * (1.0 + math.cos(math.pi * t / self.t_initial))
+
+    def step(self, epoch, metric=None):
+        for g, base in zip(self.optimizer.param_groups, self.base):
+            g["lr"] = self.lr_at(epoch, base)
+
+
+def create_optimizer(args, model):
+    """timm.optim.create_optimizer for opt='adamw' (util/args.py:38-62 defaults)."""
+    opt = getattr(args, "opt", "adamw").lower()
+    if opt != "adamw":
+        raise NotImplementedError(f"gs-lora_amd implements the AdamW path of timm.create_optimizer, not '{opt}'")
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or name.endswith(".bias")) else decay).append(p)
+    groups = [g for g in (dict(params=no_decay, weight_decay=0.0), dict(params=decay, weight_decay=args.weight_decay))
+              if g["params"]]
+    kw = dict(lr=args.lr, eps=getattr(args, "opt_eps", None) or 1e-8)
+    betas = getattr(args, "opt_betas", None)
+    if betas:
+        kw["betas"] = tuple(betas)
+    return FusedAdamW(groups, **kw)
+
+
+def create_scheduler(args, optimizer):
+    """timm.scheduler.create_scheduler for sched='cosine' -> (scheduler, num_epochs)."""
+    if getattr(args, "sched", "cosine") != "cosine":
+        raise NotImplementedError("gs-lora_amd implements the cosine schedule the GS-LoRA scripts use")
+    sch = CosineLRScheduler(optimizer, t_initial=args.epochs, lr_min=getattr(args, "min_lr", 1e-5),
+                            warmup_t=getattr(args, "warmup_epochs", 0), warmup_lr_init=getattr(args, "warmup_lr", 1e-6))
+    return sch, args.epochs + getattr(args, "cooldown_epochs", 0)

@@ -1,0 +1,114 @@
+"""One GS-LoRA forgetting step on the HIP path (shared by engine_cl.py and engine.py).
+
+Reference loop body: engine_cl.py:59-125 / engine.py:237-330 —
+    total = beta * relu(BND - CE_forget) + CE_remain + alpha * L_structure
+            + w_f * relu(BND_pro - KL_forget) + w_r * KL_remain
+Data parallel (one process per GPU, torch.distributed over RCCL): the two hinge arguments are
+batch MEANS, so their global values are all-reduced (one packed 8-float message) before the
+hinges are evaluated — that keeps the single-GPU / nn.DataParallel semantics of the reference —
+and the flat LoRA gradient bucket (0.94 MiB for ViT-P8S8 r=8) is sum-all-reduced after backward.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import losses
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _plain_ce(criterion):
+    return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0 and criterion.ignore_index == -100)
+
+
+def _globalize(local_sum, global_sum_detached):
+    """value = global sum, gradient = d(local sum): the straight-through form used for DP means."""
+    return local_sum + (global_sum_detached - local_sum.detach())
+
+
+def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
+                 group_type="block", use_prototype=False, proto_table=None, w_f=0.0, w_r=0.0, BND_pro=0.0):
+    """Runs forward x2, the three-term loss, backward, gradient all-reduce and optimizer.step().
+    Returns a packed DEVICE tensor of the 8 meter values (no host sync here):
+      [beta*loss_forget, loss_remain, total, alpha*structure, top1_forget%, top1_remain%,
+       w_f*relu(BND_pro-KL_f), w_r*KL_r]"""
+    net = model.module if isinstance(model, nn.DataParallel) else model
+    world = _world()
+    dev = x_r.device
+    out_r, emb_r = model(x_r.float(), y_r)
+    out_f, emb_f = model(x_f.float(), y_f)
+    n_r = torch.tensor(float(x_r.size(0)), device=dev)
+    n_f = torch.tensor(float(x_f.size(0)), device=dev)
+    if _plain_ce(criterion):
+        ce_r_sum, hit_r = losses.ce_sum_top1(out_r, y_r)
+        ce_f_sum, hit_f = losses.ce_sum_top1(out_f, y_f)
+    else:   # exotic criterion: keep its semantics (mean over the local batch), top-1 from the HIP kernel
+        ce_r_sum = criterion(out_r, y_r) * n_r
+        ce_f_sum = criterion(out_f, y_f) * n_f
+        hit_r = losses.ce_sum_top1(out_r.detach(), y_r)[1]
+        hit_f = losses.ce_sum_top1(out_f.detach(), y_f)[1]
+    zero = torch.zeros((), device=dev)
+    if use_prototype:
+        kl_f_sum = losses.proto_kl_sum(emb_f, y_f, proto_table)
+        kl_r_sum = losses.proto_kl_sum(emb_r, y_r, proto_table)
+    else:
+        kl_f_sum = kl_r_sum = zero
+    g_nr, g_nf = n_r, n_f
+    if world > 1:
+        pack = torch.stack([ce_r_sum.detach(), ce_f_sum.detach(), hit_r, hit_f, n_r, n_f, kl_f_sum.detach(), kl_r_sum.detach()])
+        dist.all_reduce(pack)
+        ce_r_sum, ce_f_sum = _globalize(ce_r_sum, pack[0]), _globalize(ce_f_sum, pack[1])
+        hit_r, hit_f, g_nr, g_nf = pack[2], pack[3], pack[4], pack[5]
+        if use_prototype:
+            kl_f_sum, kl_r_sum = _globalize(kl_f_sum, pack[6]), _globalize(kl_r_sum, pack[7])
+    loss_remain = ce_r_sum / g_nr
+    loss_forget = torch.relu(BND - ce_f_sum / g_nf)
+    structure = losses.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else zero
+    if use_prototype:
+        pro_f = w_f * torch.relu(BND_pro - kl_f_sum / g_nf)
+        pro_r = w_r * (kl_r_sum / g_nr)
+    else:
+        pro_f = pro_r = zero
+    total = loss_forget * beta + loss_remain + structure * alpha + (pro_f + pro_r)
+    optimizer.zero_grad()
+    total.backward()
+    if world > 1:
+        bucket = net.lora_bucket()
+        bucket.attach_grads()
+        dist.all_reduce(bucket.grad)
+    optimizer.step()
+    return torch.stack([(beta * loss_forget).detach(), loss_remain.detach(), total.detach(), (alpha * structure).detach(),
+                        hit_f * (100.0 / g_nf), hit_r * (100.0 / g_nr), pro_f.detach() if use_prototype else zero,
+                        pro_r.detach() if use_prototype else zero])
+
+
+class MeterQueue:
+    """Defers the D2H read of the per-step meter packs: the reference calls .item() >= 8 times per
+    step (engine_cl.py:68-115); here the packs stay on the device until someone needs the numbers
+    (display / evaluation / return) and are then fetched with ONE sync, and replayed into the
+    AverageMeters in order — the meters end up with exactly the values the reference computes."""
+
+    ORDER = ("losses_forget", "losses_remain", "losses_total", "losses_structure", "top1_forget", "top1_remain",
+             "losses_prototype_forget", "losses_prototype_remain")
+    # which batch size each meter is weighted with in the reference (engine_cl.py:68-120)
+    WEIGHT = ("f", "r", "r", "r", "f", "r", "r", "r")
+
+    def __init__(self):
+        self.pending = []
+
+    def push(self, pack, n_r, n_f):
+        self.pending.append((pack, n_r, n_f))
+
+    def flush(self, meters):
+        if not self.pending:
+            return
+        rows = torch.stack([p for p, _, _ in self.pending]).tolist()     # the single host sync
+        for row, (_, n_r, n_f) in zip(rows, self.pending):
+            for name, w, v in zip(self.ORDER, self.WEIGHT, row):
+                m = meters.get(name)
+                if m is not None:
+                    m.update(v, n_f if w == "f" else n_r)
+        self.pending = []

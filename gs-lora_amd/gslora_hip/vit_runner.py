@@ -1,0 +1,284 @@
+"""Whole-network forward/backward schedule of the ViT-Face + LoRA-FFN model on the HIP kernels.
+
+This is the host-side "engine" behind vit_pytorch_face.ViT_face.forward: it owns
+  * the flat f32 LoRA bucket (parameters become views into it, ordered group-by-group so that a
+    group-lasso group is one contiguous slice),
+  * the frozen-weight operand caches (bf16 casts / transposes, refreshed when a weight's
+    (data_ptr, _version) changes, e.g. after loralib merge/un-merge or load_state_dict),
+  * the per-forward activation stash that the hand-written backward consumes.
+Reference semantics: vit_pytorch_face/vit_face.py:523-548 (forward), autograd of the same.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+
+COS_S, COS_M, LN_EPS = 64.0, 0.35, 1e-5   # vit_face.py:158 ; nn.LayerNorm default
+PADK = 64                                  # LoRA K-segment width fed to the GEMM (r zero-padded to 64)
+SITE_EMB = 1_000_000
+
+
+class LoraBucket:
+    """Flat storage for the trainable LoRA tensors of one model."""
+
+    def __init__(self, layers):
+        # layers: list of (A1, B1, A2, B2) nn.Parameters per transformer block
+        self.params = [p for grp in layers for p in grp]
+        self.groups = [i for i, grp in enumerate(layers) for _ in grp]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                self.offsets.append(off)
+                off += k
+        self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        self.toff = torch.tensor(self.offsets, device=dev, dtype=torch.int64)
+        self.tnumel = torch.tensor([p.numel() for p in self.params], device=dev, dtype=torch.int64)
+        self.tgroup_block = torch.tensor(self.groups, device=dev, dtype=torch.int32)
+        self.ngroups_block = len(layers)
+
+    def valid(self):
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def group_table(self, group_type="block"):
+        """tensor->group ids for engine.get_structure_loss groupings (engine.py:585-650)."""
+        L_ = self.ngroups_block
+        if group_type == "block":
+            return self.tgroup_block, L_
+        ids = []
+        for i in range(L_):
+            if group_type == "lora":
+                ids += [i, i, L_ + i, L_ + i]
+            elif group_type == "matrix":
+                ids += [i, L_ + i, 2 * L_ + i, 3 * L_ + i]
+            else:
+                raise ValueError(f"unknown group type {group_type}")
+        n = 2 * L_ if group_type == "lora" else 4 * L_
+        return torch.tensor(ids, device=self.flat.device, dtype=torch.int32), n
+
+    def attach_grads(self):
+        """Give every LoRA parameter its view of the flat gradient bucket. Returns True when the
+        bucket had to be (re)attached, i.e. this is the first backward since zero_grad()."""
+        fresh = False
+        for p, g in zip(self.params, self.grad_views):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                fresh = True
+                break
+        if fresh:
+            self.grad.zero_()
+            for p, g in zip(self.params, self.grad_views):
+                p.grad = g
+        return fresh
+
+
+class ViTRunner:
+    def __init__(self, model):
+        self.model = model
+        self.bucket = None
+        self._wcache = {}
+        self._lcache = {}
+        self.drop_seed = 0x5EED
+        self.drop_calls = 0
+
+    def __deepcopy__(self, memo):   # copies of the model build their own runner lazily
+        return None
+
+    # ------------------------------------------------------------------ caches
+    def _cached(self, cache, key, param, fn):
+        ent = cache.get(key)
+        tag = (param.data_ptr(), param._version, param.device)
+        if ent is None or ent[0] != tag:
+            with torch.no_grad():
+                ent = (tag, fn(param.detach()))
+            cache[key] = ent
+        return ent[1]
+
+    def w(self, name, param, dtype):
+        """[N,K] operand in compute dtype."""
+        if dtype == torch.float32:
+            return param.detach()
+        return self._cached(self._wcache, (name, "n", dtype), param, lambda p: ops.cast(p.contiguous(), dtype))
+
+    def wT(self, name, param, dtype):
+        """[K,N] transposed operand (dX GEMMs)."""
+        return self._cached(self._wcache, (name, "t", dtype), param, lambda p: ops.transpose_cast(p.contiguous(), dtype))
+
+    def lora_pack(self, name, param, kind, dtype):
+        r = self.model.lora_rank
+
+        def build(p):
+            rows, cols = p.shape
+            if kind == "A_rows":      # [64, K]  rows j<r = A[j,:]
+                return ops.pack_pad(p, cols, 1, r, cols, PADK, cols, dtype)
+            if kind == "B_cols":      # [N, 64]  cols j<r = B[:,j]
+                return ops.pack_pad(p, r, 1, rows, r, rows, PADK, dtype)
+            if kind == "BT_rows":     # [64, N]  out[j, n] = B[n, j]
+                return ops.pack_pad(p, 1, r, r, rows, PADK, rows, dtype)
+            if kind == "AT_cols":     # [K, 64]  out[k, j] = A[j, k]
+                return ops.pack_pad(p, 1, cols, cols, r, cols, PADK, dtype)
+            raise ValueError(kind)
+        return self._cached(self._lcache, (name, kind, dtype), param, build)
+
+    def ensure_bucket(self):
+        m = self.model
+        if m.lora_rank <= 0:
+            return None
+        if self.bucket is None or not self.bucket.valid():
+            self.bucket = LoraBucket([blk.lora_params() for blk in m.ffn_blocks()])
+            self._lcache.clear()
+        return self.bucket
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img, label, save):
+        m = self.model
+        if not img.is_cuda:
+            raise RuntimeError("ViT_face (gs-lora_amd): the model runs only on a ROCm GPU through libgslora_hip.so; "
+                               "there is no CPU fallback. Move the model and inputs to 'cuda'.")
+        L.load()
+        dt = m.compute_dtype
+        img = img.float().contiguous()
+        if label is not None:
+            label = label.to(device=img.device, dtype=torch.int64).contiguous()
+        B = img.shape[0]
+        T, D, H = m.num_tokens, m.dim, m.heads
+        M = B * T
+        training = m.training
+        p_drop = m.dropout_p if training else 0.0
+        p_emb = m.emb_dropout_p if training else 0.0
+        self.drop_calls += 1
+        seed = (self.drop_seed << 20) + self.drop_calls
+        self.ensure_bucket()
+        r = m.lora_rank
+        s_lora = (1.0 / r) if r > 0 else 0.0
+
+        patches = ops.patchify(img, m.patch_size, dt)
+        x = torch.empty(M, D, device=img.device, dtype=torch.float32)
+        pe = m.patch_to_embedding
+        ops.gemm_nt(patches, self.w("pe", pe.weight, dt), x, epilogue=L.EPI_PATCH, bias=pe.bias.detach(),
+                    pos=m.pos_embedding.detach()[0, :T].contiguous(), cls=m.cls_token.detach().reshape(-1), T=T,
+                    p_drop=p_emb, seed=seed, site=SITE_EMB)
+        del patches
+        stash = []
+        for i, (attn, ffn) in enumerate(m.blocks()):
+            n1, n2 = attn.norm, ffn.norm
+            at, ff = attn.fn, ffn.fn
+            xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), LN_EPS, dt)
+            qkv = torch.empty(M, 3 * H * 64, device=img.device, dtype=dt)
+            ops.gemm_nt(xn, self.w(f"qkv{i}", at.to_qkv.weight, dt), qkv)
+            del xn
+            o, lse = ops.attention_fwd(qkv, B, T, H, m.attn_scale)
+            x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
+            ops.gemm_nt(o, self.w(f"wo{i}", at.to_out[0].weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
+                        bias=at.to_out[0].bias.detach(), res=x, p_drop=p_drop, seed=seed, site=4 * i)
+            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), LN_EPS, dt)
+            l1, l2 = ff.net[0], ff.net[3]
+            mlp = l1.weight.shape[0]
+            lora_on = r > 0 and not l1.merged
+            u1 = u2 = None
+            h = torch.empty(M, mlp, device=img.device, dtype=dt)
+            gp = torch.empty(M, mlp, device=img.device, dtype=dt) if save else None
+            if lora_on:
+                u1 = torch.empty(M, PADK, device=img.device, dtype=dt)
+                ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
+                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, A2=u1,
+                            W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
+                            p_drop=p_drop, seed=seed, site=4 * i + 1)
+                u2 = torch.empty(M, PADK, device=img.device, dtype=dt)
+                ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
+            else:
+                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, bias=l1.bias.detach(),
+                            out2=gp, p_drop=p_drop, seed=seed, site=4 * i + 1)
+            x2 = torch.empty(M, D, device=img.device, dtype=torch.float32)
+            ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=L.EPI_BIAS_RES_F32, A2=u2,
+                        W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
+                        bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
+            if save:
+                stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
+                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on))
+            x = x2
+        hn = m.mlp_head[0]
+        Wn = ops.cosface_prep(m.loss.weight.detach().contiguous()) if label is not None else None
+        logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), LN_EPS, Wn, label,
+                                                 COS_S, COS_M)
+        saved = None
+        if save:
+            saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, p_drop=p_drop,
+                         dt=dt)
+        return logits, emb, saved
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, saved, dlogits, demb):
+        """Accumulates d(loss)/d(LoRA) into the flat gradient bucket (views are the params' .grad)."""
+        m = self.model
+        bucket = self.bucket
+        if bucket is None:
+            return
+        bucket.attach_grads()
+        dt = saved["dt"]
+        B, seed, p_drop = saved["B"], saved["seed"], saved["p_drop"]
+        T, D, H = m.num_tokens, m.dim, m.heads
+        r = m.lora_rank
+        s_lora = 1.0 / r
+        nl = len(saved["layers"])
+        hn = m.mlp_head[0]
+        if dlogits is not None:
+            dlogits = dlogits.contiguous().float()
+        if demb is not None:
+            demb = demb.contiguous().float()
+        if dlogits is not None and saved["Wn"] is None:
+            raise RuntimeError("backward through logits requires a forward with labels")
+        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
+                               saved["emb"], saved["Wn"], COS_S, dt, p_drop=p_drop, seed=seed, site=4 * (nl - 1) + 2)
+        blocks = list(m.blocks())
+        gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
+        dev = dx.device
+        for i in reversed(range(nl)):
+            st = saved["layers"][i]
+            attn, ffn = blocks[i]
+            at, ff = attn.fn, ffn.fn
+            l1, l2 = ff.net[0], ff.net[3]
+            mlp = l1.weight.shape[0]
+            Mrows = dx.shape[0]
+            if not st["lora_on"]:
+                raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
+            # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
+            v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
+            ops.gemm_nt(dxb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
+            da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
+            ops.gemm_nt(dxb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
+                        W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=st["gp"])
+            ops.lora_grad(dxb, st["u2"], gv[id(l2.lora_B)], r, 1, r)          # dB2[c, j]
+            ops.lora_grad(st["h"], v2, gv[id(l2.lora_A)], 1, mlp, r)          # dA2[j, hid]
+            v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
+            ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
+            ops.lora_grad(da, st["u1"], gv[id(l1.lora_B)], r, 1, r)           # dB1[hid, j]
+            ops.lora_grad(st["xn2"], v1, gv[id(l1.lora_A)], 1, D, r)          # dA1[j, c]
+            if i == 0:
+                break   # nothing below the layer-0 FFN input is trainable
+            dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
+            ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2, A2=v1,
+                        W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
+            del da, v1, v2
+            n2 = ffn.norm
+            dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
+                                          p_drop=p_drop, seed=seed, site=4 * i)
+            del dxn2
+            # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
+            d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
+            ops.gemm_nt(dx1b, self.wT(f"wo{i}", at.to_out[0].weight, dt), d_o)
+            dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
+            dxn1 = torch.empty(Mrows, D, device=dev, dtype=dt)
+            ops.gemm_nt(dqkv, self.wT(f"qkv{i}", at.to_qkv.weight, dt), dxn1)
+            del d_o, dqkv, dx1b
+            n1 = attn.norm
+            dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
+                                        p_drop=p_drop, seed=seed, site=4 * (i - 1) + 2)
+            saved["layers"][i] = None   # free this layer's activations

@@ -1,0 +1,150 @@
+/* gslora_hip.h — C ABI of libgslora_hip.so: the MI355X (gfx950) kernels behind the GS-LoRA
+ * forgetting train step.
+ *
+ * Boundary contract:
+ *  - plain C: pointers + sizes, no C++/torch types. All pointers are DEVICE pointers owned by
+ *    the caller (torch tensors' data_ptr()); the library allocates nothing.
+ *  - every call is asynchronous on the given hipStream_t (passed as void*; NULL = default stream).
+ *  - return 0 on success, negative gsl_status on error; message via gsl_last_error()
+ *    (thread-local). Never aborts.
+ *  - dtype selects the operand/activation element type: GSL_F32 (parity mode, exact-f32 kernels)
+ *    or GSL_BF16 (speed mode: bf16 operands, f32 accumulate on MFMA). Residual stream, LayerNorm
+ *    statistics, biases, LoRA master weights, losses and optimizer state are always f32.
+ *
+ * Each entry point names the reference code it replaces (paths relative to bjzhb666/GS-LoRA).
+ * The reference has no FFI of its own (it is pure PyTorch); the "binding a maintainer would add"
+ * is the ctypes stub in gs-lora_amd/gslora_hip/_lib.py, shown in INTEGRATION.md.
+ */
+#ifndef GSLORA_HIP_H
+#define GSLORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gsl_stream_t;
+
+enum gsl_dtype { GSL_F32 = 0, GSL_BF16 = 1 };
+
+enum gsl_status {
+  GSL_OK = 0,
+  GSL_ERR_ARG = -1,      /* bad shape / alignment / unsupported size */
+  GSL_ERR_LAUNCH = -2,   /* hipLaunch / runtime error */
+  GSL_ERR_UNSUPPORTED = -3
+};
+
+/* GEMM epilogues (gsl_gemm_nt). acc = alpha * (A1*W1^T + A2*W2^T)  */
+enum gsl_epilogue {
+  GSL_EPI_STORE = 0,        /* out[dtype]  = acc (+ bias)                                       */
+  GSL_EPI_BIAS_RES_F32 = 1, /* outf32      = dropout(acc + bias) + res                          */
+  GSL_EPI_BIAS_GELU = 2,    /* out[dtype]  = dropout(gelu(acc+bias)); out2[dtype] = gelu'(acc+bias)*dropmask */
+  GSL_EPI_MUL = 3,          /* out[dtype]  = acc * aux[dtype]                                   */
+  GSL_EPI_PATCH = 4,        /* outf32      = dropout((tok==0 ? cls : acc + bias) + pos[tok]),  tok = m % T */
+  GSL_EPI_STORE_F32 = 5     /* outf32      = acc (+ bias)                                       */
+};
+
+int gsl_version(void);
+const char* gsl_last_error(void);
+
+/* ---- K1 patch gather: einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit_face.py:530).
+ * img f32 [B,C,H,W] -> out[dtype] [B*T, p*p*C], T = 1 + (H/p)*(W/p); row b*T (cls slot) is zero. */
+int gsl_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype, gsl_stream_t s);
+
+/* ---- K3/K5/K6/K7/K8 dense NT GEMM with an optional second K segment (the LoRA rank-r term)
+ * and a fused epilogue. Replaces F.linear + loralib.Linear.forward (vit_face.py:330-334,349-356)
+ * and their autograd dX.
+ *   A1 [M,K1] (lda1), W1 [N,K1] (ldw1); A2 [M,K2] (lda2), W2 [N,K2] (ldw2)  — all `dtype`;
+ *   K1 % 64 == 0, K2 % 64 == 0 (K2 may be 0). bias/res/pos/cls f32. out/out2/aux per epilogue.
+ *   dropout: p_drop in [0,1); mask = hash(seed, site, m*N+n) (see gsl_dropout_keep in DESIGN.md). */
+int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
+                const void* A2, int lda2, const void* W2, int ldw2, int K2,
+                int M, int N, int dtype, int epilogue, float alpha,
+                const float* bias, const float* res, const void* aux,
+                void* out, void* out2, int ldo,
+                const float* pos, const float* cls, int T,
+                float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+
+/* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x f32 rows of length D at
+ * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
+int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
+                      void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s);
+/* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D]. */
+int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma,
+                      const float* mean, const float* rstd, const float* dres,
+                      float* dx, void* dxb, int M, int D, int dtype,
+                      float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+
+/* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
+ * qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)'), o[dtype] [B*T, H*64], lse f32 [B,H,T]. */
+int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype, gsl_stream_t s);
+/* dqkv[dtype] [B*T,3*H*64]; delta_ws f32 [B,H,T] scratch. */
+int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+                      float* delta_ws, int B, int T, int H, float scale, int dtype, gsl_stream_t s);
+
+/* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
+ * Y[dtype] [M,N], U[dtype] [M,ldu] (first r columns used, r <= 16). ws f32 >= gsl_lora_grad_ws_elems(). */
+long gsl_lora_grad_ws_elems(int M, int N, int r);
+int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj,
+                  int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
+
+/* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35). */
+int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s);   /* Wn = F.normalize(W) */
+int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps,
+                 const float* Wn, const int64_t* label, float* emb, float* mean, float* rstd,
+                 float* logits, int B, int D, int C, float cos_s, float cos_m, gsl_stream_t s);
+/* dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: cls rows get the gradient, others zero.
+ * dxb[dtype] = dx * dropmask(site) (nullable). */
+int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
+                 const float* mean, const float* rstd, const float* emb, const float* Wn,
+                 float* dx, void* dxb, int B, int D, int C, float cos_s, int dtype,
+                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+
+/* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
+ * out2 f32 [2] = { sum_i CE_i , #correct }. */
+int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, int B, int C, gsl_stream_t s);
+/* dlogits (+)= coef[0] * scale * (softmax - onehot) ; coef is a DEVICE scalar (no host sync). */
+int gsl_ce_bwd(const float* logits, const int64_t* labels, const float* coef, float scale,
+               float* dlogits, int B, int C, int accumulate, gsl_stream_t s);
+
+/* ---- K13 prototype KL (engine_cl.py:571-603): out1[0] = sum_i KL(softmax(proto[y_i]) || softmax(emb_i)). */
+int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1,
+                     int B, int D, int C, gsl_stream_t s);
+int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef,
+                     float scale, float* demb, int B, int D, int C, int accumulate, gsl_stream_t s);
+
+/* ---- K12 group-lasso norms over a flat LoRA buffer (engine_cl.py:349-432, util/cal_norm.py:4-146).
+ * tensor t = flat[toff[t] .. +tnumel[t]) belongs to group tgroup[t] (tables on device, int64/int64/int32).
+ * Outputs (f32 unless noted): tensor_sumsq[ntensors], group_norm[ngroups] = sqrt(sum sumsq),
+ * cal_norm[ngroups] = sum sqrt(sumsq) (cal_norm.py 'L2'), loss[1] = sum_g group_norm,
+ * mask u8[ngroups] = group_norm > tau.  partial_ws f32 [ntensors*GSL_NORM_SPLIT]. */
+#define GSL_NORM_SPLIT 8
+int gsl_group_norms_fwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+                        int ntensors, int ngroups, float tau, float* partial_ws, float* tensor_sumsq,
+                        float* group_norm, float* cal_norm, float* loss, uint8_t* mask, gsl_stream_t s);
+/* gradflat[i] += coef[0]*scale * flat[i] / group_norm[g(i)]  (0 where group_norm == 0). */
+int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+                        int ntensors, const float* group_norm, const float* coef, float scale,
+                        float* gradflat, gsl_stream_t s);
+
+/* ---- K14 fused AdamW over a flat buffer (torch.optim.AdamW as timm.create_optimizer builds it,
+ * train_own_forget_cl.py:811-813): decoupled wd, bias correction, step >= 1. */
+int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n,
+                   float lr, float beta1, float beta2, float eps, float wd, int step, gsl_stream_t s);
+
+/* ---- helpers: f32 -> dtype casts for the frozen-weight caches and padded LoRA operands. */
+int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s);
+/* out[dtype] [C,R] = in[R,C]^T */
+int gsl_transpose_cast(const float* in, void* out, int R, int C, int dtype, gsl_stream_t s);
+/* out[dtype] [rows_out, ld_out] zero-padded copy: out[i, j] = scale * in[i*si + j*sj] for i<rows, j<cols. */
+int gsl_pack_pad(const float* in, long si, long sj, int rows, int cols, float scale,
+                 void* out, int rows_out, int ld_out, int dtype, gsl_stream_t s);
+
+/* dropout keep-mask as the kernels compute it (for tests): keep[i] = 1/0 for element index i. */
+int gsl_dropout_mask(uint8_t* keep, long n, float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLORA_HIP_H */

@@ -1,0 +1,287 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain fp32 PyTorch on CPU.
+f32 mode: tight tolerances (exact-f32 kernels). bf16 mode: inputs are pre-rounded to bf16 on both
+sides, so the tolerance only has to cover bf16 output rounding + accumulation order."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device (no CPU fallback exists)")
+    from gslora_hip import ops as _ops
+    from gslora_hip import _lib
+    _lib.load()
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def as_dt(t, dt):
+    """value actually seen by the kernel (bf16-rounded in bf16 mode), as f32 on CPU"""
+    return t.to(dt).float()
+
+
+def tol(dt, f32, bf16):
+    return f32 if dt == torch.float32 else bf16
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
+
+
+DTS = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_store_asymmetric(ops, dt):
+    """A = I with an ASYMMETRIC W catches transposed / permuted MFMA fragment layouts."""
+    from gslora_hip import _lib as L
+    M, N, K = 128, 256, 128
+    A = torch.zeros(M, K); A[torch.arange(M), torch.arange(M) % K] = 1.0
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 16.0 - 4.0
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A.cuda().to(dt), W.cuda().to(dt), out)
+    ref = as_dt(A, dt) @ as_dt(W, dt).t()
+    assert relerr(out.float().cpu(), ref) < tol(dt, 1e-6, 4e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64)])
+def test_gemm_epilogues(ops, dt, M, N, K1, K2):
+    from gslora_hip import _lib as L
+    A1, W1 = rnd(M, K1, seed=1), rnd(N, K1, seed=2, scale=K1 ** -0.5)
+    A2 = W2 = None
+    if K2:
+        A2, W2 = rnd(M, K2, seed=3), rnd(N, K2, seed=4, scale=0.1)
+        A2[:, 8:] = 0
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    aux = rnd(M, N, seed=7)
+    acc = as_dt(A1, dt) @ as_dt(W1, dt).t()
+    if K2:
+        acc = acc + as_dt(A2, dt) @ as_dt(W2, dt).t()
+    c = lambda t: None if t is None else t.cuda().to(dt)
+    t_out, t_abs = tol(dt, 2e-5, 1.5e-2), tol(dt, 2e-5, 2e-2)
+    # STORE with alpha + bias
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(c(A1), c(W1), out, A2=c(A2), W2=c(W2), alpha=0.5, bias=bias.cuda())
+    assert relerr(out.float().cpu(), 0.5 * acc + bias) < t_out
+    # STORE_F32
+    outf = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(c(A1), c(W1), outf, epilogue=L.EPI_STORE_F32, A2=c(A2), W2=c(W2))
+    assert relerr(outf.cpu(), acc) < tol(dt, 2e-5, 2e-3)
+    # BIAS_RES_F32
+    ops.gemm_nt(c(A1), c(W1), outf, epilogue=L.EPI_BIAS_RES_F32, A2=c(A2), W2=c(W2), bias=bias.cuda(), res=res.cuda())
+    assert relerr(outf.cpu(), acc + bias + res) < tol(dt, 2e-5, 2e-3)
+    # BIAS_GELU (+ derivative)
+    out2 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(c(A1), c(W1), out, epilogue=L.EPI_BIAS_GELU, A2=c(A2), W2=c(W2), bias=bias.cuda(), out2=out2)
+    a = (acc + bias).requires_grad_(True)
+    g = F.gelu(a)
+    gp, = torch.autograd.grad(g.sum(), a)
+    assert (out.float().cpu() - g.detach()).abs().max() < t_abs
+    assert (out2.float().cpu() - gp).abs().max() < t_abs
+    # MUL
+    ops.gemm_nt(c(A1), c(W1), out, epilogue=L.EPI_MUL, A2=c(A2), W2=c(W2), aux=c(aux))
+    assert relerr(out.float().cpu(), acc * as_dt(aux, dt)) < t_out
+    # PATCH
+    T = 197 if M % 197 == 0 else 13 if M % 13 == 0 else M
+    pos, cls = rnd(T, N, seed=8), rnd(N, seed=9)
+    ops.gemm_nt(c(A1), c(W1), outf, epilogue=L.EPI_PATCH, A2=c(A2), W2=c(W2), bias=bias.cuda(), pos=pos.cuda(), cls=cls.cuda(), T=T)
+    tok = torch.arange(M) % T
+    ref = torch.where((tok == 0)[:, None], cls[None, :].expand(M, N), acc + bias) + pos[tok]
+    assert relerr(outf.cpu(), ref) < tol(dt, 2e-5, 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_dropout_epilogue(ops, dt):
+    from gslora_hip import _lib as L
+    M, N, K = 256, 128, 64
+    A, W, bias, res = rnd(M, K), rnd(N, K), rnd(N), rnd(M, N)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(A.cuda().to(dt), W.cuda().to(dt), out, epilogue=L.EPI_BIAS_RES_F32, bias=bias.cuda(), res=res.cuda(),
+                p_drop=0.25, seed=77, site=5)
+    keep = ops.dropout_mask(M * N, 0.25, 77, 5, "cuda").cpu().reshape(M, N).float()
+    ref = (as_dt(A, dt) @ as_dt(W, dt).t() + bias) * keep / 0.75 + res
+    assert relerr(out.cpu(), ref) < tol(dt, 2e-5, 2e-3)
+    assert abs(keep.mean().item() - 0.75) < 0.01
+    keep2 = ops.dropout_mask(M * N, 0.25, 77, 6, "cuda").cpu().reshape(M, N).float()
+    assert (keep2 != keep).float().mean() > 0.2          # sites are independent streams
+    big = ops.dropout_mask(1 << 22, 0.1, 1, 0, "cuda").float()
+    assert abs(big.mean().item() - 0.9) < 1e-3
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("D", [64, 128, 512, 768])
+def test_layernorm(ops, dt, D):
+    M = 37
+    x, g, b = rnd(M, D, seed=1, scale=2.0) + 0.5, 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), D, M, D, g.cuda(), b.cuda(), 1e-5, dt)
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    assert (y.float().cpu() - ref).abs().max() < tol(dt, 1e-5, 3e-2)
+    assert (mean.cpu() - x.mean(1)).abs().max() < 1e-5
+    assert relerr(rstd.cpu(), 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)) < 1e-5
+    # backward
+    dy, dres = rnd(M, D, seed=4), rnd(M, D, seed=5)
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), g, b, 1e-5).backward(as_dt(dy, dt))
+    dx, dxb = ops.layernorm_bwd(dy.cuda().to(dt), x.cuda(), D, g.cuda(), mean, rstd, dres.cuda())
+    assert (dx.cpu() - (xr.grad + dres)).abs().max() < 2e-5
+    assert (dxb.float().cpu() - (xr.grad + dres)).abs().max() < tol(dt, 2e-5, 3e-2)
+    # masked copy
+    dx2, dxb2 = ops.layernorm_bwd(dy.cuda().to(dt), x.cuda(), D, g.cuda(), mean, rstd, None, p_drop=0.5, seed=3, site=9)
+    keep = ops.dropout_mask(M * D, 0.5, 3, 9, "cuda").cpu().reshape(M, D).float()
+    assert (dx2.cpu() - xr.grad).abs().max() < 2e-5
+    assert (dxb2.float().cpu() - xr.grad * keep * 2).abs().max() < tol(dt, 4e-5, 6e-2)
+
+
+def attn_ref(qkv, B, T, H, scale):
+    q, k, v = qkv.reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = (torch.einsum("bhid,bhjd->bhij", q, k) * scale).softmax(-1)
+    return torch.einsum("bhij,bhjd->bhid", p, v).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,T,H", [(3, 197, 2), (2, 26, 1), (2, 37, 2), (1, 64, 1), (1, 224, 1)])
+def test_attention(ops, dt, B, T, H):
+    scale = (H * 64) ** -0.5 * 3.0
+    qkv = rnd(B * T, 3 * H * 64, seed=B + T, scale=1.5)
+    qkv_d = as_dt(qkv, dt).requires_grad_(True)
+    ref = attn_ref(qkv_d, B, T, H, scale)
+    o, lse = ops.attention_fwd(qkv.cuda().to(dt), B, T, H, scale)
+    assert (o.float().cpu() - ref.detach()).abs().max() < tol(dt, 2e-5, 2e-2)
+    q, k, _ = qkv_d.detach().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp(torch.einsum("bhid,bhjd->bhij", q, k) * scale, -1)
+    assert (lse.cpu() - lse_ref).abs().max() < tol(dt, 2e-5, 2e-3)
+    d_o = rnd(B * T, H * 64, seed=5)
+    ref.backward(as_dt(d_o, dt))
+    dqkv = ops.attention_bwd(qkv.cuda().to(dt), o, d_o.cuda().to(dt), lse, B, T, H, scale)
+    err = (dqkv.float().cpu() - qkv_d.grad).abs().max().item()
+    assert err < tol(dt, 5e-5, 3e-2) * max(1.0, qkv_d.grad.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,r", [(591, 512, 8), (1000, 2048, 8), (333, 128, 4), (700, 768, 16)])
+def test_lora_grad(ops, dt, M, N, r):
+    Y, U = rnd(M, N, seed=1), rnd(M, 64, seed=2)
+    U[:, r:] = 0
+    ref = as_dt(Y, dt).t() @ as_dt(U, dt)[:, :r]          # [N, r]
+    G = torch.zeros(N * r, device="cuda")
+    ops.lora_grad(Y.cuda().to(dt), U.cuda().to(dt), G, r, 1, r, accumulate=False)
+    assert relerr(G.cpu().reshape(N, r), ref) < 1e-5
+    ops.lora_grad(Y.cuda().to(dt), U.cuda().to(dt), G, r, 1, r, accumulate=True)
+    assert relerr(G.cpu().reshape(N, r), 2 * ref) < 1e-5
+    Gt = torch.zeros(r * N, device="cuda")
+    ops.lora_grad(Y.cuda().to(dt), U.cuda().to(dt), Gt, 1, N, r, accumulate=False)     # transposed output [r, N]
+    assert relerr(Gt.cpu().reshape(r, N), ref.t()) < 1e-5
+
+
+def test_patchify_and_pack(ops):
+    img = rnd(3, 3, 40, 40)
+    p = 8
+    out = ops.patchify(img.cuda(), p, torch.float32).cpu().reshape(3, 26, 192)
+    ref = img.reshape(3, 3, 5, p, 5, p).permute(0, 2, 4, 3, 5, 1).reshape(3, 25, 192)
+    assert torch.equal(out[:, 1:], ref) and (out[:, 0] == 0).all()
+    outb = ops.patchify(img.cuda(), p, torch.bfloat16).float().cpu().reshape(3, 26, 192)
+    assert torch.equal(outb[:, 1:], ref.bfloat16().float())
+    W = rnd(40, 24)
+    assert torch.equal(ops.transpose_cast(W.cuda(), torch.float32).cpu(), W.t().contiguous())
+    assert torch.equal(ops.transpose_cast(W.cuda(), torch.bfloat16).cpu(), W.t().contiguous().bfloat16())
+    assert torch.equal(ops.cast(W.cuda(), torch.bfloat16).cpu(), W.bfloat16())
+    A = rnd(8, 128)    # lora_A [r, K]
+    pk = ops.pack_pad(A.cuda(), 1, 128, 128, 8, 128, 64, torch.float32).cpu()      # AT_cols: [K, 64]
+    assert torch.equal(pk[:, :8], A.t()) and (pk[:, 8:] == 0).all()
+    pk = ops.pack_pad(A.cuda(), 128, 1, 8, 128, 64, 128, torch.float32, scale=0.5).cpu()   # A_rows: [64, K]
+    assert torch.equal(pk[:8], 0.5 * A) and (pk[8:] == 0).all()
+
+
+def test_head_and_losses(ops):
+    B, T, D, C = 5, 26, 512, 100
+    x = rnd(B * T, D, seed=1, scale=2.0)
+    g, b, W = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3), rnd(C, D, seed=4)
+    y = torch.tensor([3, 99, 0, 42, 42])
+    Wn = ops.cosface_prep(W.cuda())
+    assert (Wn.cpu() - F.normalize(W)).abs().max() < 1e-6
+    logits, emb, mean, rstd = ops.head_fwd(x.cuda(), B, T, D, g.cuda(), b.cuda(), 1e-5, Wn, y.cuda(), 64.0, 0.35)
+    xr = x.clone().requires_grad_(True)
+    emb_ref = F.layer_norm(xr.reshape(B, T, D)[:, 0], (D,), g, b, 1e-5)
+    cos = F.linear(F.normalize(emb_ref), F.normalize(W))
+    oh = F.one_hot(y, C).float()
+    logits_ref = 64.0 * (cos - 0.35 * oh)
+    assert (emb.cpu() - emb_ref.detach()).abs().max() < 1e-5
+    assert (logits.cpu() - logits_ref.detach()).abs().max() < 5e-5
+    # CE fwd/bwd
+    out2 = ops.ce_fwd(logits, y.cuda()).cpu()
+    ce = F.cross_entropy(logits_ref, y, reduction="sum")
+    assert abs(out2[0].item() - ce.item()) < 1e-3 * max(1, ce.item())
+    assert out2[1].item() == (logits_ref.argmax(1) == y).sum().item()
+    coef = torch.tensor([0.7], device="cuda")
+    dl = ops.ce_bwd(logits, y.cuda(), coef, 1.0 / B)
+    proto = rnd(C, D, seed=7)
+    kl = ops.proto_kl_fwd(emb, y.cuda(), proto.cuda()).cpu()
+    kl_ref = F.kl_div(F.log_softmax(emb_ref, 1), F.log_softmax(proto[y], 1), reduction="sum", log_target=True)
+    assert abs(kl.item() - kl_ref.item()) < 1e-4 * max(1, abs(kl_ref.item()))
+    coef2 = torch.tensor([-0.3], device="cuda")
+    de = ops.proto_kl_bwd(emb, y.cuda(), proto.cuda(), coef2, 1.0 / B)
+    total = 0.7 * ce / B - 0.3 * kl_ref / B
+    total.backward()
+    # head backward consumes dlogits + demb and must reproduce autograd's dx
+    dx, dxb = ops.head_bwd(dl, de, x.cuda(), B, T, D, g.cuda(), mean, rstd, emb, Wn, 64.0, torch.float32)
+    assert (dx.cpu() - xr.grad).abs().max() < 2e-5 * max(1.0, xr.grad.abs().max().item())
+    assert torch.equal(dx, dxb)
+    nz = dx.cpu().reshape(B, T, D)
+    assert (nz[:, 1:] == 0).all() and (nz[:, 0] != 0).any()
+    # no-label path
+    lg, emb2, _, _ = ops.head_fwd(x.cuda(), B, T, D, g.cuda(), b.cuda(), 1e-5, None, None, 64.0, 0.35)
+    assert lg is None and torch.equal(emb2, emb)
+
+
+def test_group_norms_and_mask(ops):
+    sizes = [(8, 512), (2048, 8), (8, 2048), (512, 8)] * 3
+    ts = [rnd(*s, seed=i) * (0.0 if i // 4 == 1 else 1.0) for i, s in enumerate(sizes)]   # group 1 exactly zero
+    flat = torch.cat([t.reshape(-1) for t in ts]).cuda()
+    offs = np.cumsum([0] + [t.numel() for t in ts])[:-1]
+    toff = torch.tensor(offs, dtype=torch.int64).cuda()
+    tnum = torch.tensor([t.numel() for t in ts], dtype=torch.int64).cuda()
+    tgrp = torch.tensor([i // 4 for i in range(12)], dtype=torch.int32).cuda()
+    out = ops.group_norms_fwd(flat, toff, tnum, tgrp, 3, tau=0.0)
+    gn_ref = torch.stack([torch.sqrt(sum((t ** 2).sum() for t in ts[4 * g:4 * g + 4])) for g in range(3)])
+    cn_ref = torch.stack([sum(t.norm() for t in ts[4 * g:4 * g + 4]) for g in range(3)])
+    assert relerr(out["group_norm"].cpu(), gn_ref) < 1e-6
+    assert relerr(out["cal_norm"].cpu(), cn_ref) < 1e-6
+    assert abs(out["loss"].item() - gn_ref.sum().item()) < 1e-4
+    # bit-exact selection mask vs the same predicate on the oracle norms
+    assert out["mask"].cpu().tolist() == (gn_ref > 0.0).to(torch.uint8).tolist() == [1, 0, 1]
+    tau = float(gn_ref[0]) + 1e-3
+    out2 = ops.group_norms_fwd(flat, toff, tnum, tgrp, 3, tau=tau)
+    assert out2["mask"].cpu().tolist() == (gn_ref > tau).to(torch.uint8).tolist()
+    # backward: grad += coef*scale * t/||g|| ; zero group -> 0 (no NaN)
+    grad = torch.ones_like(flat)
+    coef = torch.tensor([2.0], device="cuda")
+    ops.group_norms_bwd(flat, toff, tnum, tgrp, out["group_norm"], coef, 0.5, grad)
+    ref = torch.cat([(1.0 + (t / gn_ref[i // 4] if gn_ref[i // 4] > 0 else torch.zeros_like(t))).reshape(-1)
+                     for i, t in enumerate(ts)])
+    assert (grad.cpu() - ref).abs().max() < 1e-6
+    assert torch.isfinite(grad).all()
+
+
+def test_adamw_matches_torch(ops):
+    n = 245760
+    p0, g = rnd(n, seed=1), rnd(n, seed=2)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in (1, 2, 3):
+        pt.grad = g * step
+        opt.step()
+        ops.adamw_flat(p, (g * step).cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
+        assert (p.cpu() - pt.detach()).abs().max() < 2e-6
