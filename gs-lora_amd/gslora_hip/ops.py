@@ -41,12 +41,25 @@ def patchify(img, p, dtype):
     return out
 
 
+# optional per-kernel timing hook used by bench.py: {tag: [(start_event, end_event), ...]} recorded on the
+# stream the kernel is launched on (torch's current stream == the hipStream_t handed to the C ABI)
+PROFILE = None
+
+
 def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, bias=None, res=None, aux=None, out2=None,
-            pos=None, cls=None, T=0, p_drop=0.0, seed=0, site=0):
+            pos=None, cls=None, T=0, p_drop=0.0, seed=0, site=0, tag=None):
     _need(A1, W1, A2, W2, out, bias, res, aux, out2, pos, cls)
     M, K1 = A1.shape
     N = W1.shape[0]
     K2 = 0 if A2 is None else A2.shape[1]
+    if PROFILE is not None and tag in PROFILE:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        gemm_nt(A1, W1, out, epilogue=epilogue, A2=A2, W2=W2, alpha=alpha, bias=bias, res=res, aux=aux, out2=out2, pos=pos,
+                cls=cls, T=T, p_drop=p_drop, seed=seed, site=site, tag=None)
+        ev[1].record()
+        PROFILE[tag].append(ev)
+        return out
     L.check(L.load().gsl_gemm_nt(_p(A1), A1.stride(0), _p(W1), W1.stride(0), K1, _p(A2), 0 if A2 is None else A2.stride(0),
                                  _p(W2), 0 if W2 is None else W2.stride(0), K2, M, N, code(A1.dtype), epilogue, float(alpha),
                                  _p(bias), _p(res), _p(aux), _p(out), _p(out2), out.stride(0), _p(pos), _p(cls), int(T),

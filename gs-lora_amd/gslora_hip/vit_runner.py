@@ -190,7 +190,7 @@ class ViTRunner:
                 ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, A2=u1,
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
-                            p_drop=p_drop, seed=seed, site=4 * i + 1)
+                            p_drop=p_drop, seed=seed, site=4 * i + 1, tag="ffn1")
                 u2 = torch.empty(M, PADK, device=img.device, dtype=dt)
                 ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
