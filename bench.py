@@ -44,14 +44,14 @@ def build_model(dtype, dropout, device):
     return m.to(device).set_compute_dtype(dtype).train()
 
 
-def cpu_baseline(batch=16, steps=3):
+def cpu_baseline(batch=16, steps=2):
     """The CPU oracle (a port of the reference step; the reference's Python cannot travel to the GPU
     box) timed on the host cores: fp32, B=16+16, full-size model, dropout omitted (the reference spends
     ~26 % of its CPU time in bernoulli_, so this baseline is FASTER than the reference itself)."""
     from oracle import gslora_oracle as O
     from oracle import recipe
     cfg = recipe.cfg_full()
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)     # more threads than this only adds fork/join overhead at B=16
     torch.set_num_threads(cores)
     st = recipe.make_state(cfg)
     xr = torch.tensor(recipe.make_images(cfg, batch, seed=1)); yr = torch.tensor(recipe.make_labels(cfg, batch, seed=1, hi=80))

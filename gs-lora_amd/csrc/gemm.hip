@@ -50,19 +50,23 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
     if constexpr (EPI == GSL_EPI_STORE) Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
     else Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
-    float r[4];
+    float r[4], dm[4];
     Elem<float>::ld4(e.res + off, r);
+    drop_mul4(e.drop, lin, dm);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (v[i] + e.bias[n + i]) * drop_mul(e.drop, lin + i) + r[i];
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] + e.bias[n + i]) * dm[i] + r[i];
     Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
-    float g[4];
+    float g[4], dm[4];
+    drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a = v[i] + e.bias[n + i];
-      const float dm = drop_mul(e.drop, lin + i);
-      v[i] = gelu_f(a) * dm;
-      g[i] = gelu_grad_f(a) * dm;
+      float ga, gpa;
+      if constexpr (sizeof(T) == 2) gelu_pair_fast(a, ga, gpa);      // bf16 speed mode
+      else { ga = gelu_f(a); gpa = gelu_grad_f(a); }                  // f32 parity mode: exact erf
+      v[i] = ga * dm[i];
+      g[i] = gpa * dm[i];
     }
     Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
     if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g);
@@ -74,10 +78,12 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
     Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_PATCH) {
     const int tok = m % e.T;
+    float dm[4];
+    drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float base = (tok == 0) ? e.cls[n + i] : (v[i] + e.bias[n + i]);
-      v[i] = (base + e.pos[(size_t)tok * e.N + n + i]) * drop_mul(e.drop, lin + i);
+      v[i] = (base + e.pos[(size_t)tok * e.N + n + i]) * dm[i];
     }
     Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   }

@@ -100,10 +100,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     if (dxb) {
       if (drop.thr) {
 #pragma unroll
-        for (int c = 0; c < IO::NV; ++c)
+        for (int c = 0; c < IO::NV; ++c) {
+          if constexpr (IO::VEC == 4) {
+            float dm[4];
+            drop_mul4(drop, (uint64_t)row * D + IO::idx(lane, c, 0), dm);
 #pragma unroll
-          for (int i = 0; i < IO::VEC; ++i)
-            gy[c * IO::VEC + i] *= drop_mul(drop, (uint64_t)row * D + IO::idx(lane, c, i));
+            for (int i = 0; i < 4; ++i) gy[c * 4 + i] *= dm[i];
+          } else {
+            gy[c] *= drop_mul(drop, (uint64_t)row * D + IO::idx(lane, c, 0));
+          }
+        }
       }
       IO::store(dxb + (size_t)row * D, lane, gy);
     }
