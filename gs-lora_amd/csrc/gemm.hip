@@ -12,6 +12,8 @@
 // double-buffered (one barrier per K tile). Block ids are remapped so that the blocks sharing an
 // A row-panel run on the same XCD (private L2).
 // f32 path (parity mode): 64x64x16 tile, 4x4 outputs per thread, sequential fmaf over k.
+#include <stdlib.h>
+
 #include "gsl_common.h"
 
 using namespace gsl;
@@ -180,6 +182,101 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------ bf16 MFMA kernel, direct-to-LDS staging
+// Same tile / fragment / epilogue structure, but the global->LDS copy is the gfx950 LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). The DMA destination is
+// wave-uniform base + lane*16 B, so the XOR swizzle is applied on the SOURCE address (lane -> (row, cpos)
+// reads global chunk cpos ^ (row & 7)) and again on the fragment read — the same involution.
+// NBUF = 1: one 32 KB stage, two barriers per K tile, relies on >= 3 resident blocks per CU for overlap.
+// NBUF = 2: 64 KB, next tile's DMA in flight during the MFMAs, one barrier per K tile.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int EPI, int NBUF>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                             const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                             const bf16_t* __restrict__ A2, int lda2,
+                                                             const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NBUF][2][BM * BK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+
+  auto issue = [&](int kt, int buf) {
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wave * 4 + i;                 // 8-row block: one 1 KB DMA per wave-instruction
+      const int row = rb * 8 + lrow;
+      const int c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(&smem[buf][0][rb * 8 * BK]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(&smem[buf][1][rb * 8 * BK]), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][0][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][1][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if constexpr (NBUF == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt has landed (only its DMAs are outstanding here)
+      __syncthreads();                                     // ... for every wave; and compute(kt-1) is finished everywhere
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
@@ -229,8 +326,17 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
-                       (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+    const char* ev = getenv("GSL_GEMM_VARIANT");   // development knob: 0 register-staged, 1 glds x1, 2 glds x2
+    const int variant = ev ? atoi(ev) : 2;
+    if (variant == 0)
+      hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+    else if (variant == 1)
+      hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 1>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 2>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
   } else {
     const int nblk = ((e.M + 63) / 64) * ((e.N + 63) / 64);
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,

@@ -62,6 +62,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 ent["step"] += 1
                 ops.adamw_flat(ent["p"], ent["g"], ent["m"], ent["v"], group["lr"], b1, b2, group["eps"],
                                group["weight_decay"], ent["step"])
+                for p in ent["order"]:      # the kernel wrote through raw pointers: tell torch (and the
+                    torch.autograd.graph.increment_version(p)   # runner's operand caches) the data changed
                 continue
             for p in ent["order"]:            # scattered params: same kernel, one launch per tensor
                 st = self.state[p]
@@ -70,6 +72,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 ops.adamw_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["m"].view(-1), st["v"].view(-1),
                                group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
+                torch.autograd.graph.increment_version(p)
         return loss
 
 
