@@ -327,7 +327,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     const char* ev = getenv("GSL_GEMM_VARIANT");   // development knob: 0 register-staged, 1 glds x1, 2 glds x2
-    const int variant = ev ? atoi(ev) : 2;
+    const int variant = ev ? atoi(ev) : (e.N <= 64 ? 2 : 1);   // measured: x1 wins on the wide GEMMs (3 blocks/CU), x2 on N=64
     if (variant == 0)
       hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
                          (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);

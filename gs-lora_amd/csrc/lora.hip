@@ -17,6 +17,7 @@ using namespace gsl;
 // partial slabs, then a fixed-order reduction that also applies the output strides.
 // =====================================================================================
 constexpr int LG_ROWS = 32;  // rows of U staged per LDS fill
+constexpr int LG_FAN = 32;   // splits summed per thread in the first reduction level
 
 template <typename T> struct LgVec;
 template <> struct LgVec<bf16_t> {
@@ -37,13 +38,19 @@ template <> struct LgVec<float> {
   }
 };
 
+// block = 256 threads = CG column groups x RP row phases (RP = 256 / CG in {1,2,4}); the RP phases walk
+// interleaved rows of the block's row range and are combined through LDS in a fixed order.
 template <typename T, int R>
 __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restrict__ Y, const T* __restrict__ U, int ldu,
-                                                                float* __restrict__ part, int M, int N, int rows_per_split) {
+                                                                float* __restrict__ part, int M, int N, int rows_per_split,
+                                                                int CG) {
   constexpr int V = LgVec<T>::V;
   __shared__ float us[LG_ROWS][R];
-  const int ncol = N / V;                       // column groups
-  const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // (RP-1) * CG * V * R floats
+  const int ncol = N / V;
+  const int RP = blockDim.x / CG;
+  const int cgl = threadIdx.x % CG, phase = threadIdx.x / CG;
+  const int cg = blockIdx.x * CG + cgl;
   const bool active = cg < ncol;
   const int split = blockIdx.y;
   const int r0 = split * rows_per_split, r1 = min(M, r0 + rows_per_split);
@@ -61,8 +68,8 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
     }
     __syncthreads();
     if (active) {
-#pragma unroll 4
-      for (int rr = 0; rr < nr; ++rr) {
+#pragma unroll 2
+      for (int rr = phase; rr < nr; rr += RP) {
         float y[V];
         LgVec<T>::ld(Y + (size_t)(rb + rr) * N + (size_t)cg * V, y);
 #pragma unroll
@@ -74,7 +81,28 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
       }
     }
   }
-  if (active) {
+  // combine the row phases: phases 1..RP-1 park their accumulators in LDS, phase 0 adds them in order
+  if (RP > 1) {
+    __syncthreads();
+    if (phase > 0) {
+      float* dst = red + ((size_t)(phase - 1) * CG + cgl) * (V * R);
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) dst[i * R + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (phase == 0) {
+      for (int ph = 1; ph < RP; ++ph) {
+        const float* src = red + ((size_t)(ph - 1) * CG + cgl) * (V * R);
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+          for (int j = 0; j < R; ++j) acc[i][j] += src[i * R + j];
+      }
+    }
+  }
+  if (active && phase == 0) {
     float* p = part + ((size_t)split * N + (size_t)cg * V) * R;
 #pragma unroll
     for (int i = 0; i < V; ++i)
@@ -83,31 +111,53 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
   }
 }
 
+// level 1: thread (idx, sb) sums LG_FAN consecutive splits  -> part2[sb][idx]
+__global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ part2,
+                                                                int NR, int nsplit) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NR) return;
+  const int s0 = blockIdx.y * LG_FAN, s1 = min(nsplit, s0 + LG_FAN);
+  float s = 0.f;
+  for (int sp = s0; sp < s1; ++sp) s += part[(size_t)sp * NR + idx];
+  part2[(size_t)blockIdx.y * NR + idx] = s;
+}
+// level 2: fixed-order sum of the level-1 slabs, apply output strides (+ accumulate)
 template <int R>
-__global__ void lora_grad_reduce_kernel(const float* __restrict__ part, float* G, long gsn, long gsj, int N, int r,
-                                        int nsplit, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over N*R
+__global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __restrict__ part2, float* G, long gsn, long gsj,
+                                                                int N, int r, int nslab, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * R) return;
   const int n = idx / R, j = idx % R;
   if (j >= r) return;
   float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * N * R + idx];   // fixed order
+  for (int k = 0; k < nslab; ++k) s += part2[(size_t)k * N * R + idx];
   float* g = G + (size_t)n * gsn + (size_t)j * gsj;
   *g = accumulate ? (*g + s) : s;
 }
 
-static inline int lg_nsplit(int M, int N, int V) {
-  const int bx = (N / V + 255) / 256;
-  int target = (256 * 4) / (bx > 0 ? bx : 1);      // ~4 blocks per CU in total
-  int nsplit = (M + 63) / 64;                      // at least 64 rows per split
+static inline void lg_plan(int M, int N, int V, int R, int& CG, int& bx, int& nsplit, int& rps) {
+  const int ncol = N / V;
+  CG = ncol >= 256 ? 256 : ((ncol > 64 || R > 8) ? 128 : 64);   // keeps the phase-combine LDS <= 48 KB
+  bx = (ncol + CG - 1) / CG;
+  int target = 512 / bx;                    // ~2 blocks per CU in total
+  if (target < 1) target = 1;
+  nsplit = (M + 127) / 128;                 // at least 128 rows per split
   if (nsplit > target) nsplit = target;
   if (nsplit < 1) nsplit = 1;
-  return nsplit;
+  rps = (M + nsplit - 1) / nsplit;
+  nsplit = (M + rps - 1) / rps;
 }
 
 extern "C" long gsl_lora_grad_ws_elems(int M, int N, int r) {
   const int R = (r <= 8) ? 8 : 16;
-  return (long)lg_nsplit(M, N, 4) * (long)N * R;   // V=4 gives the larger split count bound
+  long best = 0;
+  for (int V = 4; V <= 8; V += 4) {
+    int CG, bx, nsplit, rps;
+    lg_plan(M, N, V, R, CG, bx, nsplit, rps);
+    const long slabs = (long)nsplit + (nsplit + LG_FAN - 1) / LG_FAN;
+    if (slabs > best) best = slabs;
+  }
+  return best * (long)N * R;
 }
 
 extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj, int M, int N, int r,
@@ -119,25 +169,23 @@ extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, lo
   GSL_CHECK_ARG((N % V) == 0, "N must be a multiple of the vector width");
   hipStream_t st = as_stream(s);
   const int R = (r <= 8) ? 8 : 16;
-  const int ncol = N / V;
-  const int threads = ncol >= 256 ? 256 : ((ncol + 63) / 64) * 64;
-  const int bx = (ncol + threads - 1) / threads;
-  int nsplit = lg_nsplit(M, N, V);
-  const long cap = gsl_lora_grad_ws_elems(M, N, r) / ((long)N * R);
-  if (nsplit > cap) nsplit = (int)cap;
-  const int rps = (M + nsplit - 1) / nsplit;
-  nsplit = (M + rps - 1) / rps;
-#define LAUNCH(TT, RR)                                                                                              \
-  hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(threads), 0, st, (const TT*)Y, (const TT*)U, \
-                     ldu, ws, M, N, rps)
+  int CG, bx, nsplit, rps;
+  lg_plan(M, N, V, R, CG, bx, nsplit, rps);
+  const int RP = 256 / CG;
+  const size_t red_bytes = (size_t)(RP - 1) * CG * V * R * sizeof(float);
+  float* part2 = ws + (size_t)nsplit * N * R;
+#define LAUNCH(TT, RR)                                                                                                   \
+  hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(256), red_bytes, st, (const TT*)Y, (const TT*)U, \
+                     ldu, ws, M, N, rps, CG)
   if (dtype == GSL_BF16) { if (R == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
   else { if (R == 8) LAUNCH(float, 8); else LAUNCH(float, 16); }
 #undef LAUNCH
   int rc = check_launch("gsl_lora_grad(partial)");
   if (rc) return rc;
-  const int tot = N * R;
-  if (R == 8) hipLaunchKernelGGL(lora_grad_reduce_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
-  else hipLaunchKernelGGL(lora_grad_reduce_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+  const int tot = N * R, nslab = (nsplit + LG_FAN - 1) / LG_FAN;
+  hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((tot + 255) / 256, nslab), dim3(256), 0, st, ws, part2, tot, nsplit);
+  if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
+  else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
   return check_launch("gsl_lora_grad(reduce)");
 }
 
