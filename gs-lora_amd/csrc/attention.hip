@@ -47,19 +47,32 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
     *reinterpret_cast<uint4*>(dst + t * KLD + c * 8) = v;
   }
 }
-// stage the same panel transposed: dst[d][t], leading dim VLD = TP + 8, zero columns >= T
+// stage the same panel transposed: dst[d][t], leading dim VLD = TP + 8, zero columns >= T.
+// Each thread owns an 8 (keys) x 8 (d) block: eight 16-byte global loads, an in-register 8x8 transpose of the
+// packed bf16 pairs, eight 16-byte LDS stores (consecutive lanes -> consecutive key blocks of one d row:
+// conflict-free). This replaces 64 two-byte scattered LDS writes per thread.
 template <int TP>
 __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long ld, int T) {
-  constexpr int VLD = TP + 8;
-  for (int idx = threadIdx.x; idx < TP * 8; idx += blockDim.x) {
-    const int t = idx % TP, c = idx / TP;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  constexpr int VLD = TP + 8, NKB = TP / 8;
+  for (int idx = threadIdx.x; idx < NKB * 8; idx += blockDim.x) {
+    const int kb = idx % NKB, c = idx / NKB;
+    uint32_t w[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      dst[(c * 8 + 2 * i) * VLD + t] = (bf16_t)(w[i] & 0xffffu);
-      dst[(c * 8 + 2 * i + 1) * VLD + t] = (bf16_t)(w[i] >> 16);
+    for (int i = 0; i < 8; ++i) {
+      const int t = kb * 8 + i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
+      w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t o[4];
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        const uint32_t a = w[2 * p2][j >> 1], b = w[2 * p2 + 1][j >> 1];
+        o[p2] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+      }
+      *reinterpret_cast<uint4*>(dst + (c * 8 + j) * VLD + kb * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -87,7 +100,7 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
 // forward (bf16)
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int T, int H, float scale) {
   constexpr int TP = NKT * 16, VLD = TP + 8;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   for (int qt = wave; qt < nqt; qt += 4) {
+    asm volatile("" ::: "memory");   // keep the K / V^T fragment reads inside the loop (LICM would pin 224 VGPRs)
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
     const bf16_t* qrow = qb + (size_t)qrc * ld;
     const bf16x8_t qf0 = gl_frag(qrow, 0, fc), qf1 = gl_frag(qrow, 1, fc);
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 // backward dQ (bf16): waves own query tiles
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
                                                                int H, float scale) {
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   for (int qt = wave; qt < nqt; qt += 4) {
+    asm volatile("" ::: "memory");   // keep the K / V / K^T fragment reads inside the loop
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
     const bf16_t* qrow = qb + (size_t)qrc * ld;
     const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;

@@ -277,6 +277,183 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
     }
 }
 
+// ------------------------------------------------------------------ bf16 MFMA kernel, 256x128 tile, 3-stage LDS-DMA ring
+// 8 waves (4 x 2) of 64x64, BK = 64, three 48 KB stages (144 KB of the CU's 160 KB LDS): the DMA of tile
+// kt+2 is issued while tile kt is multiplied and tile kt+1 is still in flight. Waits are COUNTED
+// (s_waitcnt vmcnt(6): each wave has 6 DMA instructions per tile) and the barrier is the raw s_barrier,
+// because __syncthreads() would drain the in-flight stage (vmcnt(0)). One barrier per K tile.
+// L2->LDS traffic per flop is 25 % lower than the 128x128 tile's.
+constexpr int BM3 = 256, BN3 = 128, ST3 = (BM3 + BN3) * BK;   // elements per stage
+
+// ABL (development only): bit0 skip DMA, bit1 skip LDS fragment reads, bit2 skip MFMA, bit3 skip barrier
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                              const bf16_t* __restrict__ A2, int lda2,
+                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[3 * ST3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + BN3 - 1) / BN3;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nbn) * BM3, n0 = (tile % nbn) * BN3;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+
+  auto issue = [&](int kt) {
+    bf16_t* st = smem + (kt % 3) * ST3;
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wave * 4 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = wave * 2 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BM3 * BK + rb * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+
+  if (!(ABL & 1)) { issue(0); if (nk > 1) issue(1); }
+  bf16x8_t af[4], wf[4];
+  if (ABL & 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i] = *reinterpret_cast<const bf16x8_t*>(smem + (wm * 64 + i * 16 + fr) * BK + fc * 8); wf[i] = af[i]; }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    if (!(ABL & 1)) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed, tile kt+1 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is in LDS; compute(kt-1) finished everywhere
+    if (!(ABL & 1)) { if (kt + 2 < nk) issue(kt + 2); }   // overwrites the stage of tile kt-1
+    const bf16_t* As = smem + (kt % 3) * ST3;
+    const bf16_t* Ws = As + BM3 * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (!(ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 64 + i * 16 + fr;
+          af[i] = *reinterpret_cast<const bf16x8_t*>(As + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wn * 64 + j * 16 + fr;
+          wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+        }
+      }
+      if (!(ABL & 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(af[i]), "v"(wf[i])); }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 2-stage LDS-DMA
+// The per-CU LDS-DMA fill rate measured on this chip (~12-14 B/clk/CU, profiles/r01_*) bounds a tile
+// by its bytes per flop: 256x256x64 moves 64 KB per 8.4 MFLOP (7.6 B/kFLOP) against 15.3 B/kFLOP for
+// 128x128. 8 waves (2 x 4), each 128x64 (acc 8x4 fragments = 128 VGPRs), two 64 KB stages, next tile's DMA
+// in flight during the 64 MFMAs per wave of the current one; raw s_barrier + explicit vmcnt.
+constexpr int BM4 = 256, BN4 = 256, ST4 = (BM4 + BN4) * BK;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                             const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                             const bf16_t* __restrict__ A2, int lda2,
+                                                             const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ST4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = (e.N + BN4 - 1) / BN4;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+
+  auto issue = [&](int kt) {
+    bf16_t* st = smem + (kt & 1) * ST4;
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wave * 4 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BM4 * BK + rb * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const bf16_t* As = smem + (kt & 1) * ST4;
+    const bf16_t* Ws = As + BM4 * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + fr;
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
@@ -327,11 +504,27 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     const char* ev = getenv("GSL_GEMM_VARIANT");   // development knob: 0 register-staged, 1 glds x1, 2 glds x2
-    const int variant = ev ? atoi(ev) : (e.N <= 64 ? 2 : 1);   // measured: x1 wins on the wide GEMMs (3 blocks/CU), x2 on N=64
+    // measured on MI355X at M = 100 864 (profiles/r01_gemm_ab.md): 256x256 wins for N >= 1024, the 256x128 ring elsewhere
+    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (e.N >= 1024 ? 4 : 3));
     if (variant == 0)
       hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
                          (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
-    else if (variant == 1)
+    else if (variant == 4) {
+      const int nb4 = ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4);
+      hipLaunchKernelGGL(gemm_bf16_t256_kernel<EPI>, dim3(nb4), dim3(512), 0, st, (const bf16_t*)A1, lda1,
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+    } else if (variant == 3) {
+      const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);
+      const char* ab = getenv("GSL_GEMM_ABL");
+      const int abl = (ab && EPI == GSL_EPI_STORE) ? atoi(ab) : 0;
+#define R3(ABLV) hipLaunchKernelGGL((gemm_bf16_ring3_kernel<EPI, ABLV>), dim3(nb3), dim3(512), 0, st, (const bf16_t*)A1, lda1, \
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
+      if constexpr (EPI == GSL_EPI_STORE) {
+        switch (abl) { case 1: R3(1); break; case 2: R3(2); break; case 3: R3(3); break; case 4: R3(4); break; case 5: R3(5); break;
+                       case 6: R3(6); break; case 9: R3(9); break; case 11: R3(11); break; default: R3(0); }
+      } else { R3(0); }
+#undef R3
+    } else if (variant == 1)
       hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 1>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
                          (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
     else

@@ -202,29 +202,30 @@ __device__ __forceinline__ void row_softmax_stats(const float* row, int C, int l
   mx = m; lse = m + logf(se); amax = mi;
 }
 
-__global__ __launch_bounds__(1024) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                      float* __restrict__ out2, int B, int C) {
-  __shared__ float sl[16], sc[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float loss = 0.f, corr = 0.f;
-  for (int r = wave; r < B; r += nw) {
-    float mx, lse; int am;
-    row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
-    const int y = (int)labels[r];
-    loss += lse - logits[(size_t)r * C + y];
-    corr += (am == y) ? 1.f : 0.f;
-  }
-  if (lane == 0) { sl[wave] = loss; sc[wave] = corr; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.f, c = 0.f;
-    for (int i = 0; i < nw; ++i) { a += sl[i]; c += sc[i]; }
-    out2[0] = a; out2[1] = c;
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ rows, int B, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B) return;
+  float mx, lse; int am;
+  row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
+  const int y = (int)labels[r];
+  if (lane == 0) { rows[2 * r] = lse - logits[(size_t)r * C + y]; rows[2 * r + 1] = (am == y) ? 1.f : 0.f; }
+}
+// deterministic: lane-strided partial sums in a fixed order, fixed-order cross-wave combine
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ rows, float* __restrict__ out, int B, int ncol) {
+  __shared__ float sm[16];
+  for (int c = 0; c < ncol; ++c) {
+    float a = 0.f;
+    for (int r = threadIdx.x; r < B; r += blockDim.x) a += rows[(size_t)r * ncol + c];
+    const float t = block_sum(a, sm);
+    if (threadIdx.x == 0) out[c] = t;
   }
 }
-extern "C" int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, int B, int C, gsl_stream_t s) {
-  GSL_CHECK_ARG(logits && labels && out2 && B > 0 && C > 0, "null/size");
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, labels, out2, B, C);
+extern "C" int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, float* row_ws, int B, int C, gsl_stream_t s) {
+  GSL_CHECK_ARG(logits && labels && out2 && row_ws && B > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), logits, labels, row_ws, B, C);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, as_stream(s), row_ws, out2, B, 2);
   return check_launch("gsl_ce_fwd");
 }
 
@@ -261,35 +262,27 @@ __device__ __forceinline__ float row_lse(const float* row, int D, int lane) {
   return m + logf(wave_sum(se));
 }
 
-__global__ __launch_bounds__(1024) void proto_kl_fwd_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
-                                                            const float* __restrict__ proto, float* __restrict__ out1, int B,
-                                                            int D) {
-  __shared__ float sk[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float kl = 0.f;
-  for (int r = wave; r < B; r += nw) {
-    const float* a = emb + (size_t)r * D;
-    const float* t = proto + (size_t)labels[r] * D;
-    const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
-    float acc = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float ltd = t[d] - lt;
-      acc += expf(ltd) * (ltd - (a[d] - la));
-    }
-    kl += wave_sum(acc);
+__global__ __launch_bounds__(256) void proto_kl_rows_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ proto, float* __restrict__ rows, int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B) return;
+  const float* a = emb + (size_t)r * D;
+  const float* t = proto + (size_t)labels[r] * D;
+  const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float ltd = t[d] - lt;
+    acc += expf(ltd) * (ltd - (a[d] - la));
   }
-  if (lane == 0) sk[wave] = kl;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.f;
-    for (int i = 0; i < nw; ++i) a += sk[i];
-    out1[0] = a;
-  }
+  acc = wave_sum(acc);
+  if (lane == 0) rows[r] = acc;
 }
-extern "C" int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, int B, int D, int C,
-                                gsl_stream_t s) {
-  GSL_CHECK_ARG(emb && labels && proto && out1 && B > 0 && D > 0 && C > 0, "null/size");
-  hipLaunchKernelGGL(proto_kl_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(s), emb, labels, proto, out1, B, D);
+extern "C" int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, float* row_ws, int B,
+                                int D, int C, gsl_stream_t s) {
+  GSL_CHECK_ARG(emb && labels && proto && out1 && row_ws && B > 0 && D > 0 && C > 0, "null/size");
+  hipLaunchKernelGGL(proto_kl_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, row_ws, B, D);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, as_stream(s), row_ws, out1, B, 1);
   return check_launch("gsl_proto_kl_fwd");
 }
 

@@ -32,9 +32,9 @@ SIGNATURES = {
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
     "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _u64, _u32, _vp],
-    "gsl_ce_fwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
-    "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "gsl_group_norms_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gsl_group_norms_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp],

@@ -157,7 +157,8 @@ def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype
 def ce_fwd(logits, labels):
     _need(logits, labels)
     out = torch.empty(2, device=logits.device, dtype=torch.float32)
-    L.check(L.load().gsl_ce_fwd(_p(logits), _p(labels), _p(out), logits.shape[0], logits.shape[1], _stream()), "gsl_ce_fwd")
+    ws = torch.empty(2 * logits.shape[0], device=logits.device, dtype=torch.float32)
+    L.check(L.load().gsl_ce_fwd(_p(logits), _p(labels), _p(out), _p(ws), logits.shape[0], logits.shape[1], _stream()), "gsl_ce_fwd")
     return out
 
 
@@ -174,7 +175,8 @@ def ce_bwd(logits, labels, coef, scale, dlogits=None):
 def proto_kl_fwd(emb, labels, proto):
     _need(emb, labels, proto)
     out = torch.empty(1, device=emb.device, dtype=torch.float32)
-    L.check(L.load().gsl_proto_kl_fwd(_p(emb), _p(labels), _p(proto), _p(out), emb.shape[0], emb.shape[1], proto.shape[0],
+    ws = torch.empty(emb.shape[0], device=emb.device, dtype=torch.float32)
+    L.check(L.load().gsl_proto_kl_fwd(_p(emb), _p(labels), _p(proto), _p(out), _p(ws), emb.shape[0], emb.shape[1], proto.shape[0],
                                       _stream()), "gsl_proto_kl_fwd")
     return out
 

@@ -102,14 +102,14 @@ int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T,
                  float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
- * out2 f32 [2] = { sum_i CE_i , #correct }. */
-int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, int B, int C, gsl_stream_t s);
+ * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */
+int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, float* row_ws, int B, int C, gsl_stream_t s);
 /* dlogits (+)= coef[0] * scale * (softmax - onehot) ; coef is a DEVICE scalar (no host sync). */
 int gsl_ce_bwd(const float* logits, const int64_t* labels, const float* coef, float scale,
                float* dlogits, int B, int C, int accumulate, gsl_stream_t s);
 
 /* ---- K13 prototype KL (engine_cl.py:571-603): out1[0] = sum_i KL(softmax(proto[y_i]) || softmax(emb_i)). */
-int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1,
+int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, float* row_ws /*[B]*/,
                      int B, int D, int C, gsl_stream_t s);
 int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef,
                      float scale, float* demb, int B, int D, int C, int accumulate, gsl_stream_t s);

@@ -15,6 +15,9 @@ SHAPES = [("ffn1 512->2048 +lora gelu", 2048, 512, 64, L.EPI_BIAS_GELU), ("ffn2 
           ("qkv 512->1536", 1536, 512, 0, L.EPI_STORE), ("out 512->512 res", 512, 512, 0, L.EPI_BIAS_RES_F32),
           ("dX 2048->512 mul", 2048, 512, 64, L.EPI_MUL), ("lora-down N=64 K=2048", 64, 2048, 0, L.EPI_STORE)]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2").split(",")]
+if os.environ.get("SHAPE"):
+    SHAPES = [s_ for s_ in SHAPES if s_[0].startswith(os.environ["SHAPE"])]
+ROUNDS, ITERS = int(os.environ.get("ROUNDS", 3)), int(os.environ.get("ITERS", 10))
 dev = "cuda"
 torch.manual_seed(0)
 for name, N, K1, K2, epi in SHAPES:
@@ -32,16 +35,16 @@ for name, N, K1, K2, epi in SHAPES:
                     aux=aux if epi == L.EPI_MUL else None, out2=out2, p_drop=0.1 if epi in (L.EPI_BIAS_GELU, L.EPI_BIAS_RES_F32) else 0.0,
                     seed=1, site=1)
     res_t = {}
-    for rnd in range(3):
+    for rnd in range(ROUNDS):
         for v in VARIANTS:
             os.environ["GSL_GEMM_VARIANT"] = str(v)
             run(); torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            for _ in range(10):
+            for _ in range(ITERS):
                 run()
             e.record(); torch.cuda.synchronize()
-            res_t.setdefault(v, []).append(s.elapsed_time(e) / 10)
+            res_t.setdefault(v, []).append(s.elapsed_time(e) / ITERS)
     # correctness of the last variant vs variant 0 on a plain STORE_F32 pass
     chk = {}
     for v in VARIANTS:
