@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
 // backward dQ (bf16): waves own query tiles
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
                                                                int H, float scale) {
@@ -183,7 +183,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const bf16_t* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   for (int qt = wave; qt < nqt; qt += 4) {
-    asm volatile("" ::: "memory");   // keep the K / V / K^T fragment reads inside the loop
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
     const bf16_t* qrow = qb + (size_t)qrc * ld;
     const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
