@@ -1,0 +1,142 @@
+"""world_size-2 gloo test of the data-parallel arithmetic of gslora_hip.step.gs_lora_step.
+
+The step function is the product code; only its four device operations are swapped for CPU stand-ins
+built on the oracle (test infrastructure), because the HIP kernels cannot run here. What is proven:
+two ranks with half the batch each, after the packed scalar all-reduce (hinges on GLOBAL batch means),
+the 1/world pre-scaling of the parameter-only structure gradient and the flat gradient all-reduce, hold
+exactly the gradient / updated parameters of one process on the whole batch — for active AND inactive
+hinges (a per-rank hinge would differ: the two half-batches straddle the bound)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import gslora_oracle as O
+from oracle import recipe
+
+CFG = recipe.cfg_small()
+
+
+class OracleNet(nn.Module):
+    """CPU stand-in with ViT_face's call signature: (img, label) -> (logits, emb); LoRA tensors are Parameters."""
+
+    def __init__(self, state):
+        super().__init__()
+        self.names = list(state)
+        self.frozen = {k: torch.tensor(v) for k, v in state.items() if "lora_" not in k}
+        self.lora = nn.ParameterDict({k.replace(".", "/"): nn.Parameter(torch.tensor(v)) for k, v in state.items() if "lora_" in k})
+
+    def state(self):
+        st = dict(self.frozen)
+        st.update({k.replace("/", "."): p for k, p in self.lora.items()})
+        return st
+
+    def forward(self, img, label):
+        return O.vit_forward(self.state(), img, label, CFG)
+
+
+class OracleBackend:
+    @staticmethod
+    def ce_sum_top1(logits, labels):
+        return (torch.nn.functional.cross_entropy(logits, labels, reduction="sum"),
+                (logits.argmax(1) == labels).float().sum())
+
+    @staticmethod
+    def proto_kl_sum(emb, labels, table):
+        return O.prototype_kl(emb, labels, table) * emb.shape[0]
+
+    @staticmethod
+    def structure_loss(net, group_type, grad_scale=1.0):
+        s = O.structure_loss(net.state(), CFG, group_type)
+        return s.detach() + grad_scale * (s - s.detach())       # value unscaled, gradient pre-divided by world
+
+    @staticmethod
+    def grad_bucket(net):
+        ps = list(net.lora.values())
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        OracleBackend._pending = (ps, flat)
+        return flat
+
+
+def _scatter_back():
+    ps, flat = OracleBackend._pending
+    off = 0
+    for p in ps:
+        p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+
+
+class SGD1(torch.optim.SGD):
+    """plain SGD whose step() first writes the all-reduced flat bucket back into the .grad tensors"""
+
+    def step(self):
+        if getattr(OracleBackend, "_pending", None) is not None and dist.is_initialized():
+            _scatter_back()
+        OracleBackend._pending = None
+        return super().step()
+
+
+def _batches():
+    mk = lambda a: torch.tensor(a)
+    return (mk(recipe.make_images(CFG, 6, seed=31, tag="xr")), mk(recipe.make_labels(CFG, 6, seed=31, tag="yr", hi=8)),
+            mk(recipe.make_images(CFG, 6, seed=32, tag="xf")), mk(recipe.make_labels(CFG, 6, seed=32, tag="yf", lo=8)))
+
+
+def _run_step(net, xs, hyper):
+    from gslora_hip.step import gs_lora_step
+    opt = SGD1(net.parameters(), lr=0.1)
+    proto = torch.tensor(recipe.make_prototypes(CFG))
+    pack = gs_lora_step(net, opt, nn.CrossEntropyLoss(), *xs, beta=0.15, alpha=1e-2, BND=hyper["BND"],
+                        use_structure=True, group_type="block", use_prototype=True, proto_table=proto, w_f=0.05, w_r=0.1,
+                        BND_pro=hyper["BND_pro"], backend=OracleBackend)
+    return pack, {k: p.detach().clone() for k, p in net.lora.items()}
+
+
+def _worker(rank, world, port, hyper, ret):
+    sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-lora_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    net = OracleNet(recipe.make_state(CFG))
+    xr, yr, xf, yf = _batches()
+    sl = slice(rank * 3, rank * 3 + 3)
+    pack, params = _run_step(net, (xr[sl], yr[sl], xf[sl], yf[sl]), hyper)
+    ret[rank] = (pack.tolist(), {k: v.numpy() for k, v in params.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hyper", [dict(BND=105.0, BND_pro=2.0), dict(BND=5.0, BND_pro=0.1), dict(BND=None, BND_pro=None)])
+def test_two_rank_step_equals_single_process(hyper):
+    # single process, whole batch
+    net = OracleNet(recipe.make_state(CFG))
+    xs = _batches()
+    if hyper["BND"] is None:
+        # place both bounds BETWEEN the two ranks' local means so that a per-rank hinge would be wrong
+        with torch.no_grad():
+            lo, em = net(xs[2], xs[3])
+            per = torch.nn.functional.cross_entropy(lo, xs[3], reduction="none")
+            a, b = per[:3].mean().item(), per[3:].mean().item()
+            kl = [O.prototype_kl(em[s], xs[3][s], torch.tensor(recipe.make_prototypes(CFG))).item() for s in (slice(0, 3), slice(3, 6))]
+        hyper = dict(BND=0.5 * (a + b) + 0.25 * abs(a - b), BND_pro=0.5 * (kl[0] + kl[1]) + 0.25 * abs(kl[0] - kl[1]))
+        assert min(a, b) < hyper["BND"] < max(a, b)
+    pack1, params1 = _run_step(net, xs, hyper)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, hyper, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in range(2):
+        pack2, params2 = ret[r]
+        assert np.allclose(pack2, pack1.tolist(), rtol=1e-5, atol=1e-5), (r, pack2, pack1.tolist())
+        for k, v in params1.items():
+            assert np.abs(params2[k] - v.numpy()).max() < 2e-6, (r, k)
+    # both ranks end with identical replicas
+    for k in params1:
+        assert np.array_equal(ret[0][1][k], ret[1][1][k])
