@@ -34,6 +34,7 @@ struct EpiArgs {
   int T;
   DropCfg drop;
   int M, N;
+  int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
 };
 
 // one row m, four consecutive columns n..n+3 (N % 4 == 0 is enforced by the host wrapper)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
   const int lrow = lane >> 3, lc = lane & 7;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + BN3 - 1) / BN3;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BM3, n0 = (tile % nbn) * BN3;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
   const int lrow = lane >> 3, lc = lane & 7;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nbn = (e.N + BN4 - 1) / BN4;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
   const int lrow = lane >> 3, lc = lane & 7;
@@ -553,6 +554,7 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   EpiArgs e;
   e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
+  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
