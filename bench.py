@@ -145,6 +145,13 @@ def main():
         avg_ms = sum(durs) / max(1, len(durs))
         flops = 2.0 * M * FULL["mlp_dim"] * FULL["dim"] + 2.0 * M * FULL["mlp_dim"] * FULL["lora_rank"]
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of the roofline kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pj.get("batch") == B:
+                traffic = pj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         ips = world * 2 * B * args.steps / elapsed
         out = {
             "metric": "forgetting-step images/sec, ViT-P8S8 d6 112px r=8", "value": round(ips, 2), "unit": "images/s",
@@ -153,9 +160,10 @@ def main():
             "config": {"workload": f"ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8, per-GPU batch {B} remain + "
                                    f"{B} forget (112x112 synthetic), dropout {args.dropout}, prototype term on, FusedAdamW",
                        "global_batch": world * 2 * B, "tokens_per_image": 197, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<BIAS_GELU> (fused FFN1 + LoRA-up + bias + GELU + dropout, fwd)",
+            "roofline": {"bound": "mfma", "kernel": "gsl_gemm_nt<BIAS_GELU> (fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout, fwd)",
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "launches_timed": len(durs), "avg_ms": round(avg_ms, 4), "traffic": None},
+                         "launches_timed": len(durs), "avg_ms": round(avg_ms, 4), "traffic": traffic,
+                         "algorithmic_bytes": int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)},
             "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
         }
