@@ -456,6 +456,97 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
 }
 
 // =====================================================================================
+// backward for a cls-only output gradient (last block): rank-1 structure, one thread per key
+//   p_j = exp(q0.k_j*scale - lse0), D = dO0.O0, ds_j = p_j (dO0.v_j - D) scale
+//   dq0 = sum_j ds_j k_j ; dk_j = ds_j q0 ; dv_j = p_j dO0 ; dq_t = 0 for t > 0
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                           const T* __restrict__ d_o_cls, const float* __restrict__ lse,
+                                                           T* __restrict__ dqkv, int Tn, int H, float scale) {
+  __shared__ float q0[HD], g0[HD], red[4][HD];
+  __shared__ float sD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const T* qb = qkv + (size_t)b * Tn * ld + h * HD;
+  T* db = dqkv + (size_t)b * Tn * ld + h * HD;
+  const int tid = threadIdx.x;
+  if (tid < HD) {
+    q0[tid] = Elem<T>::ld(qb + tid);
+    g0[tid] = Elem<T>::ld(d_o_cls + (size_t)b * ldo + h * HD + tid);
+    float v = g0[tid] * Elem<T>::ld(o + (size_t)b * Tn * ldo + h * HD + tid);
+    v = wave_sum(v);
+    if (tid == 0) sD = v;
+  }
+  __syncthreads();
+  const float D = sD, l0 = lse[((size_t)b * H + h) * Tn];
+  float dq[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+  for (int j = tid; j < Tn; j += blockDim.x) {
+    const T* kr = qb + (size_t)j * ld + H * HD;
+    const T* vr = qb + (size_t)j * ld + 2 * H * HD;
+    float kv[HD], s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      float t4[4], v4[4];
+      Elem<T>::ld4(kr + c * 4, t4);
+      Elem<T>::ld4(vr + c * 4, v4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kv[c * 4 + i] = t4[i];
+        s = fmaf(q0[c * 4 + i], t4[i], s);
+        dp = fmaf(g0[c * 4 + i], v4[i], dp);
+      }
+    }
+    const float p = expf(s * scale - l0);
+    const float ds = p * (dp - D) * scale;
+    T* dk = db + (size_t)j * ld + H * HD;
+    T* dv = db + (size_t)j * ld + 2 * H * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = ds * q0[c * 4 + i];
+        bb[i] = p * g0[c * 4 + i];
+        dq[c * 4 + i] = fmaf(ds, kv[c * 4 + i], dq[c * 4 + i]);
+      }
+      Elem<T>::st4(dk + c * 4, a);
+      Elem<T>::st4(dv + c * 4, bb);
+    }
+    if (j > 0) {   // dQ of the non-cls tokens is exactly zero
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < HD / 4; ++c) Elem<T>::st4(db + (size_t)j * ld + c * 4, z);
+    }
+  }
+  // dq0 = sum over the block's threads (fixed order: wave shuffle tree, then waves 0..3)
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    const float v = wave_sum(dq[d]);
+    if (lane == 0) red[wave][d] = v;
+  }
+  __syncthreads();
+  if (tid < HD) Elem<T>::st(db + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv, int B,
+                                     int T, int H, float scale, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(qkv && o && d_o_cls && lse && dqkv && B > 0 && T > 1 && H > 0, "null/size");
+  const dim3 grid(B * H), blk(256);
+  if (dtype == GSL_BF16)
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)o,
+                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale);
+  else if (dtype == GSL_F32)
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)o,
+                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale);
+  else return fail(GSL_ERR_ARG, "gsl_attention_bwd_cls: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_attention_bwd_cls");
+}
+
+// =====================================================================================
 // C ABI
 // =====================================================================================
 extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype,

@@ -67,7 +67,8 @@ template <int NPL, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, long xs,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dres,
-                                                     float* dx, T* __restrict__ dxb, int M, DropCfg drop) {
+                                                     float* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
+                                                     long drop_row_stride) {
   constexpr int D = NPL * 64;
   using IO = RowIO<NPL>;
   const int lane = threadIdx.x & 63;
@@ -92,22 +93,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < NPL; ++i) gy[i] = rs * (gy[i] - c1 - xv[i] * c2);
     if (dres) {
       float r[NPL];
-      IO::load(dres + (size_t)row * D, lane, r);
+      IO::load(dres + (size_t)row * ios, lane, r);
 #pragma unroll
       for (int i = 0; i < NPL; ++i) gy[i] += r[i];
     }
-    IO::store(dx + (size_t)row * D, lane, gy);
+    IO::store(dx + (size_t)row * ios, lane, gy);
     if (dxb) {
       if (drop.thr) {
 #pragma unroll
         for (int c = 0; c < IO::NV; ++c) {
           if constexpr (IO::VEC == 4) {
             float dm[4];
-            drop_mul4(drop, (uint64_t)row * D + IO::idx(lane, c, 0), dm);
+            drop_mul4(drop, (uint64_t)row * drop_row_stride + IO::idx(lane, c, 0), dm);
 #pragma unroll
             for (int i = 0; i < 4; ++i) gy[c * 4 + i] *= dm[i];
           } else {
-            gy[c] *= drop_mul(drop, (uint64_t)row * D + IO::idx(lane, c, 0));
+            gy[c] *= drop_mul(drop, (uint64_t)row * drop_row_stride + IO::idx(lane, c, 0));
           }
         }
       }
@@ -129,14 +130,14 @@ static int ln_fwd_launch(const float* x, long xs, const float* gamma, const floa
 
 template <int NPL>
 static int ln_bwd_launch(const void* dy, const float* x, long xs, const float* gamma, const float* mean, const float* rstd,
-                         const float* dres, float* dx, void* dxb, int M, int dtype, DropCfg drop, hipStream_t st) {
+                         const float* dres, float* dx, long ios, void* dxb, int M, int dtype, DropCfg drop, long drs, hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
   if (dtype == GSL_BF16)
     hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
-                       dres, dx, (bf16_t*)dxb, M, drop);
+                       dres, dx, ios, (bf16_t*)dxb, M, drop, drs);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<NPL, float>), dim3(grid), dim3(256), 0, st, (const float*)dy, x, xs, gamma, mean, rstd,
-                       dres, dx, (float*)dxb, M, drop);
+                       dres, dx, ios, (float*)dxb, M, drop, drs);
   return check_launch("gsl_layernorm_bwd");
 }
 
@@ -162,13 +163,15 @@ extern "C" int gsl_layernorm_fwd(const float* x, long x_row_stride, const float*
 }
 
 extern "C" int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma, const float* mean,
-                                 const float* rstd, const float* dres, float* dx, void* dxb, int M, int D, int dtype,
-                                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
+                                 const float* rstd, const float* dres, float* dx, long io_row_stride, void* dxb, int M, int D,
+                                 int dtype, float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s) {
   GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
   const DropCfg drop = make_drop(p_drop, seed, site);
-#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, dxb, M, dtype, drop, as_stream(s))
+  const long ios = io_row_stride > 0 ? io_row_stride : D, drs = drop_row_stride > 0 ? drop_row_stride : D;
+  GSL_CHECK_ARG((ios % 4) == 0, "io row stride alignment");
+#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, drop, drs, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
 }

@@ -77,13 +77,18 @@ def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0):
-    _need(dy, x, gamma, mean, rstd, dres)
+def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
+                  io_row_stride=0, drop_row_stride=0):
+    """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place."""
+    _need(dy, x, gamma, mean, rstd)
     M, D = dy.shape
-    dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    if dx is None:
+        _need(dres)
+        dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
     dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if want_copy else None
-    L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dxb), M,
-                                       D, code(dy.dtype), float(p_drop), int(seed), int(site), _stream()), "gsl_layernorm_bwd")
+    L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                       int(io_row_stride), _p(dxb), M, D, code(dy.dtype), float(p_drop), int(seed), int(site),
+                                       int(drop_row_stride), _stream()), "gsl_layernorm_bwd")
     return dx, dxb
 
 
@@ -102,6 +107,14 @@ def attention_bwd(qkv, o, d_o, lse, B, T, H, scale):
     delta = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     L.check(L.load().gsl_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), _p(delta), B, T, H, float(scale),
                                        code(qkv.dtype), _stream()), "gsl_attention_bwd")
+    return dqkv
+
+
+def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale):
+    _need(qkv, o, d_o_cls, lse)
+    dqkv = torch.empty_like(qkv)
+    L.check(L.load().gsl_attention_bwd_cls(_p(qkv), _p(o), _p(d_o_cls), _p(lse), _p(dqkv), B, T, H, float(scale),
+                                           code(qkv.dtype), _stream()), "gsl_attention_bwd_cls")
     return dqkv
 
 

@@ -240,27 +240,37 @@ class ViTRunner:
         blocks = list(m.blocks())
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
+        cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()     # rows b*T of a [B*T, w] tensor
         for i in reversed(range(nl)):
             st = saved["layers"][i]
             attn, ffn = blocks[i]
             at, ff = attn.fn, ffn.fn
             l1, l2 = ff.net[0], ff.net[3]
             mlp = l1.weight.shape[0]
-            Mrows = dx.shape[0]
             if not st["lora_on"]:
                 raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
+            # The network pools x[:, 0] (vit_face.py:540): the stream gradient entering the LAST block is exactly zero
+            # outside the B cls rows, so its FFN backward, LoRA-gradient reductions, LN2 backward, out-proj dX and the
+            # attention backward (a rank-1 cls-query form) run on B rows instead of B*T. Exact, not an approximation.
+            sparse = (i == nl - 1)
+            if sparse:
+                dyb, xn2, h, gp, u1, u2 = (cls_rows(dxb, D), cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), cls_rows(st["gp"], mlp),
+                                           cls_rows(st["u1"], PADK), cls_rows(st["u2"], PADK))
+            else:
+                dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
+            Mrows = dyb.shape[0]
             # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
             v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
-            ops.gemm_nt(dxb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
+            ops.gemm_nt(dyb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
-            ops.gemm_nt(dxb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
-                        W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=st["gp"])
-            ops.lora_grad(dxb, st["u2"], gv[id(l2.lora_B)], r, 1, r)          # dB2[c, j]
-            ops.lora_grad(st["h"], v2, gv[id(l2.lora_A)], 1, mlp, r)          # dA2[j, hid]
+            ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
+                        W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp)
+            ops.lora_grad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                # dB2[c, j]
+            ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)                # dA2[j, hid]
             v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
-            ops.lora_grad(da, st["u1"], gv[id(l1.lora_B)], r, 1, r)           # dB1[hid, j]
-            ops.lora_grad(st["xn2"], v1, gv[id(l1.lora_A)], 1, D, r)          # dA1[j, c]
+            ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)                 # dB1[hid, j]
+            ops.lora_grad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                # dA1[j, c]
             if i == 0:
                 break   # nothing below the layer-0 FFN input is trainable
             dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
@@ -268,14 +278,22 @@ class ViTRunner:
                         W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
             del da, v1, v2
             n2 = ffn.norm
-            dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
-                                          p_drop=p_drop, seed=seed, site=4 * i)
+            if sparse:   # update the cls rows of the dense stream gradient in place; dx1b is the compact masked copy
+                dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
+                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
+                                              p_drop=p_drop, seed=seed, site=4 * i, drop_row_stride=T * D)
+            else:
+                dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
+                                              p_drop=p_drop, seed=seed, site=4 * i)
             del dxn2
             # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
             ops.gemm_nt(dx1b, self.wT(f"wo{i}", at.to_out[0].weight, dt), d_o)
-            dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
-            dxn1 = torch.empty(Mrows, D, device=dev, dtype=dt)
+            if sparse:
+                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
+            else:
+                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
+            dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)
             ops.gemm_nt(dqkv, self.wT(f"qkv{i}", at.to_qkv.weight, dt), dxn1)
             del d_o, dqkv, dx1b
             n1 = attn.norm

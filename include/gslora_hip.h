@@ -70,11 +70,14 @@ int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
  * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
 int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                       void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s);
-/* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D]. */
+/* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D] (dense).
+ * dres/dx rows are io_row_stride elements apart (0 -> D; dres may alias dx: in-place update of strided rows,
+ * used for the cls-row-only backward of the last block); the dropout counter of element (row, d) is
+ * row*drop_row_stride + d (0 -> D). dxb is always dense [M,D]. */
 int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma,
                       const float* mean, const float* rstd, const float* dres,
-                      float* dx, void* dxb, int M, int D, int dtype,
-                      float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+                      float* dx, long io_row_stride, void* dxb, int M, int D, int dtype,
+                      float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s);
 
 /* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
  * qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)'), o[dtype] [B*T, H*64], lse f32 [B,H,T]. */
@@ -82,6 +85,11 @@ int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H,
 /* dqkv[dtype] [B*T,3*H*64]; delta_ws f32 [B,H,T] scratch. */
 int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
                       float* delta_ws, int B, int T, int H, float scale, int dtype, gsl_stream_t s);
+/* Backward when only the cls query (token 0 of every image) carries an output gradient — the last
+ * transformer block, because ViT_face pools x[:,0] (vit_face.py:540). d_o_cls[dtype] [B, H*64] is dO of the cls rows;
+ * o and lse are the forward's full tensors. Writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens = 0). */
+int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
+                          int B, int T, int H, float scale, int dtype, gsl_stream_t s);
 
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
  * Y[dtype] [M,N], U[dtype] [M,ldu] (first r columns used, r <= 16). ws f32 >= gsl_lora_grad_ws_elems(). */

@@ -285,3 +285,45 @@ def test_adamw_matches_torch(ops):
         opt.step()
         ops.adamw_flat(p, (g * step).cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, step)
         assert (p.cpu() - pt.detach()).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,T,H", [(3, 197, 2), (2, 26, 1)])
+def test_attention_bwd_cls_equals_dense_backward(ops, dt, B, T, H):
+    """cls-only output gradient: the rank-1 kernel must equal the dense backward fed with zeros elsewhere."""
+    scale = (H * 64) ** -0.5 * 2.0
+    qkv = rnd(B * T, 3 * H * 64, seed=11, scale=1.2).cuda().to(dt)
+    o, lse = ops.attention_fwd(qkv, B, T, H, scale)
+    d_cls = rnd(B, H * 64, seed=12)
+    d_full = torch.zeros(B, T, H * 64); d_full[:, 0] = d_cls
+    ref = ops.attention_bwd(qkv, o, d_full.reshape(B * T, -1).cuda().to(dt), lse, B, T, H, scale).float().cpu()
+    got = ops.attention_bwd_cls(qkv, o, d_cls.cuda().to(dt), lse, B, T, H, scale).float().cpu()
+    assert (got - ref).abs().max() < tol(dt, 2e-5, 2e-2) * max(1.0, ref.abs().max().item())
+    dq = got.reshape(B, T, 3, H * 64)[:, 1:, 0]
+    assert (dq == 0).all()
+    # and against autograd in f32
+    if dt == torch.float32:
+        q = qkv.float().cpu().requires_grad_(True)
+        attn_ref(q, B, T, H, scale).backward(d_full.reshape(B * T, -1))
+        assert (got - q.grad).abs().max() < 5e-5 * max(1.0, q.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layernorm_bwd_strided_inplace(ops, dt):
+    """cls-row form: x / dres / dx rows are T*D apart, dy and the masked copy are compact."""
+    B, T, D = 5, 7, 128
+    x = rnd(B * T, D, seed=1, scale=2.0); g = 1 + 0.1 * rnd(D, seed=2); b = 0.1 * rnd(D, seed=3)
+    _, mean, rstd = ops.layernorm_fwd(x.cuda(), D, B * T, D, g.cuda(), b.cuda(), 1e-5, dt)
+    dy = rnd(B, D, seed=4)
+    dres = rnd(B * T, D, seed=5)
+    dense = dres.clone().cuda()
+    pick = lambda t: t.view(B, T, -1)[:, 0].contiguous()
+    dx, dxb = ops.layernorm_bwd(dy.cuda().to(dt), x.cuda(), T * D, g.cuda(), pick(mean.view(-1, 1)).view(-1), pick(rstd.view(-1, 1)).view(-1),
+                                dense, dx=dense, io_row_stride=T * D, p_drop=0.5, seed=3, site=9, drop_row_stride=T * D)
+    xr = x.view(B, T, D)[:, 0].clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), g, b, 1e-5).backward(as_dt(dy, dt))
+    want = dres.clone().view(B, T, D)
+    want[:, 0] += xr.grad
+    assert (dx.cpu().view(B, T, D) - want).abs().max() < 2e-5
+    keep = ops.dropout_mask(B * T * D, 0.5, 3, 9, "cuda").cpu().view(B, T, D)[:, 0].float()
+    assert (dxb.float().cpu() - want[:, 0] * keep * 2).abs().max() < tol(dt, 4e-5, 6e-2)
