@@ -5,12 +5,14 @@
 // [x | s·(x Aᵀ)] · [W | B]ᵀ  ==  x Wᵀ + s·(x Aᵀ) Bᵀ, so the adapter costs one extra K tile on the
 // matrix cores instead of two skinny GEMMs and an elementwise add.
 //
-// bf16 path: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16 with the
-// operands swapped (mfma(W, A)) so each lane owns 4 consecutive output columns of one row ->
-// 8/16-byte epilogue stores. LDS tiles are XOR-swizzled on 16-byte chunks (chunk ^= row & 7) so the
-// ds_read_b128 fragment reads are <= 2-way conflicted; global->LDS is register-staged and
-// double-buffered (one barrier per K tile). Block ids are remapped so that the blocks sharing an
-// A row-panel run on the same XCD (private L2).
+// bf16 path (v_mfma_f32_16x16x32_bf16, f32 accumulate), three tile shapes sharing one epilogue:
+//   128x128x64, 4 waves, one 32 KB LDS stage (small M); 256x128x64, 8 waves, 3-stage ring with counted vmcnt + raw
+//   s_barrier; 256x256x64, 8 waves of 128x64, 2 stages. Operands are swapped in the MFMA (mfma(W, A)) so each lane owns 4
+//   consecutive output columns of one row -> 8/16-byte epilogue stores. Global->LDS staging is the LDS-DMA
+//   (global_load_lds_dwordx4); the 16-byte-chunk XOR swizzle (chunk ^= row & 7) is applied on the DMA source address
+//   and again on the ds_read_b128 fragment read (0 bank conflicts measured). Block ids are remapped so the N-tiles of
+//   one A row-panel run on one XCD. What was tried and measured (register staging, BK=32 4-stage ring, L2 prefetch wave,
+//   main-loop ablation, PMC) is in profiles/r01_gemm_ab.md.
 // f32 path (parity mode): 64x64x16 tile, 4x4 outputs per thread, sequential fmaf over k.
 #include <stdlib.h>
 
@@ -99,91 +101,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-// ------------------------------------------------------------------ bf16 MFMA kernel
-constexpr int BM = 128, BN = 128, BK = 64;
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                        const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                        const bf16_t* __restrict__ A2, int lda2,
-                                                        const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][BM * BK];  // [buffer][A|W][row*64 + swizzled chunk]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (e.N + BN - 1) / BN;
-  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
-  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
-
-  uint4 ra[4], rw[4];
-  auto gload = [&](int kt) {
-    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
-    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
-    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
-      ra[i] = *reinterpret_cast<const uint4*>(Ab + (size_t)gm * lda + k0 + c * 8);
-      rw[i] = *reinterpret_cast<const uint4*>(Wb + (size_t)gn * ldw + k0 + c * 8);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-      const int off = row * BK + ((c ^ (row & 7)) << 3);
-      *reinterpret_cast<uint4*>(&smem[buf][0][off]) = ra[i];
-      *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rw[i];
-    }
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  const int fr = lane & 15, fc = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + fr;
-        af[i] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][0][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + fr;
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(&smem[buf][1][row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3)]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
-  }
-  // acc[i][j][reg] = C[m = m0+wm*64+i*16+(lane&15)][n = n0+wn*64+j*16+(lane>>4)*4+reg]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
-    }
-}
-
 // ------------------------------------------------------------------ bf16 MFMA kernel, direct-to-LDS staging
+constexpr int BM = 128, BN = 128, BK = 64;
 // Same tile / fragment / epilogue structure, but the global->LDS copy is the gfx950 LDS-DMA
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). The DMA destination is
 // wave-uniform base + lane*16 B, so the XOR swizzle is applied on the SOURCE address (lane -> (row, cpos)
@@ -504,33 +423,37 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
-    const char* ev = getenv("GSL_GEMM_VARIANT");   // development knob: 0 register-staged, 1 glds x1, 2 glds x2
-    // measured on MI355X at M = 100 864 (profiles/r01_gemm_ab.md): 256x256 wins for N >= 1024, the 256x128 ring elsewhere
+    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage.
+    // Defaults measured on MI355X at M = 100 864 (profiles/r01_gemm_ab.md).
+    const char* ev = getenv("GSL_GEMM_VARIANT");
     const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (e.N >= 1024 ? 4 : 3));
-    if (variant == 0)
-      hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
-    else if (variant == 4) {
-      const int nb4 = ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4);
-      hipLaunchKernelGGL(gemm_bf16_t256_kernel<EPI>, dim3(nb4), dim3(512), 0, st, (const bf16_t*)A1, lda1,
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+#define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
+                                                      ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
+    if (variant == 4) {
+      GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
     } else if (variant == 3) {
       const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);
-      const char* ab = getenv("GSL_GEMM_ABL");
+      const char* ab = getenv("GSL_GEMM_ABL");   // main-loop ablation (tools/bench_gemm_abl.py), STORE epilogue only
       const int abl = (ab && EPI == GSL_EPI_STORE) ? atoi(ab) : 0;
-#define R3(ABLV) hipLaunchKernelGGL((gemm_bf16_ring3_kernel<EPI, ABLV>), dim3(nb3), dim3(512), 0, st, (const bf16_t*)A1, lda1, \
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
       if constexpr (EPI == GSL_EPI_STORE) {
-        switch (abl) { case 1: R3(1); break; case 2: R3(2); break; case 3: R3(3); break; case 4: R3(4); break; case 5: R3(5); break;
-                       case 6: R3(6); break; case 9: R3(9); break; case 11: R3(11); break; default: R3(0); }
-      } else { R3(0); }
-#undef R3
-    } else if (variant == 1)
-      hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 1>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
-    else
-      hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 2>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)A1, lda1,
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+        switch (abl) {
+          case 1: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 1>), nb3, 512); break;
+          case 2: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 2>), nb3, 512); break;
+          case 3: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 3>), nb3, 512); break;
+          case 4: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 4>), nb3, 512); break;
+          case 5: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 5>), nb3, 512); break;
+          case 6: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 6>), nb3, 512); break;
+          case 9: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 9>), nb3, 512); break;
+          case 11: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 11>), nb3, 512); break;
+          default: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), nb3, 512);
+        }
+      } else {
+        GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), nb3, 512);
+      }
+    } else {
+      GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
+    }
+#undef GSL_LAUNCH
   } else {
     const int nblk = ((e.M + 63) / 64) * ((e.N + 63) / 64);
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,
