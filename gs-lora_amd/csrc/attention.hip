@@ -17,6 +17,8 @@
 //     and dK/dV (waves own key tiles; needs Q, Qᵀ, dO, dOᵀ in LDS); probabilities are recomputed
 //     from the saved log-sum-exp (flash-style), delta = rowsum(dO∘O) is produced by the dQ kernel.
 // f32 path (parity mode): thread-per-row VALU kernels with LDS-broadcast panels; exact f32.
+#include <stdlib.h>
+
 #include "gsl_common.h"
 
 using namespace gsl;
@@ -100,20 +102,24 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
 // forward (bf16)
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                            float* __restrict__ lse, int T, int H, float scale) {
+__global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int T, int H, float scale, int abl) {
   constexpr int TP = NKT * 16, VLD = TP + 8;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * VLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
-  stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
-  stage_transposed<TP>(Vt, qb + 2 * H * HD, ld, T);
+  if (abl != 2) {
+    stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
+    stage_transposed<TP>(Vt, qb + 2 * H * HD, ld, T);
+  }
   __syncthreads();
+  if (abl == 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int qt = wave; qt < nqt; qt += nwaves) {
     asm volatile("" ::: "memory");   // keep the K / V^T fragment reads inside the loop (LICM would pin 224 VGPRs)
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
     const bf16_t* qrow = qb + (size_t)qrc * ld;
@@ -165,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
 // backward dQ (bf16): waves own query tiles
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
-                                                               int H, float scale) {
+                                                               int H, float scale, int abl) {
   constexpr int TP = NKT * 16, VLD = TP + 8;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
@@ -176,13 +182,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
-  stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
-  stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
-  stage_transposed<TP>(Kt, qb + H * HD, ld, T);
+  if (abl != 2) {
+    stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
+    stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
+    stage_transposed<TP>(Kt, qb + H * HD, ld, T);
+  }
   __syncthreads();
+  if (abl == 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int qt = wave; qt < nqt; qt += nwaves) {
+    asm volatile("" ::: "memory");   // 8 waves per block: keep the fragment reads in the loop (<= 256 registers)
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
     const bf16_t* qrow = qb + (size_t)qrc * ld;
     const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
@@ -237,9 +248,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 // backward dK/dV (bf16): waves own key tiles
 // =====================================================================================
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl) {
   constexpr int TP = NKT * 16, VLD = TP + 8;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Os[TP * KLD];   // dO row-major
@@ -251,18 +262,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
   const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
-  stage_rowmajor<TP>(Qs, qb, ld, T);
-  stage_rowmajor<TP>(Os, dob, ldo, T);
-  stage_transposed<TP>(Qt, qb, ld, T);
-  stage_transposed<TP>(Ot, dob, ldo, T);
+  if (abl != 2) {
+    stage_rowmajor<TP>(Qs, qb, ld, T);
+    stage_rowmajor<TP>(Os, dob, ldo, T);
+    stage_transposed<TP>(Qt, qb, ld, T);
+    stage_transposed<TP>(Ot, dob, ldo, T);
+  }
   for (int t = threadIdx.x; t < TP; t += blockDim.x) {
     lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] : 3.0e38f;   // padded queries -> p = 0
     del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
   }
   __syncthreads();
+  if (abl == 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nkt = (T + 15) / 16;
-  for (int kt = wave; kt < nkt; kt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int kt = wave; kt < nkt; kt += nwaves) {
     const int kr = kt * 16 + fr, krc = min(kr, T - 1);
     const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
     const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
@@ -546,6 +561,8 @@ extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void*
   return check_launch("gsl_attention_bwd_cls");
 }
 
+static inline int attn_abl() { const char* e = getenv("GSL_ATTN_ABL"); return e ? atoi(e) : 0; }   // dev: 1 staging only, 2 no staging
+
 // =====================================================================================
 // C ABI
 // =====================================================================================
@@ -556,8 +573,8 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16) {
-    if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale);
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale);
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
   } else if (dtype == GSL_F32) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
     else hipLaunchKernelGGL(attn_fwd_f32_kernel<224>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
@@ -575,11 +592,11 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     const bf16_t* q = (const bf16_t*)qkv; const bf16_t* oo = (const bf16_t*)o; const bf16_t* g = (const bf16_t*)d_o;
     bf16_t* dq = (bf16_t*)dqkv;
     if (T <= 64) {
-      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
-      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
     } else {
-      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
-      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<14>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<14>, grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
     }
   } else if (dtype == GSL_F32) {
     const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;
