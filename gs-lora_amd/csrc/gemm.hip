@@ -39,10 +39,10 @@ struct EpiArgs {
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
 };
 
-// one row m, four consecutive columns n..n+3 (N % 4 == 0 is enforced by the host wrapper)
+// ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
+// N % 4 == 0 is enforced by the host wrapper. v = primary output, g = second output (GELU' of BIAS_GELU).
 template <int EPI, typename T>
-__device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float v[4]) {
-  if (m >= e.M || n >= e.N) return;
+__device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4]) {
   const size_t off = (size_t)m * e.ldo + n;
   const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
 #pragma unroll
@@ -52,17 +52,14 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += e.bias[n + i];
     }
-    if constexpr (EPI == GSL_EPI_STORE) Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
-    else Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
     float r[4], dm[4];
     Elem<float>::ld4(e.res + off, r);
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + e.bias[n + i]) * dm[i] + r[i];
-    Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
-    float g[4], dm[4];
+    float dm[4];
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -73,14 +70,11 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
       v[i] = ga * dm[i];
       g[i] = gpa * dm[i];
     }
-    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
-    if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g);
   } else if constexpr (EPI == GSL_EPI_MUL) {
     float a[4];
     Elem<T>::ld4(reinterpret_cast<const T*>(e.aux) + off, a);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= a[i];
-    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
   } else if constexpr (EPI == GSL_EPI_PATCH) {
     const int tok = m % e.T;
     float dm[4];
@@ -90,9 +84,70 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
       const float base = (tok == 0) ? e.cls[n + i] : (v[i] + e.bias[n + i]);
       v[i] = (base + e.pos[(size_t)tok * e.N + n + i]) * dm[i];
     }
-    Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   }
 }
+template <int EPI> constexpr bool epi_out_is_f32() { return EPI == GSL_EPI_STORE_F32 || EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_PATCH; }
+
+// direct (fragment-layout) store: 16-byte stores for f32 outputs, 8-byte for bf16 outputs
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float v[4]) {
+  if (m >= e.M || n >= e.N) return;
+  float g[4];
+  epi_math<EPI, T>(e, m, n, v, g);
+  const size_t off = (size_t)m * e.ldo + n;
+  if constexpr (epi_out_is_f32<EPI>()) {
+    Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
+  } else {
+    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
+    if constexpr (EPI == GSL_EPI_BIAS_GELU) { if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g); }
+  }
+}
+
+// bf16-output epilogue of one wave's (NI*16 rows) x 64 columns sub-tile, staged through a wave-private LDS region so
+// that global stores are 16 bytes per lane over FULL 128-byte rows (8 lanes per row, 8 rows per instruction).
+// Measured: the fragment-layout 8-byte stores touch 16 partial (32-byte) lines per instruction and bound the K = 512
+// GEMMs by store transactions, not bytes (f32 output with 2x the bytes costs +5 %; profiles/r01_gemm_ab.md).
+// cst: wave-private LDS, NOUT * 64 rows * CLD bf16. acc tiles are processed in chunks of 4 row-fragments (64 rows).
+constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-way at worst on the ds_write_b64
+template <int EPI, int NI>
+__device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane) {
+  constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
+  const int fr = lane & 15, fc = lane >> 4;
+  const int crow = lane >> 3, cch = lane & 7;
+#pragma unroll
+  for (int ib = 0; ib < NI; ib += 4) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = ib + ii;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
+        const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
+        if (m < e.M && n < e.N) epi_math<EPI, bf16_t>(e, m, n, v, g);
+        bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
+        *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        if constexpr (NOUT == 2) *reinterpret_cast<uint2*>(d + 64 * CLD) = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+      }
+    // the wave's own DS operations execute in order: the reads below see the writes above (no barrier needed)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = r * 8 + crow;
+      const int m = mw + ib * 16 + row, n = nw + cch * 8;
+      if (m < e.M && n < e.N) {
+        const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out) + (size_t)m * e.ldo + n) = val;
+        if constexpr (NOUT == 2) {
+          if (e.out2) {
+            const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n) = val2;
+          }
+        }
+      }
+    }
+  }
+}
+constexpr int CST_WAVE = 2 * 64 * CLD;            // bf16 elements of staging per wave (two outputs)
+constexpr int CST_BLOCK8 = 8 * CST_WAVE;          // 8 waves: 147 456 bytes
 
 // bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
 // range of logical tile ids so neighbouring tiles (same A row-panel) share one L2.
@@ -288,6 +343,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
       }
     }
   }
+  if constexpr (!epi_out_is_f32<EPI>()) {
+    static_assert(3 * ST3 >= CST_BLOCK8, "C staging must fit in the stage ring");
+    if (ABL == 0 && (e.N % 8) == 0 && (e.ldo % 8) == 0) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the stage ring: reuse it for C staging
+      epilogue_staged_bf16<EPI, 4>(e, acc, smem + wave * CST_WAVE, m0 + wm * 64, n0 + wn * 64, lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                              const bf16_t* __restrict__ A2, int lda2,
                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ST4];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4 > CST_BLOCK8) ? 2 * ST4 : CST_BLOCK8];   // stages, then C staging
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -363,6 +426,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
       }
+    }
+  }
+  if constexpr (!epi_out_is_f32<EPI>()) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
+      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
+      return;
     }
   }
 #pragma unroll
