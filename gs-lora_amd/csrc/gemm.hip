@@ -45,8 +45,10 @@ template <int EPI, typename T>
 __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4]) {
   const size_t off = (size_t)m * e.ldo + n;
   const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
+  if (e.alpha != 1.0f) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
+    for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
+  }
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32) {
     if (e.bias) {
 #pragma unroll

@@ -153,7 +153,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // cdf and the pdf (exp(-z^2) with z = |a|/sqrt2 IS exp(-a^2/2)), one v_rcp. ~20 VALU ops instead of ~120.
 __device__ __forceinline__ void gelu_pair_fast(float a, float& g, float& gp) {
   const float z = fabsf(a) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to an 8-op IEEE divide
   const float e = __expf(-z * z);
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, a));

@@ -386,3 +386,34 @@ def test_cpu_inputs_fail_loudly():
     m = build(cfg, "fp32")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 40, 40), torch.zeros(1, dtype=torch.long))
+
+
+def test_own_cl_driver_two_tasks(tmp_path):
+    """The build's counterpart of train_own_forget_cl.py: task loop with prototypes, per-task optimizer and
+    cosine schedule, engine_cl.train_one_epoch, LoRA-norm report, merged checkpoint, reload + re-init."""
+    import driver_cl
+    rep, out, model = driver_cl.main(["--small", "--num_class", "20", "--num_tasks", "2", "--per_forget_cls", "4", "--epochs", "2",
+                                      "--batch_size", "16", "--samples_per_class", "4", "--dtype", "fp32", "--dropout", "0.0",
+                                      "--outdir", str(tmp_path)])
+    assert [r["task"] for r in rep] == [0, 1]
+    order = O.class_order(20, 1337)
+    assert rep[0]["forget_cls"] == order[16:20] and rep[1]["forget_cls"] == order[12:16]       # en1 = num_first - i*per_forget
+    for r in rep:
+        assert abs(r["lrs"][0] - 1e-2) < 1e-12 and abs(r["lrs"][1] - O.cosine_lr(1, epochs=2)) < 1e-12
+        assert len(r["norms"]) == 3 and all(np.isfinite(r["norms"])) and np.isfinite(r["total_loss"])
+        assert r["steps"] == 2 * 4                      # 64 remain images / 16 per batch, two epochs
+    assert os.path.exists(os.path.join(out, "task-level", "Backbone_task_1.pth"))
+    # the saved checkpoint is in merged form: loading it and zeroing B reproduces the trained model's eval logits
+    sd = torch.load(os.path.join(out, "task-level", "Backbone_task_1.pth"), map_location="cpu")
+    x = torch.rand(3, 3, 48, 48).cuda(); y = torch.tensor([1, 2, 3]).cuda()
+    model.eval()
+    with torch.no_grad():
+        ref, _ = model(x, y)
+    m2 = copy.deepcopy(model)
+    m2.load_state_dict(sd)
+    from util.utils import reinitialize_lora_parameters
+    reinitialize_lora_parameters(m2)
+    m2.train()
+    with torch.no_grad():
+        got, _ = m2(x, y)
+    assert (ref - got).abs().max() < 1e-4
