@@ -401,7 +401,8 @@ def test_own_cl_driver_two_tasks(tmp_path):
     for r in rep:
         assert abs(r["lrs"][0] - 1e-2) < 1e-12 and abs(r["lrs"][1] - O.cosine_lr(1, epochs=2)) < 1e-12
         assert len(r["norms"]) == 3 and all(np.isfinite(r["norms"])) and np.isfinite(r["total_loss"])
-        assert r["steps"] == 2 * 4                      # 64 remain images / 16 per batch, two epochs
+        n_remain = (16 - 4 * r["task"]) * 4              # remain classes shrink by per_forget_cls every task
+        assert r["steps"] == 2 * -(-n_remain // 16)      # two epochs over the remain loader (drop_last=False)
     assert os.path.exists(os.path.join(out, "task-level", "Backbone_task_1.pth"))
     # the saved checkpoint is in merged form: loading it and zeroing B reproduces the trained model's eval logits
     sd = torch.load(os.path.join(out, "task-level", "Backbone_task_1.pth"), map_location="cpu")
