@@ -140,15 +140,18 @@ def main():
     meters = pack.tolist()
 
     if rank == 0:
-        M = B * 197
-        durs = [a.elapsed_time(b) for a, b in prof["ffn1"]]          # ms per launch of the fused FFN1+LoRA+GELU GEMM
+        r = FULL["lora_rank"]
+        durs = [a.elapsed_time(b) for a, b, *_ in prof["ffn1"]]       # ms per launch of the fused FFN1+LoRA+GELU GEMM
         avg_ms = sum(durs) / max(1, len(durs))
-        flops = 2.0 * M * FULL["mlp_dim"] * FULL["dim"] + 2.0 * M * FULL["mlp_dim"] * FULL["lora_rank"]
+        # algorithmic flops of one launch: 2*M*N*K for the dense part + 2*M*N*r for the LoRA up-projection K segment
+        fl = [2.0 * m_ * n_ * k1 + 2.0 * m_ * n_ * r for _, _, m_, n_, k1, _ in prof["ffn1"]]
+        flops = sum(fl) / max(1, len(fl))
+        M = prof["ffn1"][0][2] if prof["ffn1"] else 2 * B * 197
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch of the roofline kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("batch") == B:
+            if pj.get("rows_per_launch") == M:
                 traffic = pj["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -162,7 +165,7 @@ def main():
                        "global_batch": world * 2 * B, "tokens_per_image": 197, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "gsl_gemm_nt<BIAS_GELU> (fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout, fwd)",
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "launches_timed": len(durs), "avg_ms": round(avg_ms, 4), "traffic": traffic,
+                         "launches_timed": len(durs), "rows_per_launch": M, "avg_ms": round(avg_ms, 4), "traffic": traffic,
                          "algorithmic_bytes": int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)},
             "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},

@@ -58,7 +58,7 @@ def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, b
         gemm_nt(A1, W1, out, epilogue=epilogue, A2=A2, W2=W2, alpha=alpha, bias=bias, res=res, aux=aux, out2=out2, pos=pos,
                 cls=cls, T=T, p_drop=p_drop, seed=seed, site=site, tag=None)
         ev[1].record()
-        PROFILE[tag].append(ev)
+        PROFILE[tag].append((ev[0], ev[1], M, N, K1, K2))
         return out
     L.check(L.load().gsl_gemm_nt(_p(A1), A1.stride(0), _p(W1), W1.stride(0), K1, _p(A2), 0 if A2 is None else A2.stride(0),
                                  _p(W2), 0 if W2 is None else W2.stride(0), K2, M, N, code(A1.dtype), epilogue, float(alpha),
