@@ -119,11 +119,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   const int nwaves = blockDim.x >> 6;
+  bf16x8_t qn0, qn1;   // Q fragments of the NEXT query tile: their global-load latency hides under this tile's work
+  {
+    const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ld;
+    qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
+  }
   for (int qt = wave; qt < nqt; qt += nwaves) {
     asm volatile("" ::: "memory");   // keep the K / V^T fragment reads inside the loop (LICM would pin 224 VGPRs)
-    const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
-    const bf16_t* qrow = qb + (size_t)qrc * ld;
-    const bf16x8_t qf0 = gl_frag(qrow, 0, fc), qf1 = gl_frag(qrow, 1, fc);
+    const int qr = qt * 16 + fr;
+    const bf16x8_t qf0 = qn0, qf1 = qn1;
+    if (qt + nwaves < nqt) {
+      const bf16_t* qrow = qb + (size_t)min((qt + nwaves) * 16 + fr, T - 1) * ld;
+      qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
+    }
     f32x4_t s[NKT];
     float m = -3.0e38f;
 #pragma unroll

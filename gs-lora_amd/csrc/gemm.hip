@@ -111,13 +111,16 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
 // GEMMs by store transactions, not bytes (f32 output with 2x the bytes costs +5 %; profiles/r01_gemm_ab.md).
 // cst: wave-private LDS, NOUT * 64 rows * CLD bf16. acc tiles are processed in chunks of 4 row-fragments (64 rows).
 constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-way at worst on the ds_write_b64
-template <int EPI, int NI>
+// SEQ = false: both BIAS_GELU outputs staged side by side (2 x 64 rows per wave). SEQ = true: one 64-row region per wave,
+// the second output waits in registers and is staged after the first was copied out (half the LDS: two workgroups per CU).
+template <int EPI, int NI, bool SEQ = false>
 __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane) {
   constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
+    uint2 held[4][4];   // second output, packed, when SEQ
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -128,20 +131,33 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
         if (m < e.M && n < e.N) epi_math<EPI, bf16_t>(e, m, n, v, g);
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
         *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        if constexpr (NOUT == 2) *reinterpret_cast<uint2*>(d + 64 * CLD) = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+        if constexpr (NOUT == 2) {
+          const uint2 pg = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+          if constexpr (SEQ) held[ii][j] = pg; else *reinterpret_cast<uint2*>(d + 64 * CLD) = pg;
+        }
       }
     // the wave's own DS operations execute in order: the reads below see the writes above (no barrier needed)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int row = r * 8 + crow;
-      const int m = mw + ib * 16 + row, n = nw + cch * 8;
-      if (m < e.M && n < e.N) {
-        const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out) + (size_t)m * e.ldo + n) = val;
-        if constexpr (NOUT == 2) {
-          if (e.out2) {
-            const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n) = val2;
+    for (int pass = 0; pass < (SEQ ? NOUT : 1); ++pass) {
+      if (SEQ && pass == 1) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4) = held[ii][j];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = r * 8 + crow;
+        const int m = mw + ib * 16 + row, n = nw + cch * 8;
+        if (m < e.M && n < e.N) {
+          const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
+          bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
+          if (dst) *reinterpret_cast<uint4*>(dst + (size_t)m * e.ldo + n) = val;
+          if constexpr (NOUT == 2 && !SEQ) {
+            if (e.out2) {
+              const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n) = val2;
+            }
           }
         }
       }
@@ -446,6 +462,98 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
     }
 }
 
+// ------------------------------------------------------------------ 256x128x32 tile, 3-stage ring, TWO workgroups per CU
+// 72 KB of LDS and <= 128 VGPRs: two workgroups (16 waves) share a CU and drift out of phase, so one's epilogue
+// (VALU-heavy for BIAS_GELU) runs under the other's MFMA loop. BK = 32 rows are 64 B in LDS; chunk position =
+// c ^ SWZ[(row >> 2) & 3], SWZ = {0,2,3,1}: every ds_read_b128 lane group hits 16 distinct 16-byte slots (0 conflicts
+// measured). Each wave issues 3 DMA instructions per K tile -> vmcnt(3) per tile in flight. bf16 outputs are staged
+// through the (then idle) ring memory, one output at a time (SEQ) so that the staging also fits in 72 KB.
+constexpr int BK9 = 32, ST9 = (256 + 128) * BK9;
+constexpr int SM9 = (3 * ST9 > 8 * 64 * CLD) ? 3 * ST9 : 8 * 64 * CLD;
+__device__ __forceinline__ int swz9(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // {0,2,3,1}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                                 const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                                 const bf16_t* __restrict__ A2, int lda2,
+                                                                 const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SM9];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + 127) / 128;
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m0 = (tile / nbn) * 256, n0 = (tile % nbn) * 128;
+  const int nk1 = K1 / BK9, nk = nk1 + K2 / BK9;
+  const int lrow = lane >> 2, lc = lane & 3;
+
+  auto issue = [&](int kt) {
+    bf16_t* st = smem + (kt % 3) * ST9;
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK9; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK9; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = wave * 2 + i, row = rb * 16 + lrow, c = lc ^ swz9(row);
+      const int gm = min(m0 + row, e.M - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 16 * BK9), 16, 0, 0);
+    }
+    {
+      const int rb = wave, row = rb * 16 + lrow, c = lc ^ swz9(row);
+      const int gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + 256 * BK9 + rb * 16 * BK9), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2);
+    const bf16_t* As = smem + (kt % 3) * ST9;
+    const bf16_t* Ws = As + 256 * BK9;
+    bf16x8_t af[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + fr;
+      af[i] = *reinterpret_cast<const bf16x8_t*>(As + row * BK9 + ((fc ^ swz9(row)) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wn * 64 + j * 16 + fr;
+      wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK9 + ((fc ^ swz9(row)) << 3));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+  if constexpr (!epi_out_is_f32<EPI>()) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the ring: reuse it for C staging
+      epilogue_staged_bf16<EPI, 4, true>(e, acc, smem + wave * (64 * CLD), m0 + wm * 64, n0 + wn * 64, lane);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
@@ -495,13 +603,16 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
-    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage.
-    // Defaults measured on MI355X at M = 100 864 (profiles/r01_gemm_ab.md).
+    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage,
+    // 9 = 256x128x32 ring with two workgroups per CU. Defaults measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md):
+    // the VALU-heavy BIAS_GELU epilogue wants the two-workgroup tile, N >= 512 the 256x256 tile, skinny N the ring.
     const char* ev = getenv("GSL_GEMM_VARIANT");
-    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (e.N >= 1024 ? 4 : 3));
+    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (EPI == GSL_EPI_BIAS_GELU ? 9 : (e.N >= 512 ? 4 : 3)));
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
-    if (variant == 4) {
+    if (variant == 9) {
+      GSL_LAUNCH(gemm_bf16_k32x2_kernel<EPI>, ((e.M + 255) / 256) * ((e.N + 127) / 128), 512);
+    } else if (variant == 4) {
       GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
     } else if (variant == 3) {
       const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);

@@ -16,7 +16,7 @@ using namespace gsl;
 // row chunk in LDS and read as a wave-uniform broadcast. Two deterministic stages: per-row-split
 // partial slabs, then a fixed-order reduction that also applies the output strides.
 // =====================================================================================
-constexpr int LG_ROWS = 32;  // rows of U staged per LDS fill
+constexpr int LG_ROWS = 64;  // rows of U staged per LDS fill
 constexpr int LG_FAN = 32;   // splits summed per thread in the first reduction level
 
 template <typename T> struct LgVec;
@@ -68,15 +68,28 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
     }
     __syncthreads();
     if (active) {
-#pragma unroll 2
-      for (int rr = phase; rr < nr; rr += RP) {
-        float y[V];
-        LgVec<T>::ld(Y + (size_t)(rb + rr) * N + (size_t)cg * V, y);
+      // four independent 16-byte loads in flight per thread before the FMAs (memory-level parallelism: the kernel is
+      // an HBM stream of Y with ~64 accumulators per thread, i.e. low occupancy)
+      for (int rr = phase; rr < nr; rr += 4 * RP) {
+        float y[4][V];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const float u = us[rr][j];
+        for (int k = 0; k < 4; ++k) {
+          const int r = rr + k * RP;
+          if (r < nr) LgVec<T>::ld(Y + (size_t)(rb + r) * N + (size_t)cg * V, y[k]);
+          else {
 #pragma unroll
-          for (int i = 0; i < V; ++i) acc[i][j] = fmaf(y[i], u, acc[i][j]);
+            for (int i = 0; i < V; ++i) y[k][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = min(rr + k * RP, LG_ROWS - 1);
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const float u = us[r][j];
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i][j] = fmaf(y[k][i], u, acc[i][j]);
+          }
         }
       }
     }
