@@ -418,3 +418,63 @@ def test_own_cl_driver_two_tasks(tmp_path):
     with torch.no_grad():
         got, _ = m2(x, y)
     assert (ref - got).abs().max() < 1e-4
+
+
+def _fresh(cfg, dtype="fp32"):
+    from gslora_hip.optim import FusedAdamW
+    m = build(cfg, dtype).train()
+    opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    return m, opt
+
+
+def test_fused_batch_step_equals_two_forward_step():
+    """gs_lora_step concatenates the remain and forget batches into one forward; with p=0 that must be exactly the
+    reference's two-forward arithmetic (per-sample network)."""
+    from gslora_hip import losses
+    from gslora_hip.step import gs_lora_step
+    cfg = recipe.cfg_small2()
+    xr, yr, xf, yf = batches(cfg, 5)
+    proto = losses.prototype_table({c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}, "cuda")
+    outs = []
+    for fuse in (True, False):
+        m, opt = _fresh(cfg)
+        pack = gs_lora_step(m, opt, torch.nn.CrossEntropyLoss(), xr, yr, xf, yf, beta=0.15, alpha=1e-2, BND=105.0, use_prototype=True,
+                            proto_table=proto, w_f=0.05, w_r=0.1, BND_pro=2.0, fuse_batches=fuse)
+        outs.append((pack.cpu(), {n: p.detach().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}))
+    assert (outs[0][0] - outs[1][0]).abs().max() < 1e-4
+    for n in outs[0][1]:
+        assert (outs[0][1][n] - outs[1][1][n]).abs().max() < 1e-5, n
+
+
+def test_single_task_engine_alpha_gate_grouping_and_fewshot_swap():
+    """engine.train_one_epoch (reference engine.py): structure term gated by ALPHA_EPOCH, GROUP_TYPE grouping, literal
+    prototype bound 18, and the few-shot loader inversion (iterate the longer forget loader, cycle the remain loader)."""
+    import engine
+    from util.utils import AverageMeter
+    cfg = recipe.cfg_small2()
+    names = ["losses_forget", "losses_remain", "losses_total", "losses_structure", "top1_forget", "top1_remain"]
+    proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
+    def run(epoch, cfgd, n_forget_batches, n_remain_batches):
+        m, opt = _fresh(cfg)
+        fb = [tuple(t.cpu() for t in batches(cfg, 4, s)[2:]) for s in range(n_forget_batches)]
+        rb = [tuple(t.cpu() for t in batches(cfg, 4, s)[:2]) for s in range(n_remain_batches)]
+        meters = {k: AverageMeter() for k in names}
+        ret = engine.train_one_epoch(model=m, dataloader_forget=fb, dataloader_remain=rb, device=torch.device("cuda"),
+                                     criterion=torch.nn.CrossEntropyLoss(), optimizer=opt, epoch=epoch, beta=0.15, alpha=1e-2, BND=105.0,
+                                     batch=0, testloader_forget=None, testloader_remain=None, forget_acc_before=0.0, highest_H_mean=0.0,
+                                     cfg=cfgd, use_prototype=True, prototype_dict=proto, prototype_weight_forget=0.05,
+                                     prototype_weight_remain=0.1, **meters)
+        return ret, meters
+    base = {"ALPHA_EPOCH": 1, "GROUP_TYPE": "lora", "GROUP_POS": "FFN", "NUM_LAYERS": cfg["depth"], "few_shot": False,
+            "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+    ret, met = run(0, base, 1, 2)                       # epoch < ALPHA_EPOCH: no structure term
+    assert ret[0] == 2 and met["losses_structure"].val == 0.0 and len(ret) == 10
+    ret, met = run(1, base, 1, 2)                       # gated on; 'lora' grouping = 2*depth groups
+    st = O.to_torch(recipe.make_state(cfg))
+    # the meter holds alpha * structure of the parameters at the LAST step; at step 1 it equals the oracle on the initial state
+    ret1, met1 = run(1, base, 1, 1)
+    assert abs(met1["losses_structure"].val - 1e-2 * O.structure_loss(st, cfg, "lora").item()) < 1e-5
+    ret, met = run(1, dict(base, few_shot=True), 3, 1)  # few-shot inversion: 3 forget batches drive the loop
+    assert ret[0] == 3
+    ret, met = run(1, dict(base, few_shot=False), 3, 1)
+    assert ret[0] == 1
