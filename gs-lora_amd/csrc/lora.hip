@@ -38,6 +38,21 @@ template <> struct LgVec<float> {
   }
 };
 
+template <typename T> struct LgRaw;
+template <> struct LgRaw<bf16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ void unpack(const uint4 t, float v[8]) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+template <> struct LgRaw<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ void unpack(const float4 t, float v[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+};
+
 // block = 256 threads = CG column groups x RP row phases (RP = 256 / CG in {1,2,4}); the RP phases walk
 // interleaved rows of the block's row range and are combined through LDS in a fixed order.
 template <typename T, int R>
@@ -59,6 +74,11 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
   for (int i = 0; i < V; ++i)
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[i][j] = 0.f;
+  // Raw 16-byte (V*sizeof(T)) loads are double-buffered in registers: the loads of batch b+1 are issued before the FMAs of
+  // batch b, so every thread always has LGF loads in flight (a thread's rows are otherwise a chain of exposed latencies).
+  constexpr int LGF = 4;
+  using raw_t = typename LgRaw<T>::type;
+  const T* ycol = Y + (size_t)cg * V;
   for (int rb = r0; rb < r1; rb += LG_ROWS) {
     const int nr = min(LG_ROWS, r1 - rb);
     __syncthreads();
@@ -66,31 +86,38 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
       const int rr = t / R, j = t % R;
       us[rr][j] = (rr < nr) ? Elem<T>::ld(U + (size_t)(rb + rr) * ldu + j) : 0.f;
     }
+    raw_t cur[LGF], nxt[LGF];
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < LGF; ++k) {
+        const int r = min(phase + k * RP, nr - 1);
+        cur[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * N);
+      }
+    }
     __syncthreads();
     if (active) {
-      // four independent 16-byte loads in flight per thread before the FMAs (memory-level parallelism: the kernel is
-      // an HBM stream of Y with ~64 accumulators per thread, i.e. low occupancy)
-      for (int rr = phase; rr < nr; rr += 4 * RP) {
-        float y[4][V];
+      for (int rr = phase; rr < nr; rr += LGF * RP) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < LGF; ++k) {     // prefetch the next batch (clamped rows: harmless re-reads at the tail)
+          const int r = min(rr + (LGF + k) * RP, nr - 1);
+          nxt[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * N);
+        }
+#pragma unroll
+        for (int k = 0; k < LGF; ++k) {
           const int r = rr + k * RP;
-          if (r < nr) LgVec<T>::ld(Y + (size_t)(rb + r) * N + (size_t)cg * V, y[k]);
-          else {
+          if (r < nr) {
+            float y[V];
+            LgRaw<T>::unpack(cur[k], y);
 #pragma unroll
-            for (int i = 0; i < V; ++i) y[k][i] = 0.f;
+            for (int j = 0; j < R; ++j) {
+              const float u = us[r][j];
+#pragma unroll
+              for (int i = 0; i < V; ++i) acc[i][j] = fmaf(y[i], u, acc[i][j]);
+            }
           }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = min(rr + k * RP, LG_ROWS - 1);
-#pragma unroll
-          for (int j = 0; j < R; ++j) {
-            const float u = us[r][j];
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[i][j] = fmaf(y[k][i], u, acc[i][j]);
-          }
-        }
+        for (int k = 0; k < LGF; ++k) cur[k] = nxt[k];
       }
     }
   }
@@ -152,7 +179,7 @@ static inline void lg_plan(int M, int N, int V, int R, int& CG, int& bx, int& ns
   const int ncol = N / V;
   CG = ncol >= 256 ? 256 : ((ncol > 64 || R > 8) ? 128 : 64);   // keeps the phase-combine LDS <= 48 KB
   bx = (ncol + CG - 1) / CG;
-  int target = 512 / bx;                    // ~2 blocks per CU in total
+  int target = 768 / bx;                    // ~3 blocks per CU in total
   if (target < 1) target = 1;
   nsplit = (M + 127) / 128;                 // at least 128 rows per split
   if (nsplit > target) nsplit = target;
