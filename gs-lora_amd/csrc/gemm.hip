@@ -462,6 +462,140 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
     }
 }
 
+// ------------------------------------------------------------------ 256x256 kernel with the LoRA rank-r term computed IN the kernel
+//   out = epilogue( A·Wᵀ + t·Qᵀ ),  t = s·(A·Pᵀ)  [M, r],   P [16, K] (rows >= r zero), Q [N, 32] (cols >= r zero)
+// A workgroup streams the whole K range of its 256 rows anyway, so the down-projection t = s·A·Pᵀ costs 16 extra output
+// columns (2 extra MFMAs per 32 per wave and k-step, P rides along in the W stage) instead of a separate launch that re-reads
+// the [M, K] activation from HBM (413-826 MB per call). After the K loop t goes through LDS (C layout -> operand layout),
+// one more MFMA k-step applies the rank-r update, and the N-tile-0 workgroups store t (bf16, zero padded to 64 columns) for
+// the LoRA-gradient reductions. Replaces loralib.Linear's (x @ Aᵀ @ Bᵀ)·scaling (vit_face.py:330,333) and its autograd.
+struct LoraInk {
+  const bf16_t* P; int ldp;
+  const bf16_t* Q; int ldq;
+  float s;
+  bf16_t* tout; int ldt;
+};
+constexpr int ST4L = (BM4 + BN4 + 16) * BK;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_t256_lora_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                                  const bf16_t* __restrict__ W1, int ldw1, int K1, LoraInk lk,
+                                                                  EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4L > CST_BLOCK8) ? 2 * ST4L : CST_BLOCK8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = (e.N + BN4 - 1) / BN4;
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
+  const int nk = K1 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+
+  auto issue = [&](int kt) {
+    bf16_t* st = smem + (kt & 1) * ST4L;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wave * 4 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(A1 + (size_t)gm * lda1 + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(W1 + (size_t)gn * ldw1 + k0 + c * 8), (lptr_t)(st + BM4 * BK + rb * 8 * BK), 16, 0, 0);
+    }
+    if (wave < 2) {   // the 16 rows of P (2 KB) ride along: one extra DMA for waves 0 and 1
+      const int row = wave * 8 + lrow, c = lc ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(lk.P + (size_t)row * lk.ldp + k0 + c * 8), (lptr_t)(st + (BM4 + BN4) * BK + wave * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4], accp[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  accp[0] = accp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const bf16_t* As = smem + (kt & 1) * ST4L;
+    const bf16_t* Ws = As + BM4 * BK;
+    const bf16_t* Ps = Ws + BN4 * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+      }
+      const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(Ps + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + fr;
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
+        if ((i >> 1) == wn)   // wave-uniform: the 4 waves of a row-half split its 8 row fragments of the 16 extra columns
+          accp[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, af, accp[i & 1], 0, 0, 0);
+      }
+    }
+  }
+  // ---- t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg]  -> LDS [256][32] bf16 (cols 16..31 = 0)
+  __builtin_amdgcn_s_barrier();                      // stages are free
+  bf16_t* tbuf = smem;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bf16_t* d = tbuf + (wm * 128 + (2 * wn + t) * 16 + fr) * 32 + fc * 4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
+    *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (n0 == 0 && lk.tout) {                          // one N-tile stores t for the gradient reductions: [M, 64], zero padded
+    const int row = tid >> 1, half = tid & 1;
+    if (m0 + row < e.M) {
+      bf16_t* dst = lk.tout + (size_t)(m0 + row) * lk.ldt + half * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = half ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(tbuf + row * 32 + c * 8);
+        *reinterpret_cast<uint4*>(dst + c * 8) = v;
+      }
+    }
+  }
+  {   // rank-r update: one more k-step (k = 32: r live columns)
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+    }
+  }
+  if constexpr (!epi_out_is_f32<EPI>()) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
+      __builtin_amdgcn_s_barrier();                  // everyone has read tbuf: the C staging may overwrite it
+      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------ 256x128x32 tile, 3-stage ring, TWO workgroups per CU
 // 72 KB of LDS and <= 128 VGPRs: two workgroups (16 waves) share a CU and drift out of phase, so one's epilogue
 // (VALU-heavy for BIAS_GELU) runs under the other's MFMA loop. BK = 32 rows are 64 B in LDS; chunk position =
@@ -679,4 +813,35 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
       return launch_gemm<GSL_EPI_PATCH>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     default: return fail(GSL_ERR_ARG, "gsl_gemm_nt: unknown epilogue%s %ld", "", epilogue);
   }
+}
+
+extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+                                int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
+                                const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                                float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
+  if (dtype != GSL_BF16) return fail(GSL_ERR_UNSUPPORTED, "gsl_gemm_nt_lora: bf16 only (f32 parity mode uses gsl_gemm_nt with a K segment)%s %ld", "", dtype);
+  GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && (K % 64) == 0, "M,N>0, N%4==0, K%64==0");
+  GSL_CHECK_ARG(A && W && P && Q && out, "null operand");
+  GSL_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (ldp % 8) == 0 && (ldq % 8) == 0 && ldq >= 32 && (ldo % 4) == 0 &&
+                (!tout || ((ldt % 8) == 0 && ldt >= 64)), "leading dimensions (P [16,K], Q [N,>=32], tout [M,>=64])");
+  GSL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "p_drop");
+  EpiArgs e;
+  e.alpha = 1.0f; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
+  e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
+  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
+  LoraInk lk;
+  lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
+  const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
+  hipStream_t st = as_stream(s);
+#define GSL_LL(EPIV) hipLaunchKernelGGL(gemm_bf16_t256_lora_kernel<EPIV>, dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, \
+                                        (const bf16_t*)W, ldw, K, lk, e)
+  switch (epilogue) {
+    case GSL_EPI_STORE: GSL_LL(GSL_EPI_STORE); break;
+    case GSL_EPI_BIAS_RES_F32: GSL_CHECK_ARG(bias && res, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_F32); break;
+    case GSL_EPI_BIAS_GELU: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU); break;
+    case GSL_EPI_MUL: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL); break;
+    default: return fail(GSL_ERR_ARG, "gsl_gemm_nt_lora: unsupported epilogue%s %ld", "", epilogue);
+  }
+#undef GSL_LL
+  return check_launch("gsl_gemm_nt_lora");
 }

@@ -23,6 +23,8 @@ SIGNATURES = {
     "gsl_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gsl_gemm_nt": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i,
                     _vp, _vp, _i, _f, _u64, _u32, _vp],
+    "gsl_gemm_nt_lora": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i,
+                         _f, _u64, _u32, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _f, _u64, _u32, _l, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],

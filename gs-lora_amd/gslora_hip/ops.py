@@ -67,6 +67,27 @@ def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, b
     return out
 
 
+def gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, *, epilogue=L.EPI_STORE, bias=None, res=None, aux=None, out2=None, p_drop=0.0,
+                 seed=0, site=0, tag=None):
+    """out = epilogue(A W^T + t Q^T), t = lora_scale * A P^T computed inside the kernel and stored to tout [M,64] (bf16)."""
+    _need(A, W, P, Q, tout, out, bias, res, aux, out2)
+    M, K = A.shape
+    N = W.shape[0]
+    if PROFILE is not None and tag in PROFILE:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, epilogue=epilogue, bias=bias, res=res, aux=aux, out2=out2, p_drop=p_drop,
+                     seed=seed, site=site)
+        ev[1].record()
+        PROFILE[tag].append((ev[0], ev[1], M, N, K, 0))
+        return out
+    L.check(L.load().gsl_gemm_nt_lora(_p(A), A.stride(0), _p(W), W.stride(0), K, _p(P), P.stride(0), _p(Q), Q.stride(0),
+                                      float(lora_scale), _p(tout), 0 if tout is None else tout.stride(0), M, N, code(A.dtype), epilogue,
+                                      _p(bias), _p(res), _p(aux), _p(out), _p(out2), out.stride(0), float(p_drop), int(seed), int(site),
+                                      _stream()), "gsl_gemm_nt_lora")
+    return out
+
+
 def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     _need(x, gamma, beta)
     y = torch.empty(M, D, device=x.device, dtype=dtype)

@@ -124,8 +124,21 @@ class ViTRunner:
                 return ops.pack_pad(p, 1, r, r, rows, PADK, rows, dtype)
             if kind == "AT_cols":     # [K, 64]  out[k, j] = A[j, k]
                 return ops.pack_pad(p, 1, cols, cols, r, cols, PADK, dtype)
+            # operands of the in-kernel LoRA GEMM (gsl_gemm_nt_lora): P [16, K], Q [N, 32]
+            if kind == "A_rows16":
+                return ops.pack_pad(p, cols, 1, r, cols, 16, cols, dtype)
+            if kind == "B_cols32":
+                return ops.pack_pad(p, r, 1, rows, r, rows, 32, dtype)
+            if kind == "BT_rows16":
+                return ops.pack_pad(p, 1, r, r, rows, 16, rows, dtype)
+            if kind == "AT_cols32":
+                return ops.pack_pad(p, 1, cols, cols, r, cols, 32, dtype)
             raise ValueError(kind)
         return self._cached(self._lcache, (name, kind, dtype), param, build)
+
+    def lora_in_kernel(self, dtype, rows):
+        """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation)."""
+        return dtype == torch.bfloat16 and rows >= 1024 and self.model.lora_rank <= 16
 
     def ensure_bucket(self):
         m = self.model
@@ -192,14 +205,20 @@ class ViTRunner:
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                             p_drop=p_drop, seed=seed, site=4 * i + 1, tag="ffn1")
                 u2 = torch.empty(M, PADK, device=img.device, dtype=dt)
-                ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
+                if not self.lora_in_kernel(dt, M):
+                    ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, bias=l1.bias.detach(),
                             out2=gp, p_drop=p_drop, seed=seed, site=4 * i + 1)
             x2 = torch.empty(M, D, device=img.device, dtype=torch.float32)
-            ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=L.EPI_BIAS_RES_F32, A2=u2,
-                        W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
-                        bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
+            if lora_on and self.lora_in_kernel(dt, M):
+                ops.gemm_nt_lora(h, self.w(f"w2_{i}", l2.weight, dt), self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows16", dt),
+                                 self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols32", dt), s_lora, u2, x2, epilogue=L.EPI_BIAS_RES_F32,
+                                 bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
+            else:
+                ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=L.EPI_BIAS_RES_F32, A2=u2,
+                            W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
+                            bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
                                   xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on))
@@ -260,22 +279,34 @@ class ViTRunner:
                 dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
             Mrows = dyb.shape[0]
             # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
+            ink = self.lora_in_kernel(dt, Mrows)
             v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
-            ops.gemm_nt(dyb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
-            ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
-                        W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp)
+            if ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
+                ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
+                                 self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=L.EPI_MUL, aux=gp)
+            else:
+                ops.gemm_nt(dyb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
+                ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
+                            W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp)
             ops.lora_grad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                # dB2[c, j]
             ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)                # dA2[j, hid]
             v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
-            ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
+            dxn2 = None
+            if ink and i > 0:   # v1 = s*da*B1 is produced inside the FFN1-dX GEMM
+                dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
+                ops.gemm_nt_lora(da, self.wT(f"w1_{i}", l1.weight, dt), self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows16", dt),
+                                 self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols32", dt), s_lora, v1, dxn2)
+            else:
+                ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
             ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)                 # dB1[hid, j]
             ops.lora_grad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                # dA1[j, c]
             if i == 0:
                 break   # nothing below the layer-0 FFN input is trainable
-            dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
-            ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2, A2=v1,
-                        W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
+            if dxn2 is None:
+                dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
+                ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2, A2=v1,
+                            W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
             del da, v1, v2
             n2 = ffn.norm
             if sparse:   # update the cls rows of the dense stream gradient in place; dx1b is the compact masked copy

@@ -66,6 +66,18 @@ int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
                 const float* pos, const float* cls, int T,
                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
 
+/* Same GEMM with the LoRA rank-r term produced INSIDE the kernel (bf16 only; replaces the two-launch form
+ * t = s*(A P^T) [gsl_gemm_nt, N=64] ; out = A W^T + t Q^T [gsl_gemm_nt with a K segment], and saves one full read of A):
+ *   out = epilogue(A*W^T + t*Q^T),  t = lora_scale * (A*P^T)
+ *   A [M,K] (lda), W [N,K] (ldw), P [16,K] (ldp; rows >= r zero), Q [N,32] (ldq >= 32; cols >= r zero), K % 64 == 0.
+ *   tout (nullable) [M, ldt >= 64] receives t in bf16, zero padded to 64 columns (input of gsl_lora_grad).
+ * Epilogues: STORE, BIAS_RES_F32, BIAS_GELU, MUL. */
+int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
+                     const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
+                     int M, int N, int dtype, int epilogue,
+                     const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                     float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+
 /* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x f32 rows of length D at
  * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
 int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,

@@ -327,3 +327,38 @@ def test_layernorm_bwd_strided_inplace(ops, dt):
     assert (dx.cpu().view(B, T, D) - want).abs().max() < 2e-5
     keep = ops.dropout_mask(B * T * D, 0.5, 3, 9, "cuda").cpu().view(B, T, D)[:, 0].float()
     assert (dxb.float().cpu() - want[:, 0] * keep * 2).abs().max() < tol(dt, 4e-5, 6e-2)
+
+
+@pytest.mark.parametrize("M,N,K,r", [(2100, 512, 2048, 8), (1300, 2048, 512, 8), (1111, 768, 256, 16), (300, 256, 64, 4)])
+def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
+    """out = epilogue(A W^T + t Q^T), t = s*(A P^T) computed inside the kernel; t is also returned (bf16, padded to 64)."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    P = torch.zeros(16, K); P[:r] = rnd(r, K, seed=3, scale=K ** -0.5)
+    Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
+    s = 1.0 / r
+    bias, res, aux = rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    t_ref = (s * (as_dt(A, dt) @ as_dt(P, dt).t())).bfloat16().float()          # the kernel rounds t to bf16 before the update
+    acc = as_dt(A, dt) @ as_dt(W, dt).t() + t_ref @ as_dt(Q, dt)[:, :16].t()
+    c = lambda t: t.cuda().to(dt)
+    tout = torch.full((M, 64), 7.0, device="cuda", dtype=dt)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt_lora(c(A), c(W), c(P), c(Q), s, tout, out)
+    assert relerr(out.float().cpu(), acc) < 1.5e-2
+    assert (tout.float().cpu()[:, :16] - t_ref).abs().max() < 2e-2 * max(1.0, t_ref.abs().max().item())
+    assert (tout[:, r:] == 0).all()
+    outf = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt_lora(c(A), c(W), c(P), c(Q), s, tout, outf, epilogue=L.EPI_BIAS_RES_F32, bias=bias.cuda(), res=res.cuda())
+    assert relerr(outf.cpu(), acc + bias + res) < 4e-3
+    ops.gemm_nt_lora(c(A), c(W), c(P), c(Q), s, None, out, epilogue=L.EPI_MUL, aux=c(aux))
+    assert relerr(out.float().cpu(), acc * as_dt(aux, dt)) < 1.5e-2
+    # agrees with the two-launch form it replaces
+    t2 = torch.zeros(M, 64, device="cuda", dtype=dt)
+    P64 = torch.zeros(64, K); P64[:16] = P
+    Q64 = torch.zeros(N, 64); Q64[:, :32] = Q
+    ops.gemm_nt(c(A), c(P64), t2, alpha=s)
+    out2 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(c(A), c(W), out2, epilogue=L.EPI_STORE_F32, A2=t2, W2=c(Q64))
+    ops.gemm_nt_lora(c(A), c(W), c(P), c(Q), s, tout, outf, epilogue=L.EPI_BIAS_RES_F32, bias=torch.zeros(N).cuda(), res=torch.zeros(M, N).cuda())
+    assert relerr(outf.cpu(), out2.cpu()) < 2e-3
