@@ -51,13 +51,12 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
 }
 // stage the same panel transposed: dst[d][t], leading dim VLD = TP + 8, zero columns >= T.
 // Each thread owns an 8 (keys) x 8 (d) block: eight 16-byte global loads, an in-register 8x8 transpose of the
-// packed bf16 pairs, eight 16-byte LDS stores (consecutive lanes -> consecutive key blocks of one d row:
-// conflict-free). This replaces 64 two-byte scattered LDS writes per thread.
+// packed bf16 pairs, eight 16-byte LDS stores. This replaces 64 two-byte scattered LDS writes per thread.
 template <int TP>
 __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long ld, int T) {
   constexpr int VLD = TP + 8, NKB = TP / 8;
   for (int idx = threadIdx.x; idx < NKB * 8; idx += blockDim.x) {
-    const int kb = idx % NKB, c = idx / NKB;
+    const int c = idx & 7, kb = idx >> 3;   // 8 lanes cover one 128-byte row: coalesced global loads (the LDS stores conflict, but are few)
     uint32_t w[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -285,55 +284,77 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nkt = (T + 15) / 16;
   const int nwaves = blockDim.x >> 6;
-  for (int kt = wave; kt < nkt; kt += nwaves) {
-    const int kr = kt * 16 + fr, krc = min(kr, T - 1);
-    const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
-    const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
-    const bf16x8_t kf0 = gl_frag(krow, 0, fc), kf1 = gl_frag(krow, 1, fc);
-    const bf16x8_t vf0 = gl_frag(vrow, 0, fc), vf1 = gl_frag(vrow, 1, fc);
-    f32x4_t adk[4], adv[4];
+  // Each wave owns TWO adjacent key tiles: every Q / dO / Q^T / dO^T fragment read from LDS feeds two MFMAs (one per
+  // key tile). The kernel is LDS-bandwidth-bound (1 KB of fragment reads per MFMA when a wave owns a single tile).
+  for (int kp = wave; kp * 2 < nkt; kp += nwaves) {
+    bf16x8_t kf[2][2], vf[2][2];
+    int kr[2];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 2; ++t) {
+      kr[t] = (kp * 2 + t) * 16 + fr;
+      const int krc = min(kr[t], T - 1);
+      const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
+      const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+      kf[t][0] = gl_frag(krow, 0, fc); kf[t][1] = gl_frag(krow, 1, fc);
+      vf[t][0] = gl_frag(vrow, 0, fc); vf[t][1] = gl_frag(vrow, 1, fc);
+    }
+    f32x4_t adk[2][4], adv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { adk[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int qp = 0; qp < NKT / 2; ++qp) {
-      Frag pf, dsf;
+      Frag pf[2], dsf[2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qt = 2 * qp + half;
-        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sa = mfma16(lds_frag_rm(Qs, qt * 16 + fr, 0, fc), kf0, sa);   // S[q = qt*16+fc*4+r][key = fr]
-        sa = mfma16(lds_frag_rm(Qs, qt * 16 + fr, 1, fc), kf1, sa);
-        dp = mfma16(lds_frag_rm(Os, qt * 16 + fr, 0, fc), vf0, dp);   // dP[q][key]
-        dp = mfma16(lds_frag_rm(Os, qt * 16 + fr, 1, fc), vf1, dp);
+        const bf16x8_t q0 = lds_frag_rm(Qs, qt * 16 + fr, 0, fc), q1 = lds_frag_rm(Qs, qt * 16 + fr, 1, fc);
+        const bf16x8_t g0 = lds_frag_rm(Os, qt * 16 + fr, 0, fc), g1 = lds_frag_rm(Os, qt * 16 + fr, 1, fc);
         const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[qt * 16 + fc * 4]);
         const float4 d4 = *reinterpret_cast<const float4*>(&del_s[qt * 16 + fc * 4]);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-        float p[4], ds[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[r] = __expf(sa[r] * scale - lv[r]);
-          ds[r] = p[r] * (dp[r] - dv[r]) * scale;
-        }
-        if (half == 0) {
-          pf.u.x = pack2bf(p[0], p[1]); pf.u.y = pack2bf(p[2], p[3]);
-          dsf.u.x = pack2bf(ds[0], ds[1]); dsf.u.y = pack2bf(ds[2], ds[3]);
-        } else {
-          pf.u.z = pack2bf(p[0], p[1]); pf.u.w = pack2bf(p[2], p[3]);
-          dsf.u.z = pack2bf(ds[0], ds[1]); dsf.u.w = pack2bf(ds[2], ds[3]);
+        for (int t = 0; t < 2; ++t) {
+          f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sa = mfma16(q0, kf[t][0], sa);   // S[q = qt*16+fc*4+r][key = fr of tile t]
+          sa = mfma16(q1, kf[t][1], sa);
+          dp = mfma16(g0, vf[t][0], dp);   // dP[q][key]
+          dp = mfma16(g1, vf[t][1], dp);
+          float p[4], ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[r] = __expf(sa[r] * scale - lv[r]);
+            ds[r] = p[r] * (dp[r] - dv[r]) * scale;
+          }
+          if (half == 0) {
+            pf[t].u.x = pack2bf(p[0], p[1]); pf[t].u.y = pack2bf(p[2], p[3]);
+            dsf[t].u.x = pack2bf(ds[0], ds[1]); dsf[t].u.y = pack2bf(ds[2], ds[3]);
+          } else {
+            pf[t].u.z = pack2bf(p[0], p[1]); pf[t].u.w = pack2bf(p[2], p[3]);
+            dsf[t].u.z = pack2bf(ds[0], ds[1]); dsf[t].u.w = pack2bf(ds[2], ds[3]);
+          }
         }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        adv[dt] = mfma16(lds_frag_tr<VLD>(Ot, dt * 16 + fr, qp, fc), pf.v, adv[dt]);    // dVᵀ[d][key]
-        adk[dt] = mfma16(lds_frag_tr<VLD>(Qt, dt * 16 + fr, qp, fc), dsf.v, adk[dt]);   // dKᵀ[d][key]
+        const bf16x8_t ot = lds_frag_tr<VLD>(Ot, dt * 16 + fr, qp, fc), qtf = lds_frag_tr<VLD>(Qt, dt * 16 + fr, qp, fc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          adv[t][dt] = mfma16(ot, pf[t].v, adv[t][dt]);     // dV^T[d][key]
+          adk[t][dt] = mfma16(qtf, dsf[t].v, adk[t][dt]);   // dK^T[d][key]
+        }
       }
     }
-    if (kr < T) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16_t* base = dqkv + ((size_t)b * T + kr) * ld + h * HD + dt * 16 + fc * 4;
-        store4bf(base + H * HD, adk[dt], 1.0f);
-        store4bf(base + 2 * H * HD, adv[dt], 1.0f);
+    for (int t = 0; t < 2; ++t) {
+      if (kr[t] < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16_t* base = dqkv + ((size_t)b * T + kr[t]) * ld + h * HD + dt * 16 + fc * 4;
+          store4bf(base + H * HD, adk[t][dt], 1.0f);
+          store4bf(base + 2 * H * HD, adv[t][dt], 1.0f);
+        }
       }
     }
   }

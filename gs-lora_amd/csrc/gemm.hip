@@ -639,6 +639,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* _
     }
   };
 
+  // Two workgroups share a CU. Launched together they would stay in lock step (both in the MFMA loop, then both in the
+  // VALU/store epilogue); delaying the workgroups that fill the SECOND slot of every CU (the dispatcher hands out blocks
+  // 0..255 first) by about half a tile puts the pair out of phase for the rest of the launch: one's epilogue runs under
+  // the other's MFMAs. e.T carries the delay (units of s_sleep 127 = 8128 clocks); placement-independent for correctness.
+  if (e.T > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int d = 0; d < e.T; ++d) __builtin_amdgcn_s_sleep(127);
+  }
   f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -745,7 +752,10 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
     if (variant == 9) {
-      GSL_LAUNCH(gemm_bf16_k32x2_kernel<EPI>, ((e.M + 255) / 256) * ((e.N + 127) / 128), 512);
+      EpiArgs e9 = e;
+      if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }
+      hipLaunchKernelGGL(gemm_bf16_k32x2_kernel<EPI>, dim3(((e.M + 255) / 256) * ((e.N + 127) / 128)), dim3(512), 0, st, (const bf16_t*)A1, lda1,
+                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e9);
     } else if (variant == 4) {
       GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
     } else if (variant == 3) {

@@ -117,11 +117,12 @@ inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
   d.scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
   return d;
 }
-// one 32-bit hash serves the element pair (2k, 2k+1): low / high 16 bits
+// one 32-bit hash serves the element pair (2k, 2k+1): low / high 16 bits. Two multiply rounds on the 32-bit pair
+// counter (the high counter word only perturbs the key): 6 integer ops per pair — the epilogue that uses it is VALU-bound
+// (profiles/r01_gemm_ab.md), every instruction per element counts.
 __device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint64_t pair) {
-  uint32_t x = (uint32_t)pair ^ key;
-  x += (uint32_t)(pair >> 32) * 0x9E3779B1u;
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  uint32_t x = ((uint32_t)pair ^ key) * 0x9E3779B1u + (uint32_t)(pair >> 32);
+  x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
   return x;
 }
 // multiplier to apply to an element: 0 or 1/(1-p)
@@ -154,7 +155,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ void gelu_pair_fast(float a, float& g, float& gp) {
   const float z = fabsf(a) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to an 8-op IEEE divide
-  const float e = __expf(-z * z);
+  const float e = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);   // exp(-a^2/2) = 2^(-a^2 * log2(e)/2): one v_exp_f32
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, a));
   g = a * cdf;
