@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, float eps, const float* __restrict__ Wn,
                                                        const int64_t* __restrict__ label, float* __restrict__ emb,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
-                                                       float* __restrict__ logits, int D, int C, float cs, float cm) {
+                                                       float* __restrict__ logits, int D, int C, float cs, float cm,
+                                                       const float* __restrict__ hbias, int linear) {
   __shared__ float e[HEAD_MAXD];
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -89,19 +90,22 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   for (int c = wave; c < C; c += 4) {
     float dot = 0.f;
     for (int d = lane; d < D; d += 64) dot += e[d] * Wn[(size_t)c * D + d];
-    dot = wave_sum(dot) * inv;
-    if (lane == 0) logits[(size_t)b * C + c] = cs * ((c == lab) ? (dot - cm) : dot);
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      if (linear) logits[(size_t)b * C + c] = dot + (hbias ? hbias[c] : 0.f);     // plain nn.Linear head (modified_VIT.py:34-36)
+      else { dot *= inv; logits[(size_t)b * C + c] = cs * ((c == lab) ? (dot - cm) : dot); }
+    }
   }
 }
 
 extern "C" int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps, const float* Wn,
                             const int64_t* label, float* emb, float* mean, float* rstd, float* logits, int B, int D, int C,
-                            float cos_s, float cos_m, gsl_stream_t s) {
+                            float cos_s, float cos_m, const float* head_bias, int linear_head, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
   GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
   hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, as_stream(s), x, T, gamma, beta, eps, Wn, label, emb, mean, rstd,
-                     logits, D, C, cos_s, cos_m);
+                     logits, D, C, cos_s, cos_m, head_bias, linear_head);
   return check_launch("gsl_head_fwd");
 }
 
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ emb, const float* __restrict__ Wn,
                                                        float* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
-                                                       DropCfg drop) {
+                                                       DropCfg drop, int linear) {
   __shared__ float de[HEAD_MAXD];   // d emb
   __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
   __shared__ float sm[16];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const float* xr = x + (size_t)b * Tn * D;
   float s1 = 0.f, s2 = 0.f;
   for (int d = tid; d < D; d += 256) {
-    float g = (de[d] - er[d] * proj) / nrm;               // d emb from CosFace
+    float g = linear ? de[d] : (de[d] - er[d] * proj) / nrm;   // d emb from the Linear / CosFace head
     if (demb_in) g += demb_in[(size_t)b * D + d];
     g *= gamma[d];
     de[d] = g;
@@ -171,17 +175,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
                             const float* mean, const float* rstd, const float* emb, const float* Wn, float* dx, void* dxb,
                             int B, int D, int C, float cos_s, int dtype, float p_drop, uint64_t seed, uint32_t site,
-                            gsl_stream_t s) {
+                            int linear_head, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T > 1, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
   GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
   const DropCfg drop = make_drop(p_drop, seed, site);
   if (dtype == GSL_BF16)
     hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop);
+                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head);
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (float*)dxb, D, C, cos_s, drop);
+                       Wn, dx, (float*)dxb, D, C, cos_s, drop, linear_head);
   else return fail(GSL_ERR_ARG, "gsl_head_bwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_head_bwd");
 }

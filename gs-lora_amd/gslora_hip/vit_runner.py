@@ -13,9 +13,35 @@ import torch
 from . import _lib as L
 from . import ops
 
-COS_S, COS_M, LN_EPS = 64.0, 0.35, 1e-5   # vit_face.py:158 ; nn.LayerNorm default
 PADK = 64                                  # LoRA K-segment width fed to the GEMM (r zero-padded to 64)
 SITE_EMB = 1_000_000
+
+
+class BlockSpec:
+    """One pre-norm transformer block as the kernels see it: x1 = x + drop(Wo attn(LN1 x) + bo), x2 = x1 + drop(W2' drop(gelu(W1' LN2 x1)))."""
+    __slots__ = ("ln1", "qkv_w", "qkv_b", "out", "ln2", "l1", "l2")
+
+    def __init__(self, ln1, qkv_w, qkv_b, out, ln2, l1, l2):
+        self.ln1, self.qkv_w, self.qkv_b, self.out, self.ln2, self.l1, self.l2 = ln1, qkv_w, qkv_b, out, ln2, l1, l2
+
+    def lora_params(self):
+        return (self.l1.lora_A, self.l1.lora_B, self.l2.lora_A, self.l2.lora_B)
+
+
+class ModelSpec:
+    """Geometry + parameter handles of one model family. Built by the model's `hip_spec()` on every forward (attribute
+    look-ups only), so module surgery between calls — replace_ffn_with_lora, modify_head, load_state_dict — is picked up.
+      ViT_face      (vit_pytorch_face/vit_face.py:449-548): Linear patch embedding, bias-free QKV, LN eps 1e-5,
+                    scale dim^-0.5, CosFace head (s 64, m 0.35).
+      ModifiedViT   (vit_pytorch_face/modified_VIT.py:5-45 over torchvision vit_b_16): conv16 patch embedding, QKV bias,
+                    LN eps 1e-6, scale head_dim^-0.5, nn.Linear head with bias, the label argument is ignored."""
+    __slots__ = ("patch_size", "num_tokens", "dim", "heads", "attn_scale", "ln_eps", "dropout_p", "emb_dropout_p", "lora_rank",
+                 "patch_w", "patch_is_conv", "patch_b", "cls", "pos", "blocks", "final_ln", "head_kind", "head_w", "head_b",
+                 "cos_s", "cos_m")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw[k])
 
 
 class LoraBucket:
@@ -85,6 +111,7 @@ class ViTRunner:
         self.bucket = None
         self._wcache = {}
         self._lcache = {}
+        self._rank = 0
         self.drop_seed = 0x5EED
         self.drop_calls = 0
 
@@ -107,15 +134,21 @@ class ViTRunner:
             return param.detach()
         return self._cached(self._wcache, (name, "n", dtype), param, lambda p: ops.cast(p.contiguous(), dtype))
 
+    def w_conv(self, name, param, dtype):
+        """conv_proj weight [D, C, p, p] as the [D, p*p*C] operand matching gsl_patchify's (p1 p2 c) feature order."""
+        def build(p):
+            w2 = p.permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous()
+            return w2 if dtype == torch.float32 else ops.cast(w2, dtype)
+        return self._cached(self._wcache, (name, "conv", dtype), param, build)
+
     def wT(self, name, param, dtype):
         """[K,N] transposed operand (dX GEMMs)."""
         return self._cached(self._wcache, (name, "t", dtype), param, lambda p: ops.transpose_cast(p.contiguous(), dtype))
 
     def lora_pack(self, name, param, kind, dtype):
-        r = self.model.lora_rank
-
         def build(p):
             rows, cols = p.shape
+            r = min(rows, cols)
             if kind == "A_rows":      # [64, K]  rows j<r = A[j,:]
                 return ops.pack_pad(p, cols, 1, r, cols, PADK, cols, dtype)
             if kind == "B_cols":      # [N, 64]  cols j<r = B[:,j]
@@ -138,14 +171,16 @@ class ViTRunner:
 
     def lora_in_kernel(self, dtype, rows):
         """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation)."""
-        return dtype == torch.bfloat16 and rows >= 1024 and self.model.lora_rank <= 16
+        return dtype == torch.bfloat16 and rows >= 1024 and self._rank <= 16
 
-    def ensure_bucket(self):
-        m = self.model
-        if m.lora_rank <= 0:
+    def ensure_bucket(self, spec=None):
+        spec = spec or self.model.hip_spec()
+        self._rank = spec.lora_rank
+        if spec.lora_rank <= 0:
             return None
-        if self.bucket is None or not self.bucket.valid():
-            self.bucket = LoraBucket([blk.lora_params() for blk in m.ffn_blocks()])
+        layers = [blk.lora_params() for blk in spec.blocks]
+        if self.bucket is None or not self.bucket.valid() or any(a is not b for a, b in zip(self.bucket.params, (p for g in layers for p in g))):
+            self.bucket = LoraBucket(layers)
             self._lcache.clear()
         return self.bucket
 
@@ -153,46 +188,50 @@ class ViTRunner:
     def forward(self, img, label, save):
         m = self.model
         if not img.is_cuda:
-            raise RuntimeError("ViT_face (gs-lora_amd): the model runs only on a ROCm GPU through libgslora_hip.so; "
+            raise RuntimeError(f"{type(m).__name__} (gs-lora_amd): the model runs only on a ROCm GPU through libgslora_hip.so; "
                                "there is no CPU fallback. Move the model and inputs to 'cuda'.")
         L.load()
+        sp = m.hip_spec()
         dt = m.compute_dtype
         img = img.float().contiguous()
-        if label is not None:
+        linear_head = sp.head_kind == "linear"
+        if linear_head:
+            label = None                       # modified_VIT.py:23-24: "label is not used in this model"
+        elif label is not None:
             label = label.to(device=img.device, dtype=torch.int64).contiguous()
         B = img.shape[0]
-        T, D, H = m.num_tokens, m.dim, m.heads
+        T, D, H = sp.num_tokens, sp.dim, sp.heads
         M = B * T
         training = m.training
-        p_drop = m.dropout_p if training else 0.0
-        p_emb = m.emb_dropout_p if training else 0.0
+        p_drop = sp.dropout_p if training else 0.0
+        p_emb = sp.emb_dropout_p if training else 0.0
         self.drop_calls += 1
         seed = (self.drop_seed << 20) + self.drop_calls
-        self.ensure_bucket()
-        r = m.lora_rank
+        self.ensure_bucket(sp)
+        r = sp.lora_rank
         s_lora = (1.0 / r) if r > 0 else 0.0
+        eps = sp.ln_eps
 
-        patches = ops.patchify(img, m.patch_size, dt)
+        patches = ops.patchify(img, sp.patch_size, dt)
         x = torch.empty(M, D, device=img.device, dtype=torch.float32)
-        pe = m.patch_to_embedding
-        ops.gemm_nt(patches, self.w("pe", pe.weight, dt), x, epilogue=L.EPI_PATCH, bias=pe.bias.detach(),
-                    pos=m.pos_embedding.detach()[0, :T].contiguous(), cls=m.cls_token.detach().reshape(-1), T=T,
+        pw = self.w_conv("pe", sp.patch_w, dt) if sp.patch_is_conv else self.w("pe", sp.patch_w, dt)
+        ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH, bias=sp.patch_b.detach(),
+                    pos=sp.pos.detach()[0, :T].contiguous(), cls=sp.cls.detach().reshape(-1), T=T,
                     p_drop=p_emb, seed=seed, site=SITE_EMB)
         del patches
         stash = []
-        for i, (attn, ffn) in enumerate(m.blocks()):
-            n1, n2 = attn.norm, ffn.norm
-            at, ff = attn.fn, ffn.fn
-            xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), LN_EPS, dt)
+        for i, blk in enumerate(sp.blocks):
+            n1, n2 = blk.ln1, blk.ln2
+            xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
             qkv = torch.empty(M, 3 * H * 64, device=img.device, dtype=dt)
-            ops.gemm_nt(xn, self.w(f"qkv{i}", at.to_qkv.weight, dt), qkv)
+            ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             del xn
-            o, lse = ops.attention_fwd(qkv, B, T, H, m.attn_scale)
+            o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale)
             x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
-            ops.gemm_nt(o, self.w(f"wo{i}", at.to_out[0].weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
-                        bias=at.to_out[0].bias.detach(), res=x, p_drop=p_drop, seed=seed, site=4 * i)
-            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), LN_EPS, dt)
-            l1, l2 = ff.net[0], ff.net[3]
+            ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
+                        bias=blk.out.bias.detach(), res=x, p_drop=p_drop, seed=seed, site=4 * i)
+            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
+            l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
             lora_on = r > 0 and not l1.merged
             u1 = u2 = None
@@ -223,31 +262,37 @@ class ViTRunner:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
                                   xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on))
             x = x2
-        hn = m.mlp_head[0]
-        Wn = ops.cosface_prep(m.loss.weight.detach().contiguous()) if label is not None else None
-        logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), LN_EPS, Wn, label,
-                                                 COS_S, COS_M)
+        hn = sp.final_ln
+        if linear_head:      # plain classifier: logits for every call, no normalisation, no margin
+            Wn = sp.head_w.detach().contiguous()
+            logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, None, 1.0, 0.0,
+                                                     head_bias=sp.head_b.detach(), linear=True)
+        else:
+            Wn = ops.cosface_prep(sp.head_w.detach().contiguous()) if label is not None else None
+            logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, label,
+                                                     sp.cos_s, sp.cos_m)
         saved = None
         if save:
             saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, p_drop=p_drop,
-                         dt=dt)
+                         dt=dt, spec=sp)
         return logits, emb, saved
 
     # ------------------------------------------------------------------ backward
     def backward(self, saved, dlogits, demb):
         """Accumulates d(loss)/d(LoRA) into the flat gradient bucket (views are the params' .grad)."""
-        m = self.model
+        sp = saved["spec"]
         bucket = self.bucket
         if bucket is None:
             return
         bucket.attach_grads()
         dt = saved["dt"]
         B, seed, p_drop = saved["B"], saved["seed"], saved["p_drop"]
-        T, D, H = m.num_tokens, m.dim, m.heads
-        r = m.lora_rank
+        T, D, H = sp.num_tokens, sp.dim, sp.heads
+        r = sp.lora_rank
         s_lora = 1.0 / r
         nl = len(saved["layers"])
-        hn = m.mlp_head[0]
+        hn = sp.final_ln
+        linear_head = sp.head_kind == "linear"
         if dlogits is not None:
             dlogits = dlogits.contiguous().float()
         if demb is not None:
@@ -255,16 +300,16 @@ class ViTRunner:
         if dlogits is not None and saved["Wn"] is None:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
-                               saved["emb"], saved["Wn"], COS_S, dt, p_drop=p_drop, seed=seed, site=4 * (nl - 1) + 2)
-        blocks = list(m.blocks())
+                               saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
+                               site=4 * (nl - 1) + 2, linear=linear_head)
+        blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()     # rows b*T of a [B*T, w] tensor
         for i in reversed(range(nl)):
             st = saved["layers"][i]
-            attn, ffn = blocks[i]
-            at, ff = attn.fn, ffn.fn
-            l1, l2 = ff.net[0], ff.net[3]
+            blk = blocks[i]
+            l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
             if not st["lora_on"]:
                 raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
@@ -308,7 +353,7 @@ class ViTRunner:
                 ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2, A2=v1,
                             W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
             del da, v1, v2
-            n2 = ffn.norm
+            n2 = blk.ln2
             if sparse:   # update the cls rows of the dense stream gradient in place; dx1b is the compact masked copy
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
                                               cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
@@ -319,15 +364,15 @@ class ViTRunner:
             del dxn2
             # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
-            ops.gemm_nt(dx1b, self.wT(f"wo{i}", at.to_out[0].weight, dt), d_o)
+            ops.gemm_nt(dx1b, self.wT(f"wo{i}", blk.out.weight, dt), d_o)
             if sparse:
-                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
+                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
             else:
-                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, m.attn_scale)
+                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
             dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)
-            ops.gemm_nt(dqkv, self.wT(f"qkv{i}", at.to_qkv.weight, dt), dxn1)
+            ops.gemm_nt(dqkv, self.wT(f"qkv{i}", blk.qkv_w, dt), dxn1)
             del d_o, dqkv, dx1b
-            n1 = attn.norm
+            n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
                                         p_drop=p_drop, seed=seed, site=4 * (i - 1) + 2)
             saved["layers"][i] = None   # free this layer's activations

@@ -5,8 +5,10 @@ import torch
 
 def get_norm_of_lora(model, type="L2", group_num=6, group_type: str = "block", group_pos: str = "FFN",
                      imagenet: bool = False):
-    if imagenet or group_pos != "FFN":
-        raise NotImplementedError("gs-lora_amd covers the ViT-Face FFN-LoRA grouping (imagenet / Attention: next scope rows)")
+    if group_pos != "FFN":
+        raise NotImplementedError("gs-lora_amd covers the FFN-LoRA grouping (group_pos='Attention': next scope row)")
+    if imagenet:      # reference :91-107: always the 12 per-block groups of ViT-B/16, group_num / group_type ignored
+        group_type, group_num = "block", len(model.hip_spec().blocks)
     if type not in ("L2", "L1"):
         raise ValueError("type should be L1 or L2")
     bucket = model.lora_bucket()

@@ -1,9 +1,12 @@
 """Step helpers of the reference's util/utils.py that sit on the GS-LoRA path
 (AverageMeter :316-332, train_accuracy :354-368, count_trainable_parameters :423-425,
-reinitialize_lora_parameters :428-441, calculate_prototypes :502-549), backed by the HIP model.
-Data plumbing, verification and the ImageNet head surgery of that file are out of scope."""
+reinitialize_lora_parameters :428-441, calculate_prototypes :502-549, replace_ffn_with_lora :552-577,
+modify_head :580-621, resume_head :623-636), backed by the HIP model.
+Data plumbing and face verification of that file are out of scope."""
+import copy
 import datetime
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -79,3 +82,50 @@ def calculate_prototypes(backbone, dataset, batch_size=32, device="cuda", aug_nu
 
 def get_time():
     return (str(datetime.datetime.now())[:-10]).replace(" ", "-").replace(":", "-")
+
+
+# ---- ViT-B/16 ImageNet100 model surgery --------------------------------------------------------------------------
+HEAD_CACHE = "results/original_VIT_head/classifier.pth"     # same relative path as the reference (:593-597, :628)
+
+
+def replace_ffn_with_lora(model, rank=8):
+    """Swap the two nn.Linear of every `.mlp` for loralib.Linear(r=rank) (reference :552-577). As in the reference the new
+    layers are freshly initialised — the frozen FFN weights come from the checkpoint the driver loads afterwards
+    (train_own_forget_cl.py:250-262)."""
+    import loralib as lora
+    for _, module in list(model.named_modules()):
+        if hasattr(module, "mlp"):
+            ffn = module.mlp
+            for ffn_name, ffn_layer in list(ffn.named_children()):
+                if isinstance(ffn_layer, nn.Linear) and not isinstance(ffn_layer, lora.Linear):
+                    new = lora.Linear(ffn_layer.in_features, ffn_layer.out_features, r=rank)
+                    setattr(ffn, ffn_name, new.to(ffn_layer.weight.device))
+    return model
+
+
+def modify_head(model_ori, current_id_to_original_id, device):
+    """Deep-copied model whose classifier keeps only the rows of the listed original class ids, in dict order
+    (reference :580-621). The untouched 1000-way head is saved once to HEAD_CACHE for resume_head."""
+    model = copy.deepcopy(model_ori)
+    old = model.heads.head
+    old_w, old_b = old.weight.data, old.bias.data
+    if not os.path.exists(HEAD_CACHE):
+        os.makedirs(os.path.dirname(HEAD_CACHE), exist_ok=True)
+        torch.save(old.state_dict(), HEAD_CACHE)
+    ids = torch.tensor([int(i) for i in current_id_to_original_id.values()], dtype=torch.long, device=old_w.device)
+    new = nn.Linear(old.in_features, len(current_id_to_original_id))
+    new.weight.data = old_w.index_select(0, ids).clone()
+    new.bias.data = old_b.index_select(0, ids).clone()
+    model.heads.head = new
+    return model.to(device)
+
+
+def resume_head(model, device):
+    """Deep-copied model with the original 1000-way ImageNet head restored from HEAD_CACHE (reference :623-636)."""
+    model = copy.deepcopy(model)
+    sd = torch.load(HEAD_CACHE)
+    new = nn.Linear(sd["weight"].shape[1], sd["weight"].shape[0])
+    new.weight.data = sd["weight"].data
+    new.bias.data = sd["bias"].data
+    model.heads.head = new
+    return model.to(device)

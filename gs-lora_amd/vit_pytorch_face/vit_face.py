@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 import loralib as lora
-from gslora_hip.vit_runner import ViTRunner
+from gslora_hip.vit_runner import BlockSpec, ModelSpec, ViTRunner
 
 MIN_NUM_PATCHES = 16
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
@@ -120,7 +120,41 @@ class _ViTFaceFn(torch.autograd.Function):
         return (None, None, None) + (None,) * ctx.n
 
 
-class ViT_face(nn.Module):
+class HipModelMixin:
+    """Shared by the model families that run on ViTRunner (ViT_face, ModifiedViT): compute-dtype switch, the lazily built
+    runner / flat LoRA bucket, and the one-autograd-node call."""
+    _runner = None
+
+    def set_compute_dtype(self, name):
+        """'bf16' (speed: bf16 MFMA operands, f32 accumulate) or 'fp32' (parity: exact-f32 kernels)."""
+        self.compute_dtype = _DTYPES[name.lower()] if isinstance(name, str) else name
+        return self
+
+    def runner(self):
+        if self._runner is None:
+            self._runner = ViTRunner(self)
+        return self._runner
+
+    def lora_bucket(self):
+        """Flat f32 storage behind the LoRA parameters (created on first use on the GPU)."""
+        return self.runner().ensure_bucket()
+
+    def _hip_call(self, img, label):
+        runner = self.runner()
+        spec = self.hip_spec()
+        lora_params = [p for blk in spec.blocks for p in blk.lora_params()] if spec.lora_rank > 0 else []
+        grad_on = torch.is_grad_enabled()
+        if grad_on and any(p.requires_grad for n, p in self.named_parameters() if "lora_" not in n):
+            raise RuntimeError(f"gs-lora_amd {type(self).__name__} trains LoRA parameters only: call "
+                               "loralib.mark_only_lora_as_trainable(model) first (or run under torch.no_grad())")
+        if grad_on and any(p.requires_grad for p in lora_params):
+            out = _ViTFaceFn.apply(runner, img, label, *lora_params)
+            return out if isinstance(out, tuple) else (None, out)
+        logits, emb, _ = runner.forward(img, label, save=False)
+        return logits, emb
+
+
+class ViT_face(HipModelMixin, nn.Module):
     def __init__(self, *, loss_type, GPU_ID, num_class, image_size, patch_size, dim, depth, heads, mlp_dim, pool="cls",
                  channels=3, dim_head=64, dropout=0.0, emb_dropout=0.0, lora_rank=8, lora_pos: str = "FFN"):
         super().__init__()
@@ -170,35 +204,26 @@ class ViT_face(nn.Module):
         for _, ff in self.transformer.layers:
             yield ff.fn.fn
 
-    def set_compute_dtype(self, name):
-        """'bf16' (speed: bf16 MFMA operands, f32 accumulate) or 'fp32' (parity: exact-f32 kernels)."""
-        self.compute_dtype = _DTYPES[name.lower()] if isinstance(name, str) else name
-        return self
-
-    def runner(self):
-        if self._runner is None:
-            self._runner = ViTRunner(self)
-        return self._runner
-
-    def lora_bucket(self):
-        """Flat f32 storage behind the LoRA parameters (created on first use on the GPU)."""
-        return self.runner().ensure_bucket()
+    def hip_spec(self):
+        """What the kernels need to know about this family (see gslora_hip.vit_runner.ModelSpec)."""
+        blocks = []
+        for attn, ff in self.transformer.layers:
+            a, f = attn.fn, ff.fn
+            blocks.append(BlockSpec(a.norm, a.fn.to_qkv.weight, None, a.fn.to_out[0], f.norm, f.fn.net[0], f.fn.net[3]))
+        has_loss = self.loss_type == "CosFace"
+        return ModelSpec(patch_size=self.patch_size, num_tokens=self.num_tokens, dim=self.dim, heads=self.heads,
+                         attn_scale=self.attn_scale, ln_eps=1e-5, dropout_p=self.dropout_p, emb_dropout_p=self.emb_dropout_p,
+                         lora_rank=self.lora_rank, patch_w=self.patch_to_embedding.weight, patch_is_conv=False,
+                         patch_b=self.patch_to_embedding.bias, cls=self.cls_token, pos=self.pos_embedding, blocks=blocks,
+                         final_ln=self.mlp_head[0], head_kind="cosface", head_w=self.loss.weight if has_loss else None,
+                         head_b=None, cos_s=self.loss.s if has_loss else 64.0, cos_m=self.loss.m if has_loss else 0.35)
 
     # ---- reference API ---------------------------------------------------------------------------
     def forward(self, img, label=None, mask=None):
         """:return: (logits, emb) if label is given else emb — as the reference (:523-548)."""
         if mask is not None:
             raise NotImplementedError("attention masks are never passed by the GS-LoRA engines")
-        runner = self.runner()
-        lora_params = [p for blk in self.ffn_blocks() for p in blk.lora_params()] if self.lora_rank > 0 else []
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in lora_params)
-        if torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters() if "lora_" not in n):
-            raise RuntimeError("gs-lora_amd ViT_face trains LoRA parameters only: call "
-                               "loralib.mark_only_lora_as_trainable(model) first (or run under torch.no_grad())")
-        if needs_grad:
-            out = _ViTFaceFn.apply(runner, img, label, *lora_params)
-            return out
-        logits, emb, _ = runner.forward(img, label, save=False)
+        logits, emb = self._hip_call(img, label)
         return emb if label is None else (logits, emb)
 
 
@@ -213,4 +238,3 @@ def _not_in_scope(name, why):
 ViT_face_low = _not_in_scope("ViT_face_low", "LIRF baseline half-network, reference vit_face.py:551-781")
 ViT_face_up = _not_in_scope("ViT_face_up", "LIRF baseline half-network, reference vit_face.py:551-781")
 ViTs_face = _not_in_scope("ViTs_face", "overlapping-patch variant, not used by any GS-LoRA config")
-ModifiedViT = _not_in_scope("ModifiedViT", "ViT-B/16 ImageNet100 adapter — next row of the scope table")

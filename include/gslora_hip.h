@@ -109,17 +109,20 @@ long gsl_lora_grad_ws_elems(int M, int N, int r);
 int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj,
                   int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
 
-/* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35). */
+/* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35).
+ * linear_head != 0 selects the ViT-B/16 path instead (modified_VIT.py:32-38): logits = emb * W^T + head_bias, with Wn = W
+ * un-normalised and cos_s = 1 on the backward side. */
 int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s);   /* Wn = F.normalize(W) */
 int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps,
                  const float* Wn, const int64_t* label, float* emb, float* mean, float* rstd,
-                 float* logits, int B, int D, int C, float cos_s, float cos_m, gsl_stream_t s);
+                 float* logits, int B, int D, int C, float cos_s, float cos_m,
+                 const float* head_bias, int linear_head, gsl_stream_t s);
 /* dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: cls rows get the gradient, others zero.
  * dxb[dtype] = dx * dropmask(site) (nullable). */
 int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
                  float* dx, void* dxb, int B, int D, int C, float cos_s, int dtype,
-                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+                 float p_drop, uint64_t seed, uint32_t site, int linear_head, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
  * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */

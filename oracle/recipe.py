@@ -143,3 +143,79 @@ def make_labels(cfg, batch, seed=7, tag="lab", lo=0, hi=None):
 def make_prototypes(cfg, seed=11):
     """[num_class, dim] table standing in for calculate_prototypes output."""
     return normalish("prototypes", (cfg["num_class"], cfg["dim"]), seed, 1.0)
+
+
+# ---------------------------------------------------------------------------
+# ViT-B/16 family (torchvision VisionTransformer naming; reference vit_pytorch_face/modified_VIT.py)
+# ---------------------------------------------------------------------------
+def cfg_vitb(lora_rank=16, num_class=1000):
+    """torchvision vit_b_16: 224 px, patch 16, 12 layers x 12 heads x 64, mlp 3072 (train_own_forget_cl.py:238-241)."""
+    return dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, num_class=num_class,
+                lora_rank=lora_rank, channels=3)
+
+
+def cfg_vitb_small(lora_rank=4, num_class=20):
+    """12 layers (the reference hard-codes 12 groups, engine_cl.py:395-403) but 64 px / dim 64 / 1 head: 17 tokens."""
+    return dict(image_size=64, patch_size=16, dim=64, depth=12, heads=1, mlp_dim=128, num_class=num_class,
+                lora_rank=lora_rank, channels=3)
+
+
+def cfg_vitb_small2(lora_rank=16, num_class=16):
+    """2 heads, rank 16 (the ImageNet100 rank), 3 layers, 96 px -> 37 tokens."""
+    return dict(image_size=96, patch_size=16, dim=128, depth=3, heads=2, mlp_dim=256, num_class=num_class,
+                lora_rank=lora_rank, channels=3)
+
+
+def tv_param_shapes(cfg):
+    """Ordered {name: shape} of ModifiedViT(vit) after replace_ffn_with_lora (named_parameters() order)."""
+    d, mlp, r, p = cfg["dim"], cfg["mlp_dim"], cfg["lora_rank"], cfg["patch_size"]
+    ntok = (cfg["image_size"] // p) ** 2 + 1
+    sh = {"class_token": (1, 1, d), "conv_proj.weight": (d, cfg["channels"], p, p), "conv_proj.bias": (d,),
+          "encoder.pos_embedding": (1, ntok, d)}
+    for i in range(cfg["depth"]):
+        e = f"encoder.layers.encoder_layer_{i}"
+        sh[f"{e}.ln_1.weight"] = (d,)
+        sh[f"{e}.ln_1.bias"] = (d,)
+        sh[f"{e}.self_attention.in_proj_weight"] = (3 * d, d)
+        sh[f"{e}.self_attention.in_proj_bias"] = (3 * d,)
+        sh[f"{e}.self_attention.out_proj.weight"] = (d, d)
+        sh[f"{e}.self_attention.out_proj.bias"] = (d,)
+        sh[f"{e}.ln_2.weight"] = (d,)
+        sh[f"{e}.ln_2.bias"] = (d,)
+        for j, (o, k) in ((0, (mlp, d)), (3, (d, mlp))):
+            sh[f"{e}.mlp.{j}.weight"] = (o, k)
+            sh[f"{e}.mlp.{j}.bias"] = (o,)
+            if r > 0:
+                sh[f"{e}.mlp.{j}.lora_A"] = (r, k)
+                sh[f"{e}.mlp.{j}.lora_B"] = (o, r)
+    sh["encoder.ln.weight"] = (d,)
+    sh["encoder.ln.bias"] = (d,)
+    sh["heads.head.weight"] = (cfg["num_class"], d)
+    sh["heads.head.bias"] = (cfg["num_class"],)
+    return sh
+
+
+def make_tv_state(cfg, seed=4242, lora_b_std=0.02):
+    out = {}
+    for name, shape in tv_param_shapes(cfg).items():
+        if name.endswith(("ln_1.weight", "ln_2.weight", "ln.weight")):
+            v = 1.0 + uniform(name, shape, seed, -0.2, 0.2)
+        elif name.endswith(("ln_1.bias", "ln_2.bias", "ln.bias")):
+            v = uniform(name, shape, seed, -0.1, 0.1)
+        elif name in ("encoder.pos_embedding", "class_token"):
+            v = normalish(name, shape, seed, 0.5)
+        elif name.endswith("lora_A"):
+            bound = float(np.sqrt(6.0 / ((1 + 5.0) * shape[1])))
+            v = uniform(name, shape, seed, -bound, bound)
+        elif name.endswith("lora_B"):
+            v = normalish(name, shape, seed, lora_b_std)
+        elif name.endswith("bias"):
+            v = uniform(name, shape, seed, -0.05, 0.05)
+        elif name == "heads.head.weight":
+            v = uniform(name, shape, seed, -0.3, 0.3)      # logits O(1..5): CE and top-1 are non-trivial
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            bound = 1.0 / float(np.sqrt(fan_in))
+            v = uniform(name, shape, seed, -bound, bound)
+        out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return out

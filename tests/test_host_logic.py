@@ -223,3 +223,39 @@ def test_prototype_table_from_dict():
     t = prototype_table(d, "cpu")
     assert t.shape == (4, 8) and (t[3] == 1).all() and (t[1] == 0).all() and torch.equal(t[0], torch.arange(8.0))
     assert prototype_table(d, "cpu") is t            # cached per dict object
+
+
+# ---- ViT-B/16 adapter: module tree, surgery helpers, loud failure on CPU -----------------------------------------------
+def test_modified_vit_tree_names_and_surgery(tmp_path, monkeypatch):
+    import loralib as lora
+    from oracle import recipe
+    from util import utils as U
+    from vit_pytorch_face import ModifiedViT
+    from vit_pytorch_face.modified_VIT import vit_b_16
+    cfg = recipe.cfg_vitb_small()
+    vit = vit_b_16(image_size=cfg["image_size"], patch_size=cfg["patch_size"], num_layers=cfg["depth"], num_heads=cfg["heads"],
+                   hidden_dim=cfg["dim"], mlp_dim=cfg["mlp_dim"], num_classes=cfg["num_class"])
+    m = U.replace_ffn_with_lora(ModifiedViT(vit), rank=cfg["lora_rank"])
+    assert [n for n, _ in m.named_parameters()] == list(recipe.tv_param_shapes(cfg))
+    assert {n: tuple(p.shape) for n, p in m.named_parameters()} == recipe.tv_param_shapes(cfg)
+    m.load_state_dict({k: torch.tensor(v) for k, v in recipe.make_tv_state(cfg).items()}, strict=True)
+    monkeypatch.chdir(tmp_path)
+    cmap = {0: 5, 1: 2, 2: 19}
+    m2 = U.modify_head(m, current_id_to_original_id=cmap, device="cpu")
+    assert m2 is not m and m2.heads.head.weight.shape == (3, cfg["dim"])
+    assert torch.equal(m2.heads.head.weight, m.heads.head.weight[[5, 2, 19]]) and torch.equal(m2.heads.head.bias, m.heads.head.bias[[5, 2, 19]])
+    assert (tmp_path / "results/original_VIT_head/classifier.pth").exists()
+    m3 = U.resume_head(m2, device="cpu")
+    assert torch.equal(m3.heads.head.weight, m.heads.head.weight) and torch.equal(m3.heads.head.bias, m.heads.head.bias)
+    lora.mark_only_lora_as_trainable(m2)
+    assert U.count_trainable_parameters(m2) == sum(p.numel() for n, p in m2.named_parameters() if "lora_" in n)
+    sp = m2.hip_spec()
+    assert (sp.num_tokens, sp.dim, sp.heads, sp.lora_rank, len(sp.blocks), sp.head_kind) == (17, 64, 1, 4, 12, "linear")
+    assert abs(sp.ln_eps - 1e-6) < 1e-12 and abs(sp.attn_scale - 0.125) < 1e-12
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m2(torch.zeros(1, 3, 64, 64), None)
+
+
+def test_vit_b16_parameter_count():
+    from vit_pytorch_face.modified_VIT import vit_b_16
+    assert sum(p.numel() for p in vit_b_16().parameters()) == 86_567_656      # torchvision's published vit_b_16 size
