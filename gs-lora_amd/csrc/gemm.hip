@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "gsl_common.h"
+#include <type_traits>
 
 using namespace gsl;
 
@@ -462,13 +463,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
     }
 }
 
-// ------------------------------------------------------------------ 256x256 kernel with the LoRA rank-r term computed IN the kernel
-//   out = epilogue( A·Wᵀ + t·Qᵀ ),  t = s·(A·Pᵀ)  [M, r],   P [16, K] (rows >= r zero), Q [N, 32] (cols >= r zero)
-// A workgroup streams the whole K range of its 256 rows anyway, so the down-projection t = s·A·Pᵀ costs 16 extra output
-// columns (2 extra MFMAs per 32 per wave and k-step, P rides along in the W stage) instead of a separate launch that re-reads
-// the [M, K] activation from HBM (413-826 MB per call). After the K loop t goes through LDS (C layout -> operand layout),
-// one more MFMA k-step applies the rank-r update, and the N-tile-0 workgroups store t (bf16, zero padded to 64 columns) for
-// the LoRA-gradient reductions. Replaces loralib.Linear's (x @ Aᵀ @ Bᵀ)·scaling (vit_face.py:330,333) and its autograd.
 struct LoraInk {
   const bf16_t* P; int ldp;
   const bf16_t* Q; int ldq;
@@ -476,6 +470,242 @@ struct LoraInk {
   bf16_t* tout; int ldt;
 };
 constexpr int ST4L = (BM4 + BN4 + 16) * BK;
+
+// ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 8-phase ping-pong schedule
+// Same tile, wave grid (2 x 4, 128x64 per wave) and epilogue as gemm_bf16_t256_kernel; the K loop is re-scheduled:
+//  * a K tile (BK = 64) is computed in 4 phases = the 4 quadrants (64 rows x 32 cols x K 64 = 16 MFMAs) of the wave's 128x64 tile;
+//  * the LDS stage of a K tile is 4 half-tiles of 16 KB: B-h0 / B-h1 hold the ch = 0 / 1 column halves of all 4 wave columns,
+//    A-h0 / A-h1 the rh = 0 / 1 row halves of both wave rows, so that a half-tile is read in exactly one phase
+//    (q0: B-h0 + A-h0, q1: B-h1, q2: A-h1, q3: nothing) and can be re-staged for K tile t+2 right after: one LDS-DMA half-tile is
+//    issued per phase, the stream runs 7 half-tiles ahead, and the counted wait (vmcnt(6), once per K tile, in q3) leaves three
+//    half-tiles in flight;
+//  * the two wave rows run staggered by one barrier (wm == 1 takes one extra s_barrier up front): while one group issues its
+//    16 MFMAs at raised priority the other one issues ds_reads and the LDS-DMA — the matrix pipe and the LDS/TA pipes overlap.
+// Hazards (stagger included): a half-tile staged in phase p is read in phase >= p+4; the wait that retires it sits before the
+// first barrier of the phase before the read; a half-tile is re-staged >= 2 phases after its last ds_read, or 1 phase after for
+// B-h0 whose reads are retired (lgkmcnt(8)) before the first barrier of q0.
+// LORA = true: the in-kernel LoRA form of gemm_bf16_t256_lora_kernel (below) on this schedule — the 16 rows of P ride along
+// with piece B-h0 (one extra DMA for waves 0 and 1, so their counted wait is vmcnt(7)), the P fragment is read in q0 next to B-h0,
+// and a wave issues its 4 extra MFMAs (2 of its row-half's 8 row fragments x 2 k-steps) in q0 (wn < 2) or q2 (wn >= 2).
+template <int EPI, bool LORA>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                           const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                           const bf16_t* __restrict__ A2, int lda2,
+                                                           const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
+  constexpr int STG = LORA ? ST4L : ST4;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8];   // stages, then C staging
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = (e.N + BN4 - 1) / BN4;
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+  constexpr int HT = 128 * BK;     // half-tile, bf16 elements
+
+  // per-lane source rows of the two DMA instructions a lane contributes to an A / B half-tile (half added at issue time)
+  int arow[2], brow[2], csw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + lrow;
+    arow[i] = m0 + (r >> 6) * 128 + (r & 63);
+    brow[i] = n0 + (r >> 5) * 64 + (r & 31);
+    csw[i] = (lc ^ (r & 7)) * 8;
+  }
+  // PIECE: 0 = B-h0, 1 = A-h0, 2 = B-h1, 3 = A-h1 (stream order within a K tile)
+  auto stage = [&](int kt, auto piece_c) {
+    constexpr int PIECE = decltype(piece_c)::value;
+    if (kt >= nk) return;
+    constexpr bool isA = PIECE & 1;
+    constexpr int half = PIECE >> 1;
+    bf16_t* dst = smem + (kt & 1) * STG + (isA ? 0 : BM4 * BK) + half * HT;
+    const bf16_t* base; int ld, k0;
+    if (kt < nk1) { base = isA ? A1 : W1; ld = isA ? lda1 : ldw1; k0 = kt * BK; }
+    else { base = isA ? A2 : W2; ld = isA ? lda2 : ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, 0);
+    }
+    if constexpr (LORA && PIECE == 0) {
+      if (wave < 2) {
+        const int row = wave * 8 + lrow, c = lc ^ (row & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(lk.P + (size_t)row * lk.ldp + k0 + c * 8),
+                                         (lptr_t)(smem + (kt & 1) * STG + (BM4 + BN4) * BK + wave * 8 * BK), 16, 0, 0);
+      }
+    }
+  };
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+  // fragment read offsets inside a half-tile (bf16 elements): A rows wm*64 + i*16 + fr, B rows wn*32 + j*16 + fr; chunk (ks*4+fc)^(row&7)
+  int aoff[4][2], boff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + fr; aoff[i][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int row = wn * 32 + j * 16 + fr; boff[j][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
+  }
+
+  // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
+  stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
+  stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
+  if (nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
+
+  bf16x8_t af[4][2], bf0[2][2], bf1[2][2], pf[2];
+  f32x4_t accp[2];
+  accp[0] = accp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int poff0 = fr * BK + (((0 * 4 + fc) ^ (fr & 7)) << 3), poff1 = fr * BK + (((1 * 4 + fc) ^ (fr & 7)) << 3);
+  const int pi = (wn & 1) * 2;      // this wave's two row fragments (within its row half wn >> 1) of the 16 extra columns
+#define GSL_P8_MFMA(RH, CH, BF, PQ)                                                                          \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  if constexpr (LORA && (PQ)) {                                                                             \
+    if ((wn >> 1) == (RH)) {                                                                                \
+      if (pi) {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
+          accp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[2][ks], accp[0], 0, 0, 0);           \
+          accp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[3][ks], accp[1], 0, 0, 0);           \
+        }                                                                                                   \
+      } else {                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
+          accp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[0][ks], accp[0], 0, 0, 0);           \
+          accp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[1][ks], accp[1], 0, 0, 0);           \
+        }                                                                                                   \
+      }                                                                                                     \
+    }                                                                                                       \
+  }                                                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+        acc[(RH) * 4 + i][(CH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16_t* As0 = smem + (kt & 1) * STG;
+    const bf16_t* As1 = As0 + HT;
+    const bf16_t* Bs0 = As0 + BM4 * BK;
+    const bf16_t* Bs1 = Bs0 + HT;
+    // ---- q0: quadrant (rh0, ch0); reads B-h0 (first, retired before the barrier) and A-h0; stages A-h1(kt+1)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf0[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs0 + boff[j][ks]);
+    if constexpr (LORA) {
+      pf[0] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff0);
+      pf[1] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 1, P3{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    GSL_P8_MFMA(0, 0, bf0, true)
+    // ---- q1: (rh0, ch1); reads B-h1; stages B-h0(kt+2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 2, P0{});
+    GSL_P8_MFMA(0, 1, bf1, false)
+    // ---- q2: (rh1, ch1); reads A-h1; stages A-h0(kt+2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 2, P1{});
+    GSL_P8_MFMA(1, 1, bf1, true)
+    // ---- q3: (rh1, ch0); no reads; stages B-h1(kt+2); the once-per-K-tile counted wait: K tile kt+1 has landed
+    stage(kt + 2, P2{});
+    if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    GSL_P8_MFMA(1, 0, bf0, false)
+  }
+#undef GSL_P8_MFMA
+  if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
+  if constexpr (LORA) {
+    // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
+    __builtin_amdgcn_s_barrier();                      // stages are free
+    bf16_t* tbuf = smem;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16_t* d = tbuf + (wm * 128 + (2 * wn + t) * 16 + fr) * 32 + fc * 4;
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
+      *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (n0 == 0 && lk.tout) {                          // one N-tile stores t for the gradient reductions: [M, 64], zero padded
+      const int row = tid >> 1, half = tid & 1;
+      if (m0 + row < e.M) {
+        bf16_t* dst = lk.tout + (size_t)(m0 + row) * lk.ldt + half * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint4 v = half ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(tbuf + row * 32 + c * 8);
+          *reinterpret_cast<uint4*>(dst + c * 8) = v;
+        }
+      }
+    }
+    bf16x8_t qf[4];                                    // rank-r update: one more k-step (k = 32: r live columns)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+    }
+  }
+  if constexpr (!epi_out_is_f32<EPI>()) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
+      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------ 256x256 kernel with the LoRA rank-r term computed IN the kernel
+//   out = epilogue( A·Wᵀ + t·Qᵀ ),  t = s·(A·Pᵀ)  [M, r],   P [16, K] (rows >= r zero), Q [N, 32] (cols >= r zero)
+// A workgroup streams the whole K range of its 256 rows anyway, so the down-projection t = s·A·Pᵀ costs 16 extra output
+// columns (2 extra MFMAs per 32 per wave and k-step, P rides along in the W stage) instead of a separate launch that re-reads
+// the [M, K] activation from HBM (413-826 MB per call). After the K loop t goes through LDS (C layout -> operand layout),
+// one more MFMA k-step applies the rank-r update, and the N-tile-0 workgroups store t (bf16, zero padded to 64 columns) for
+// the LoRA-gradient reductions. Replaces loralib.Linear's (x @ Aᵀ @ Bᵀ)·scaling (vit_face.py:330,333) and its autograd.
+
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_t256_lora_kernel(const bf16_t* __restrict__ A1, int lda1,
@@ -744,11 +974,11 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
-    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage,
+    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage, 8 = 256x256 8-phase ping-pong,
     // 9 = 256x128x32 ring with two workgroups per CU. Defaults measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md):
     // the VALU-heavy BIAS_GELU epilogue wants the two-workgroup tile, N >= 512 the 256x256 tile, skinny N the ring.
     const char* ev = getenv("GSL_GEMM_VARIANT");
-    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (EPI == GSL_EPI_BIAS_GELU ? 9 : (e.N >= 512 ? 4 : 3)));
+    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (EPI == GSL_EPI_BIAS_GELU ? 9 : (e.N >= 512 ? 8 : 3)));
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
     if (variant == 9) {
@@ -756,6 +986,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }
       hipLaunchKernelGGL(gemm_bf16_k32x2_kernel<EPI>, dim3(((e.M + 255) / 256) * ((e.N + 127) / 128)), dim3(512), 0, st, (const bf16_t*)A1, lda1,
                          (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e9);
+    } else if (variant == 8) {
+      hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
     } else if (variant == 4) {
       GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
     } else if (variant == 3) {
@@ -843,8 +1076,15 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
   hipStream_t st = as_stream(s);
-#define GSL_LL(EPIV) hipLaunchKernelGGL(gemm_bf16_t256_lora_kernel<EPIV>, dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, \
-                                        (const bf16_t*)W, ldw, K, lk, e)
+  const char* ev = getenv("GSL_GEMM_VARIANT");      // development knob: 4 = single-phase 256x256 kernel, default = 8-phase schedule
+  const bool old_sched = ev && atoi(ev) == 4;
+#define GSL_LL(EPIV)                                                                                                              \
+  do {                                                                                                                            \
+    if (old_sched) hipLaunchKernelGGL(gemm_bf16_t256_lora_kernel<EPIV>, dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda,         \
+                                      (const bf16_t*)W, ldw, K, lk, e);                                                            \
+    else hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPIV, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W, \
+                            ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);                                \
+  } while (0)
   switch (epilogue) {
     case GSL_EPI_STORE: GSL_LL(GSL_EPI_STORE); break;
     case GSL_EPI_BIAS_RES_F32: GSL_CHECK_ARG(bias && res, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_F32); break;
