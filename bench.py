@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (the engines' default for launch-bound batches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,8 +113,11 @@ def main():
     y_f = torch.tensor(order[80:])[torch.randint(0, 20, (B,), generator=g)].to(dev)
     proto = torch.randn(100, FULL["dim"], generator=g).to(dev)
 
+    from gslora_hip.step import GraphedStep
+    stepper = GraphedStep(model, opt, crit) if (args.graph and world == 1) else (lambda *a, **k: gs_lora_step(model, opt, crit, *a, **k))
+
     def step():
-        return gs_lora_step(model, opt, crit, x_r, y_r, x_f, y_f, beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"],
+        return stepper(x_r, y_r, x_f, y_f, beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"],
                             use_structure=True, group_type="block", use_prototype=True, proto_table=proto, w_f=HYPER["pro_f"],
                             w_r=HYPER["pro_r"], BND_pro=HYPER["BND_pro"])
 
@@ -169,6 +173,7 @@ def main():
                          "algorithmic_bytes": int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)},
             "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
+            "hip_graph": bool(args.graph and world == 1),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

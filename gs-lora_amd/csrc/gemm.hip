@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                              const bf16_t* __restrict__ A2, int lda2,
                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[NBUF][2][BM * BK];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
                                                               const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[3 * ST3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                              const bf16_t* __restrict__ A2, int lda2,
                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4 > CST_BLOCK8) ? 2 * ST4 : CST_BLOCK8];   // stages, then C staging
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                            const bf16_t* __restrict__ A2, int lda2,
                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
+  resolve_drop(e.drop);
   constexpr int STG = LORA ? ST4L : ST4;
   __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8];   // stages, then C staging
   const int tid = threadIdx.x, lane = tid & 63;
@@ -711,6 +715,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_t256_lora_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                                   const bf16_t* __restrict__ W1, int ldw1, int K1, LoraInk lk,
                                                                   EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4L > CST_BLOCK8) ? 2 * ST4L : CST_BLOCK8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -841,6 +846,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                                  const bf16_t* __restrict__ A2, int lda2,
                                                                  const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[SM9];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -931,6 +937,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ W1, int ldw1, int K1,
                                                        const float* __restrict__ A2, int lda2,
                                                        const float* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) float As[16][68];
   __shared__ __attribute__((aligned(16))) float Ws[16][68];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;

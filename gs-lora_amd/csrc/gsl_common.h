@@ -105,17 +105,30 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 // with round(p*2^16). The same function regenerates the mask in backward — no mask tensor is stored.
 struct DropCfg {
   uint32_t thr;   // drop if 16-bit sample < thr ; thr = 0 disables (thr = round(p * 65536))
-  uint32_t key;   // seed/site mix
+  uint32_t key;   // seed/site mix (host-computed when the seed is passed by value)
   float scale;    // 1/(1-p)
+  uint32_t site;
+  const uint64_t* seed_ptr;   // != nullptr: the seed lives in device memory (HIP-graph replays advance it), key is derived in-kernel
 };
+#define GSL_SEED_ON_DEVICE 0x80000000u   // flag bit of every `site` argument of the C ABI: `seed` is then a device pointer to a uint64
+__host__ __device__ inline uint32_t drop_mix(uint64_t seed, uint32_t site) {
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  z ^= z >> 29; z *= 0xD6E8FEB86659FD93ull; z ^= z >> 32;
+  return (uint32_t)z;
+}
 inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
   DropCfg d;
   d.thr = (p > 0.f) ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
-  uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
-  z ^= z >> 29; z *= 0xD6E8FEB86659FD93ull; z ^= z >> 32;
-  d.key = (uint32_t)z;
+  d.site = site & ~GSL_SEED_ON_DEVICE;
+  d.seed_ptr = (site & GSL_SEED_ON_DEVICE) ? reinterpret_cast<const uint64_t*>(seed) : nullptr;
+  d.key = d.seed_ptr ? 0u : drop_mix(seed, d.site);
   d.scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
   return d;
+}
+// first statement of every kernel that applies dropout: one uniform 8-byte load when the seed is device resident
+__device__ __forceinline__ void resolve_drop(DropCfg& d) {
+  if (d.seed_ptr && d.thr) { d.key = drop_mix(*d.seed_ptr, d.site); }
+  d.seed_ptr = nullptr;
 }
 // one 32-bit hash serves the element pair (2k, 2k+1): low / high 16 bits. Two multiply rounds on the 32-bit pair
 // counter (the high counter word only perturbs the key): 6 integer ops per pair — the epilogue that uses it is VALU-bound

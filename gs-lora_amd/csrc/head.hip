@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ emb, const float* __restrict__ Wn,
                                                        float* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
                                                        DropCfg drop, int linear) {
+  resolve_drop(drop);
   __shared__ float de[HEAD_MAXD];   // d emb
   __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
   __shared__ float sm[16];

@@ -340,6 +340,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// HIP-graph form: the step count and the learning rate live in device memory (a captured graph replays with fresh values)
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1,
+                                                        float b2, float eps, float wd, const int64_t* __restrict__ step_dev) {
+  const double t = (double)*step_dev;
+  const float lr = *lr_dev;
+  const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+extern "C" int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1,
+                                  float beta2, float eps, float wd, const int64_t* step_dev, gsl_stream_t s) {
+  GSL_CHECK_ARG(p && g && m && v && n > 0 && lr_dev && step_dev, "null/size");
+  const int grid = (int)min((n + 255) / 256, (long)(256 * 8));
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid), dim3(256), 0, as_stream(s), p, g, m, v, n, lr_dev, beta1, beta2, eps, wd, step_dev);
+  return check_launch("gsl_adamw_flat_dev");
+}
+
 extern "C" int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                               float eps, float wd, int step, gsl_stream_t s) {
   GSL_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "null/size/step");
@@ -411,7 +437,29 @@ extern "C" int gsl_pack_pad(const float* in, long si, long sj, int rows, int col
   return check_launch("gsl_pack_pad");
 }
 
+// all LoRA operand packs of a step in ONE launch: blockIdx.y selects the descriptor (device-resident table built once by the host)
+template <typename T>
+__global__ void pack_pad_batch_kernel(const gsl_pack_desc* __restrict__ descs) {
+  const gsl_pack_desc d = descs[blockIdx.y];
+  const long tot = (long)d.rows_out * d.ld_out;
+  T* out = reinterpret_cast<T*>(d.out);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / d.ld_out), j = (int)(idx % d.ld_out);
+    const float v = (i < d.rows && j < d.cols) ? d.scale * d.in[(size_t)i * d.si + (size_t)j * d.sj] : 0.f;
+    Elem<T>::st(out + idx, v);
+  }
+}
+extern "C" int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long max_elems, int dtype, gsl_stream_t s) {
+  GSL_CHECK_ARG(descs_dev && n > 0 && max_elems > 0, "null/size");
+  const dim3 grid((unsigned)min((max_elems + 255) / 256, (long)64), (unsigned)n);
+  if (dtype == GSL_BF16) hipLaunchKernelGGL(pack_pad_batch_kernel<bf16_t>, grid, dim3(256), 0, as_stream(s), descs_dev);
+  else if (dtype == GSL_F32) hipLaunchKernelGGL(pack_pad_batch_kernel<float>, grid, dim3(256), 0, as_stream(s), descs_dev);
+  else return fail(GSL_ERR_ARG, "gsl_pack_pad_batch: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_pack_pad_batch");
+}
+
 __global__ void dropout_mask_kernel(uint8_t* keep, long n, DropCfg d) {
+  resolve_drop(d);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     keep[i] = drop_mul(d, (uint64_t)i) != 0.f ? 1 : 0;
 }

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, const float* dres,
                                                      float* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
                                                      long drop_row_stride) {
+  resolve_drop(drop);
   constexpr int D = NPL * 64;
   using IO = RowIO<NPL>;
   const int lane = threadIdx.x & 63;

@@ -11,7 +11,7 @@ import util.utils as util
 from engine_cl import DISP_FREQ, VER_FREQ, _log, _unwrap, eval_data  # noqa: F401
 from engine_cl import evaluate as _evaluate_cl
 from gslora_hip import losses as _losses
-from gslora_hip.step import MeterQueue, gs_lora_step
+from gslora_hip.step import MeterQueue, gs_lora_step, pick_stepper  # noqa: F401
 from util.data_prefetcher import data_prefetcher
 
 PROTO_BND = 18   # hard-coded in the reference (engine.py:105)
@@ -44,10 +44,10 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
     for xo, yo in iter(outer):
         xo, yo = xo.to(device), yo.to(device)
         (x_f, y_f, x_r, y_r) = (xo, yo, xi, yi) if swap else (xi, yi, xo, yo)
-        pack = gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, beta=beta, alpha=alpha, BND=BND,
-                            use_structure=use_structure, group_type=group_type, use_prototype=use_prototype,
-                            proto_table=proto_table, w_f=prototype_weight_forget, w_r=prototype_weight_remain,
-                            BND_pro=PROTO_BND)
+        stepper = pick_stepper(model, optimizer, criterion, cfg, x_r.size(0) + x_f.size(0))    # HIP graph for launch-bound batches
+        pack = stepper(x_r, y_r, x_f, y_f, beta=beta, alpha=alpha, BND=BND, use_structure=use_structure, group_type=group_type,
+                       use_prototype=use_prototype, proto_table=proto_table, w_f=prototype_weight_forget,
+                       w_r=prototype_weight_remain, BND_pro=PROTO_BND)
         queue.push(pack, x_r.size(0), x_f.size(0))
         if ((batch + 1) % DISP_FREQ == 0) and batch != 0:
             queue.flush(meters)

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 import util.utils as util
 from gslora_hip import losses as _losses
-from gslora_hip.step import MeterQueue, gs_lora_step
+from gslora_hip.step import MeterQueue, gs_lora_step, pick_stepper  # noqa: F401
 from util.data_prefetcher import data_prefetcher
 from util.utils import get_time, train_accuracy  # noqa: F401  (re-exported like the reference)
 
@@ -57,9 +57,11 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
     x_f, y_f = forget_iter.next()
     for x_r, y_r in iter(dataloader_remain):
         x_r, y_r = x_r.to(device), y_r.to(device)
-        pack = gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, beta=beta, alpha=alpha, BND=BND,
-                            use_structure=True, group_type="block", use_prototype=use_prototype, proto_table=proto_table,
-                            w_f=prototype_weight_forget, w_r=prototype_weight_remain, BND_pro=cfg.get("BND_pro", 0.0))
+        # small batches are launch-bound: the step is captured once as a HIP graph and replayed (cfg["HIP_GRAPH"], default "auto")
+        stepper = pick_stepper(model, optimizer, criterion, cfg, x_r.size(0) + x_f.size(0))
+        pack = stepper(x_r, y_r, x_f, y_f, beta=beta, alpha=alpha, BND=BND, use_structure=True, group_type="block",
+                       use_prototype=use_prototype, proto_table=proto_table, w_f=prototype_weight_forget,
+                       w_r=prototype_weight_remain, BND_pro=cfg.get("BND_pro", 0.0))
         queue.push(pack, x_r.size(0), x_f.size(0))
 
         if ((batch + 1) % DISP_FREQ == 0) and batch != 0:

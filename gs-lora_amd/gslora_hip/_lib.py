@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgslora_hip.so")
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32 = 0, 1, 2, 3, 4, 5
 NORM_SPLIT = 8
+SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 
 _vp, _i, _l, _f, _u64, _u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32
 
@@ -42,9 +43,11 @@ SIGNATURES = {
     "gsl_group_norms_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gsl_group_norms_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp],
     "gsl_adamw_flat": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp],
+    "gsl_adamw_flat_dev": [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp],
     "gsl_cast": [_vp, _vp, _l, _i, _vp],
     "gsl_transpose_cast": [_vp, _vp, _i, _i, _i, _vp],
     "gsl_pack_pad": [_vp, _l, _l, _i, _i, _f, _vp, _i, _i, _i, _vp],
+    "gsl_pack_pad_batch": [_vp, _i, _l, _i, _vp],
     "gsl_dropout_mask": [_vp, _l, _f, _u64, _u32, _vp],
 }
 _RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long}

@@ -253,6 +253,13 @@ def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step):
                                     float(wd), int(step), _stream()), "gsl_adamw_flat")
 
 
+def adamw_flat_dev(p, g, m, v, lr_dev, b1, b2, eps, wd, step_dev):
+    """Same update with the step count (int64) and learning rate (f32) read from device memory (HIP-graph replays)."""
+    _need(p, g, m, v, lr_dev, step_dev)
+    L.check(L.load().gsl_adamw_flat_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), float(b1), float(b2), float(eps), float(wd),
+                                        _p(step_dev), _stream()), "gsl_adamw_flat_dev")
+
+
 def cast(x, dtype):
     _need(x)
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
@@ -274,6 +281,30 @@ def pack_pad(src, si, sj, rows, cols, rows_out, ld_out, dtype, scale=1.0):
     L.check(L.load().gsl_pack_pad(_p(src), si, sj, rows, cols, float(scale), _p(out), rows_out, ld_out, code(dtype), _stream()),
             "gsl_pack_pad")
     return out
+
+
+PACK_DESC = None
+
+
+def pack_desc_table(entries, device):
+    """entries: list of (src f32 tensor, si, sj, rows, cols, scale, out tensor). -> (uint8 device tensor holding gsl_pack_desc[n], max_elems)"""
+    import numpy as np
+    global PACK_DESC
+    if PACK_DESC is None:   # mirrors struct gsl_pack_desc (include/gslora_hip.h), 56 bytes
+        PACK_DESC = np.dtype([("in", "<u8"), ("si", "<i8"), ("sj", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("scale", "<f4"),
+                              ("pad_", "<i4"), ("out", "<u8"), ("rows_out", "<i4"), ("ld_out", "<i4")], align=False)
+        assert PACK_DESC.itemsize == 56
+    arr = np.zeros(len(entries), dtype=PACK_DESC)
+    mx = 0
+    for k, (src, si, sj, rows, cols, scale, out) in enumerate(entries):
+        arr[k] = (src.data_ptr(), si, sj, rows, cols, scale, 0, out.data_ptr(), out.shape[0], out.shape[1])
+        mx = max(mx, out.numel())
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), mx
+
+
+def pack_pad_batch(table, n, max_elems, dtype):
+    _need(table)
+    L.check(L.load().gsl_pack_pad_batch(_p(table), int(n), int(max_elems), code(dtype), _stream()), "gsl_pack_pad_batch")
 
 
 def dropout_mask(n, p_drop, seed, site, device):

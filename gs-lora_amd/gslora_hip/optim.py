@@ -19,6 +19,38 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = {}
+        self.graph_mode = False     # set by gslora_hip.step.GraphedStep: step count / lr are read from device memory
+
+    # ---- HIP-graph support: a captured step() must not bake the step count (bias corrections) or the lr into the graph
+    def graph_sync(self):
+        """Bring the device-resident (step, lr) of every flat group in line with the host values (cheap fills, outside the graph)."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._flat.get(gi)
+            if ent is None or not ent.get("ok"):
+                continue
+            if "step_dev" not in ent:
+                dev = ent["p"].device
+                ent["step_dev"] = torch.zeros(1, device=dev, dtype=torch.int64)
+                ent["lr_dev"] = torch.zeros(1, device=dev, dtype=torch.float32)
+                ent["step_dev_val"], ent["lr_dev_val"] = None, None
+            if ent["step_dev_val"] != ent["step"]:
+                ent["step_dev"].fill_(ent["step"])
+                ent["step_dev_val"] = ent["step"]
+            if ent["lr_dev_val"] != group["lr"]:
+                ent["lr_dev"].fill_(group["lr"])
+                ent["lr_dev_val"] = group["lr"]
+
+    def graph_replayed(self):
+        """Host-side bookkeeping after one replay of a captured step(): the device counters advanced by one."""
+        for ent in self._flat.values():
+            if ent.get("ok") and "step_dev" in ent:
+                ent["step"] += 1
+                ent["step_dev_val"] += 1
+                for p in ent["order"]:
+                    torch.autograd.graph.increment_version(p)
+
+    def graph_capturable(self):
+        return bool(self._flat) and all(e.get("ok") for e in self._flat.values())
 
     def _flat_state(self, gi, group):
         """Detect that a group's grad-bearing params tile one contiguous f32 range (the LoRA bucket)."""
@@ -57,6 +89,11 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ent = self._flat_state(gi, group)
             if ent is None:
+                continue
+            if ent["ok"] and self.graph_mode:      # being captured: counters on the device, host bookkeeping in graph_replayed()
+                ent["step_dev"].add_(1)
+                ops.adamw_flat_dev(ent["p"], ent["g"], ent["m"], ent["v"], ent["lr_dev"], b1, b2, group["eps"],
+                                   group["weight_decay"], ent["step_dev"])
                 continue
             if ent["ok"]:
                 ent["step"] += 1

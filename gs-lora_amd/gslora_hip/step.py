@@ -63,8 +63,11 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     else:
         out_r, emb_r = model(x_r.float(), y_r)
         out_f, emb_f = model(x_f.float(), y_f)
-    n_r = torch.tensor(float(x_r.size(0)), device=dev)
-    n_f = torch.tensor(float(x_f.size(0)), device=dev)
+    if world > 1:      # device scalars: they travel in the packed all-reduce below (fill kernels, no pageable H2D copy)
+        n_r = torch.full((), float(x_r.size(0)), device=dev)
+        n_f = torch.full((), float(x_f.size(0)), device=dev)
+    else:
+        n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
     if _plain_ce(criterion):
         ce_r_sum, hit_r = backend.ce_sum_top1(out_r, y_r)
         ce_f_sum, hit_f = backend.ce_sum_top1(out_f, y_f)
@@ -104,6 +107,110 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     return torch.stack([(beta * loss_forget).detach(), loss_remain.detach(), total.detach(), (alpha * structure).detach(),
                         hit_f * (100.0 / g_nf), hit_r * (100.0 / g_nr), pro_f.detach() if use_prototype else zero,
                         pro_r.detach() if use_prototype else zero])
+
+
+class GraphedStep:
+    """gs_lora_step captured ONCE per configuration as a HIP graph and replayed: below ~64 images per forward the eager step is
+    bound by the ~370 kernel launches it makes from Python (4.7 ms at batch 4+4 and 5.9 ms at the reference's batch 48+48 on
+    MI355X), not by the GPU. Everything that varies from step to step is read from device memory by the captured kernels: the batch
+    (static input buffers), the dropout seed (GSL_SEED_ON_DEVICE), AdamW's step count and learning rate (gsl_adamw_flat_dev).
+    Everything else is part of the key — shapes, the loss hyper-parameters, the prototype table, train/eval state, the versions of
+    the frozen weights (eval()/train() merge round trips, load_state_dict) — and a key change falls back to one eager step (which
+    also refreshes the operand caches) followed by a fresh capture. Replays are bit-identical to eager steps (same kernels, same
+    seeds; tests/test_hip_graph.py). Single process only: with torch.distributed initialised the step stays eager."""
+
+    def __init__(self, model, optimizer, criterion):
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.net = model.module if isinstance(model, nn.DataParallel) else model
+        self._frozen = [p for n, p in self.net.named_parameters() if "lora_" not in n]
+        self.key = self.pending = self.graph = self.static = None
+        self.seed_dev, self._seed_val, self._nfwd = None, None, 0
+        self.replays = self.captures = self.eager_steps = 0
+
+    def _key(self, x_r, y_r, x_f, y_f, kw):
+        pt = kw.get("proto_table")
+        return (tuple(x_r.shape), tuple(x_f.shape), x_r.dtype, y_r.dtype, self.net.training, self.net.compute_dtype,
+                sum(p._version for p in self._frozen), None if pt is None else (pt.data_ptr(), tuple(pt.shape)),
+                tuple(sorted((k, v) for k, v in kw.items() if k != "proto_table")))
+
+    def _usable(self):
+        return (_world() == 1 and hasattr(self.optimizer, "graph_capturable") and _plain_ce(self.criterion)
+                and not isinstance(self.model, nn.DataParallel))
+
+    def _eager(self, x_r, y_r, x_f, y_f, kw):
+        self.eager_steps += 1
+        return gs_lora_step(self.model, self.optimizer, self.criterion, x_r, y_r, x_f, y_f, **kw)
+
+    def __call__(self, x_r, y_r, x_f, y_f, **kw):
+        if not self._usable():
+            return self._eager(x_r, y_r, x_f, y_f, kw)
+        key = self._key(x_r, y_r, x_f, y_f, kw)
+        if key != self.key:
+            if key != self.pending or not self.optimizer.graph_capturable():
+                # first sighting of this configuration: one eager step (warms operand caches, optimizer state, gradient bucket)
+                self.pending, self.key, self.graph = key, None, None
+                return self._eager(x_r, y_r, x_f, y_f, kw)
+            self._capture(x_r, y_r, x_f, y_f, kw)
+            self.key, self.pending = key, None
+        xr, yr, xf, yf = self.static[:4]
+        xr.copy_(x_r, non_blocking=True)
+        yr.copy_(y_r, non_blocking=True)
+        xf.copy_(x_f, non_blocking=True)
+        yf.copy_(y_f, non_blocking=True)
+        # device-resident step state: AdamW (step, lr) and the dropout seed follow the host values
+        self.optimizer.graph_sync()
+        r = self.net.runner()
+        want = (r.drop_seed << 20) + r.drop_calls
+        if self._seed_val != want:
+            self.seed_dev.fill_(want)
+            self._seed_val = want
+        self.graph.replay()
+        r.drop_calls += self._nfwd
+        self._seed_val += self._nfwd
+        self.optimizer.graph_replayed()
+        self.replays += 1
+        return self.static[4].clone()
+
+    def _capture(self, x_r, y_r, x_f, y_f, kw):
+        r = self.net.runner()
+        self.static = [x_r.clone(), y_r.clone(), x_f.clone(), y_f.clone(), None]
+        if self.seed_dev is None:
+            self.seed_dev = torch.zeros(1, device=x_r.device, dtype=torch.int64)
+        self._seed_val = None
+        self.optimizer.graph_sync()
+        calls0 = r.drop_calls
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.graph_mode, r.seed_dev = True, self.seed_dev
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *self.static[:4], **kw)
+        finally:
+            self.optimizer.graph_mode, r.seed_dev = False, None     # eager forwards keep passing the seed by value
+            self._nfwd = r.drop_calls - calls0
+            r.drop_calls = calls0                                     # nothing ran during capture
+        self.captures += 1
+
+
+def graphed_step_for(model, optimizer, criterion):
+    """The engines call train_one_epoch once per epoch: the captured graph lives on the optimizer object across calls."""
+    cache = optimizer.__dict__.setdefault("_gsl_graphed", {})
+    k = (id(model), id(criterion))
+    if k not in cache or cache[k].model is not model:
+        cache.clear()
+        cache[k] = GraphedStep(model, optimizer, criterion)
+    return cache[k]
+
+
+GRAPH_AUTO_MAX_IMAGES = 256     # "auto": capture when a step carries at most this many images (launch-bound regime)
+
+
+def pick_stepper(model, optimizer, criterion, cfg, n_images):
+    """cfg["HIP_GRAPH"]: True / False / "auto" (default). Returns a callable with gs_lora_step's data/keyword signature."""
+    mode = (cfg or {}).get("HIP_GRAPH", "auto")
+    if mode is True or (mode == "auto" and n_images <= GRAPH_AUTO_MAX_IMAGES):
+        return graphed_step_for(model, optimizer, criterion)
+    return lambda x_r, y_r, x_f, y_f, **kw: gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, **kw)
 
 
 class MeterQueue:

@@ -69,6 +69,7 @@ class LoraBucket:
         self.tnumel = torch.tensor([p.numel() for p in self.params], device=dev, dtype=torch.int64)
         self.tgroup_block = torch.tensor(self.groups, device=dev, dtype=torch.int32)
         self.ngroups_block = len(layers)
+        self._gtables = {}
 
     def valid(self):
         base = self.flat.data_ptr()
@@ -79,6 +80,8 @@ class LoraBucket:
         L_ = self.ngroups_block
         if group_type == "block":
             return self.tgroup_block, L_
+        if group_type in self._gtables:
+            return self._gtables[group_type]
         ids = []
         for i in range(L_):
             if group_type == "lora":
@@ -88,7 +91,8 @@ class LoraBucket:
             else:
                 raise ValueError(f"unknown group type {group_type}")
         n = 2 * L_ if group_type == "lora" else 4 * L_
-        return torch.tensor(ids, device=self.flat.device, dtype=torch.int32), n
+        self._gtables[group_type] = (torch.tensor(ids, device=self.flat.device, dtype=torch.int32), n)
+        return self._gtables[group_type]
 
     def attach_grads(self):
         """Give every LoRA parameter its view of the flat gradient bucket. Returns True when the
@@ -111,7 +115,9 @@ class ViTRunner:
         self.bucket = None
         self._wcache = {}
         self._lcache = {}
+        self._packs, self._pack_tables = {}, {}
         self._rank = 0
+        self.seed_dev = None      # int64 [1] device tensor: dropout seed of a step that is being captured / replayed as a HIP graph
         self.drop_seed = 0x5EED
         self.drop_calls = 0
 
@@ -145,29 +151,61 @@ class ViTRunner:
         """[K,N] transposed operand (dX GEMMs)."""
         return self._cached(self._wcache, (name, "t", dtype), param, lambda p: ops.transpose_cast(p.contiguous(), dtype))
 
+    PACK_GEOM = {   # kind -> (si, sj, rows, cols, rows_out, ld_out) of gsl_pack_pad as functions of the LoRA tensor's (rows, cols, r)
+        "A_rows": lambda R, C, r: (C, 1, r, C, PADK, C),        # [64, K]  rows j<r = A[j,:]
+        "B_cols": lambda R, C, r: (r, 1, R, r, R, PADK),        # [N, 64]  cols j<r = B[:,j]
+        "BT_rows": lambda R, C, r: (1, r, r, R, PADK, R),       # [64, N]  out[j, n] = B[n, j]
+        "AT_cols": lambda R, C, r: (1, C, C, r, C, PADK),       # [K, 64]  out[k, j] = A[j, k]
+        # operands of the in-kernel LoRA GEMM (gsl_gemm_nt_lora): P [16, K], Q [N, 32]
+        "A_rows16": lambda R, C, r: (C, 1, r, C, 16, C),
+        "B_cols32": lambda R, C, r: (r, 1, R, r, R, 32),
+        "BT_rows16": lambda R, C, r: (1, r, r, R, 16, R),
+        "AT_cols32": lambda R, C, r: (1, C, C, r, C, 32),
+    }
+
     def lora_pack(self, name, param, kind, dtype):
-        def build(p):
-            rows, cols = p.shape
-            r = min(rows, cols)
-            if kind == "A_rows":      # [64, K]  rows j<r = A[j,:]
-                return ops.pack_pad(p, cols, 1, r, cols, PADK, cols, dtype)
-            if kind == "B_cols":      # [N, 64]  cols j<r = B[:,j]
-                return ops.pack_pad(p, r, 1, rows, r, rows, PADK, dtype)
-            if kind == "BT_rows":     # [64, N]  out[j, n] = B[n, j]
-                return ops.pack_pad(p, 1, r, r, rows, PADK, rows, dtype)
-            if kind == "AT_cols":     # [K, 64]  out[k, j] = A[j, k]
-                return ops.pack_pad(p, 1, cols, cols, r, cols, PADK, dtype)
-            # operands of the in-kernel LoRA GEMM (gsl_gemm_nt_lora): P [16, K], Q [N, 32]
-            if kind == "A_rows16":
-                return ops.pack_pad(p, cols, 1, r, cols, 16, cols, dtype)
-            if kind == "B_cols32":
-                return ops.pack_pad(p, r, 1, rows, r, rows, 32, dtype)
-            if kind == "BT_rows16":
-                return ops.pack_pad(p, 1, r, r, rows, 16, rows, dtype)
-            if kind == "AT_cols32":
-                return ops.pack_pad(p, 1, cols, cols, r, cols, 32, dtype)
-            raise ValueError(kind)
-        return self._cached(self._lcache, (name, kind, dtype), param, build)
+        """Padded / transposed compute-dtype copy of one LoRA tensor. The output buffers are persistent and registered in a device
+        descriptor table: after the first step, refresh_lora_packs() rebuilds ALL of them with one launch per step."""
+        key = (name, kind, dtype)
+        ent = self._packs.get(key)
+        if ent is None or ent["ptr"] != param.data_ptr() or ent["dev"] != param.device:
+            rows, cols = param.shape
+            si, sj, pr, pc, ro, ld = self.PACK_GEOM[kind](rows, cols, min(rows, cols))
+            out = torch.empty(ro, ld, device=param.device, dtype=dtype)
+            ent = dict(ptr=param.data_ptr(), dev=param.device, param=param, out=out, geom=(si, sj, pr, pc), version=None)
+            self._packs[key] = ent
+            self._pack_tables.pop(dtype, None)
+        if ent["version"] != param._version:
+            si, sj, pr, pc = ent["geom"]
+            with torch.no_grad():
+                L.check(L.load().gsl_pack_pad(param.data_ptr(), si, sj, pr, pc, 1.0, ent["out"].data_ptr(), ent["out"].shape[0],
+                                              ent["out"].shape[1], ops.code(dtype), ops._stream()), "gsl_pack_pad")
+            ent["version"] = param._version
+        return ent["out"]
+
+    def refresh_lora_packs(self, dtype):
+        """One launch for every registered pack whose source changed (the optimizer touches all LoRA tensors each step)."""
+        ents = [e for k, e in self._packs.items() if k[2] == dtype]
+        if len(ents) < 2 or all(e["version"] == e["param"]._version for e in ents):
+            return
+        tab = self._pack_tables.get(dtype)
+        if tab is None or tab[2] != len(ents):
+            if torch.cuda.is_current_stream_capturing():
+                return      # no H2D copy inside a capture: lora_pack() refreshes tensor by tensor (build_pack_tables() avoids this)
+            tab = self.build_pack_tables(dtype)
+        ops.pack_pad_batch(tab[0], tab[2], tab[1], dtype)
+        for e in ents:
+            e["version"] = e["param"]._version
+
+    def build_pack_tables(self, dtype):
+        """Device descriptor table of every registered pack of `dtype` (called at the end of an eager backward, so that a following
+        HIP-graph capture finds it ready)."""
+        ents = [e for k, e in self._packs.items() if k[2] == dtype]
+        tab = self._pack_tables.get(dtype)
+        if ents and (tab is None or tab[2] != len(ents)):
+            t, mx = ops.pack_desc_table([(e["param"], *e["geom"], 1.0, e["out"]) for e in ents], ents[0]["dev"])
+            tab = self._pack_tables[dtype] = (t, mx, len(ents))
+        return tab
 
     def lora_in_kernel(self, dtype, rows):
         """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation)."""
@@ -182,6 +220,8 @@ class ViTRunner:
         if self.bucket is None or not self.bucket.valid() or any(a is not b for a, b in zip(self.bucket.params, (p for g in layers for p in g))):
             self.bucket = LoraBucket(layers)
             self._lcache.clear()
+            self._packs.clear()
+            self._pack_tables.clear()
         return self.bucket
 
     # ------------------------------------------------------------------ forward
@@ -206,9 +246,15 @@ class ViTRunner:
         p_drop = sp.dropout_p if training else 0.0
         p_emb = sp.emb_dropout_p if training else 0.0
         self.drop_calls += 1
-        seed = (self.drop_seed << 20) + self.drop_calls
+        if self.seed_dev is not None:      # HIP-graph mode: the kernels read the seed from device memory; one captured increment per forward
+            self.seed_dev.add_(1)
+            seed, sflag = self.seed_dev.data_ptr(), L.SEED_ON_DEVICE
+        else:
+            seed, sflag = (self.drop_seed << 20) + self.drop_calls, 0
         self.ensure_bucket(sp)
         r = sp.lora_rank
+        if r > 0:
+            self.refresh_lora_packs(dt)
         s_lora = (1.0 / r) if r > 0 else 0.0
         eps = sp.ln_eps
 
@@ -217,7 +263,7 @@ class ViTRunner:
         pw = self.w_conv("pe", sp.patch_w, dt) if sp.patch_is_conv else self.w("pe", sp.patch_w, dt)
         ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH, bias=sp.patch_b.detach(),
                     pos=sp.pos.detach()[0, :T].contiguous(), cls=sp.cls.detach().reshape(-1), T=T,
-                    p_drop=p_emb, seed=seed, site=SITE_EMB)
+                    p_drop=p_emb, seed=seed, site=SITE_EMB | sflag)
         del patches
         stash = []
         for i, blk in enumerate(sp.blocks):
@@ -229,7 +275,7 @@ class ViTRunner:
             o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale)
             x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
             ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
-                        bias=blk.out.bias.detach(), res=x, p_drop=p_drop, seed=seed, site=4 * i)
+                        bias=blk.out.bias.detach(), res=x, p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
             xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
             l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
@@ -242,22 +288,22 @@ class ViTRunner:
                 ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, A2=u1,
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
-                            p_drop=p_drop, seed=seed, site=4 * i + 1, tag="ffn1")
+                            p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
                 u2 = torch.empty(M, PADK, device=img.device, dtype=dt)
                 if not self.lora_in_kernel(dt, M):
                     ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, bias=l1.bias.detach(),
-                            out2=gp, p_drop=p_drop, seed=seed, site=4 * i + 1)
+                            out2=gp, p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag)
             x2 = torch.empty(M, D, device=img.device, dtype=torch.float32)
             if lora_on and self.lora_in_kernel(dt, M):
                 ops.gemm_nt_lora(h, self.w(f"w2_{i}", l2.weight, dt), self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows16", dt),
                                  self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols32", dt), s_lora, u2, x2, epilogue=L.EPI_BIAS_RES_F32,
-                                 bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
+                                 bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             else:
                 ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=L.EPI_BIAS_RES_F32, A2=u2,
                             W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
-                            bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=4 * i + 2)
+                            bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
                                   xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on))
@@ -273,7 +319,7 @@ class ViTRunner:
                                                      sp.cos_s, sp.cos_m)
         saved = None
         if save:
-            saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, p_drop=p_drop,
+            saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, sflag=sflag, p_drop=p_drop,
                          dt=dt, spec=sp)
         return logits, emb, saved
 
@@ -286,7 +332,7 @@ class ViTRunner:
             return
         bucket.attach_grads()
         dt = saved["dt"]
-        B, seed, p_drop = saved["B"], saved["seed"], saved["p_drop"]
+        B, seed, p_drop, sflag = saved["B"], saved["seed"], saved["p_drop"], saved["sflag"]
         T, D, H = sp.num_tokens, sp.dim, sp.heads
         r = sp.lora_rank
         s_lora = 1.0 / r
@@ -301,7 +347,7 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
-                               site=4 * (nl - 1) + 2, linear=linear_head)
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head)
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -357,10 +403,10 @@ class ViTRunner:
             if sparse:   # update the cls rows of the dense stream gradient in place; dx1b is the compact masked copy
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
                                               cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
-                                              p_drop=p_drop, seed=seed, site=4 * i, drop_row_stride=T * D)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
             else:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
-                                              p_drop=p_drop, seed=seed, site=4 * i)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
             del dxn2
             # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
@@ -374,5 +420,7 @@ class ViTRunner:
             del d_o, dqkv, dx1b
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
-                                        p_drop=p_drop, seed=seed, site=4 * (i - 1) + 2)
+                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag)
             saved["layers"][i] = None   # free this layer's activations
+        if not torch.cuda.is_current_stream_capturing():
+            self.build_pack_tables(dt)    # every pack of the step is registered now: the next forward refreshes them in one launch

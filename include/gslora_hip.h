@@ -57,7 +57,10 @@ int gsl_patchify(const float* img, void* out, int B, int C, int H, int W, int p,
  * and their autograd dX.
  *   A1 [M,K1] (lda1), W1 [N,K1] (ldw1); A2 [M,K2] (lda2), W2 [N,K2] (ldw2)  — all `dtype`;
  *   K1 % 64 == 0, K2 % 64 == 0 (K2 may be 0). bias/res/pos/cls f32. out/out2/aux per epilogue.
- *   dropout: p_drop in [0,1); mask = hash(seed, site, m*N+n) (see gsl_dropout_keep in DESIGN.md). */
+ *   dropout: p_drop in [0,1); mask = hash(seed, site, m*N+n) (see gsl_dropout_keep in DESIGN.md).
+ *   Every (seed, site) pair of this ABI: when bit 31 of `site` (GSL_SEED_ON_DEVICE) is set, `seed` is not the value but a device
+ *   pointer to a uint64 holding it — the kernels load it, so a captured HIP graph replays with the value current at replay time. */
+#define GSL_SEED_ON_DEVICE 0x80000000u
 int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
                 const void* A2, int lda2, const void* W2, int ldw2, int K2,
                 int M, int N, int dtype, int epilogue, float alpha,
@@ -155,6 +158,10 @@ int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const int64_t* t
  * train_own_forget_cl.py:811-813): decoupled wd, bias correction, step >= 1. */
 int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n,
                    float lr, float beta1, float beta2, float eps, float wd, int step, gsl_stream_t s);
+/* HIP-graph form of the same update: the step count t (>= 1, int64) and the learning rate (f32) are read from device memory,
+ * so a captured graph of the whole forgetting step replays with fresh values (bias corrections 1 - beta^t in f64 in-kernel). */
+int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
+                       float eps, float wd, const int64_t* step_dev, gsl_stream_t s);
 
 /* ---- helpers: f32 -> dtype casts for the frozen-weight caches and padded LoRA operands. */
 int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s);
@@ -163,6 +170,12 @@ int gsl_transpose_cast(const float* in, void* out, int R, int C, int dtype, gsl_
 /* out[dtype] [rows_out, ld_out] zero-padded copy: out[i, j] = scale * in[i*si + j*sj] for i<rows, j<cols. */
 int gsl_pack_pad(const float* in, long si, long sj, int rows, int cols, float scale,
                  void* out, int rows_out, int ld_out, int dtype, gsl_stream_t s);
+/* The same for n packs in one launch. descs_dev: device array of n descriptors (all outputs share `dtype`); max_elems =
+ * max over descriptors of rows_out * ld_out. The table is built once by the host and reused every step (HIP-graph friendly). */
+typedef struct gsl_pack_desc {
+  const float* in; long si, sj; int rows, cols; float scale; int pad_; void* out; int rows_out, ld_out;
+} gsl_pack_desc;
+int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long max_elems, int dtype, gsl_stream_t s);
 
 /* dropout keep-mask as the kernels compute it (for tests): keep[i] = 1/0 for element index i. */
 int gsl_dropout_mask(uint8_t* keep, long n, float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);

@@ -1,0 +1,100 @@
+"""HIP-graph replay of the forgetting step (gslora_hip.step.GraphedStep) against the eager step: same kernels, same seeds —
+the meters and every LoRA parameter must be BIT-IDENTICAL, across a learning-rate change (lr is device resident) and an
+eval()/train() round trip (frozen-weight versions change -> one eager step + re-capture)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import recipe
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg, dtype, dropout):
+    import loralib as lora
+    from vit_pytorch_face import ViT_face
+    m = ViT_face(loss_type="CosFace", GPU_ID=[0], num_class=cfg["num_class"], image_size=cfg["image_size"],
+                 patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"], mlp_dim=cfg["mlp_dim"],
+                 dropout=dropout, emb_dropout=dropout, lora_rank=cfg["lora_rank"])
+    m.load_state_dict({k: torch.tensor(v) for k, v in recipe.make_state(cfg).items()}, strict=True)
+    lora.mark_only_lora_as_trainable(m)
+    return m.to("cuda").set_compute_dtype(dtype).train()
+
+
+def batch(cfg, b, s):
+    nf = max(2, cfg["num_class"] // 5)
+    mk = lambda a: torch.tensor(a).cuda()
+    return (mk(recipe.make_images(cfg, b, seed=100 + s, tag="xr")), mk(recipe.make_labels(cfg, b, seed=100 + s, tag="yr", lo=0, hi=cfg["num_class"] - nf)),
+            mk(recipe.make_images(cfg, b, seed=200 + s, tag="xf")), mk(recipe.make_labels(cfg, b, seed=200 + s, tag="yf", lo=cfg["num_class"] - nf, hi=cfg["num_class"])))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_graph_replay_bit_identical_to_eager(dtype):
+    from gslora_hip.optim import FusedAdamW
+    from gslora_hip.step import GraphedStep, gs_lora_step
+    cfg, b = recipe.cfg_small2(), 6
+    m1 = build(cfg, dtype, 0.1)
+    m2 = copy.deepcopy(m1)
+    mk_opt = lambda m: FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    o1, o2 = mk_opt(m1), mk_opt(m2)
+    crit = torch.nn.CrossEntropyLoss()
+    proto = torch.tensor(recipe.make_prototypes(cfg)).cuda()
+    kw = dict(beta=0.15, alpha=1e-2, BND=105.0, use_structure=True, group_type="block", use_prototype=True, proto_table=proto,
+              w_f=0.05, w_r=0.1, BND_pro=2.0)
+    g = GraphedStep(m2, o2, crit)
+    x_eval = batch(cfg, b, 99)
+    for s in range(9):
+        if s == 4:      # cosine schedule moves the lr between epochs: no re-capture needed
+            for o in (o1, o2):
+                o.param_groups[0]["lr"] = 5e-3
+        if s == 6:      # evaluation between steps: loralib merge / un-merge bumps the frozen weights' versions
+            for m in (m1, m2):
+                m.eval()
+                with torch.no_grad():
+                    m(x_eval[0], x_eval[1])
+                m.train()
+        xr, yr, xf, yf = batch(cfg, b, s)
+        p1 = gs_lora_step(m1, o1, crit, xr, yr, xf, yf, **kw)
+        p2 = g(xr, yr, xf, yf, **kw)
+        assert torch.equal(p1, p2), (s, p1.tolist(), p2.tolist())
+        for (n, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()):
+            if a.requires_grad:
+                assert torch.equal(a, c), (s, n)
+    # steps 0 (first sighting) and 6 (after the eval round trip) ran eagerly, 1 and 7 captured + replayed, the rest replayed
+    assert (g.eager_steps, g.captures, g.replays) == (2, 2, 7)
+    assert o2._flat[0]["step"] == o1._flat[0]["step"] == 9
+
+
+def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path):
+    """engine_cl.train_one_epoch with cfg HIP_GRAPH 'auto' (batch 5+5 -> graph) vs HIP_GRAPH False: identical meters / parameters."""
+    import engine_cl
+    from gslora_hip.optim import FusedAdamW
+    from util.utils import AverageMeter
+    cfg, b = recipe.cfg_small(), 5
+    proto_np = recipe.make_prototypes(cfg)
+    proto = {c: torch.tensor(proto_np[c]) for c in range(cfg["num_class"])}
+    res = {}
+    for mode in (False, "auto"):
+        m = build(cfg, "bf16", 0.1)
+        opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+        crit = torch.nn.CrossEntropyLoss()
+        cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": 2.0, "MULTI_GPU": False, "WORK_PATH": str(tmp_path), "BACKBONE_NAME": "VIT",
+                "HIP_GRAPH": mode}
+        loader_r = [batch(cfg, b, s)[:2] for s in range(6)]
+        loader_f = [batch(cfg, b, s)[2:] for s in range(6)]
+        mk = AverageMeter
+        meters = dict(losses_forget=mk(), losses_remain=mk(), losses_total=mk(), losses_structure=mk(), top1_forget=mk(),
+                      top1_remain=mk(), losses_prototype_forget=mk(), losses_prototype_remain=mk())
+        ret = engine_cl.train_one_epoch(
+            model=m, dataloader_forget=loader_f, dataloader_remain=loader_r, device=torch.device("cuda"), criterion=crit, optimizer=opt,
+            epoch=0, beta=0.15, alpha=1e-2, BND=105.0, batch=0, testloader_forget=None, testloader_remain=None, forget_acc_before=0.0,
+            highest_H_mean=0.0, cfg=cfgd, task_i="0", use_prototype=True, prototype_dict=proto, prototype_weight_forget=0.05,
+            prototype_weight_remain=0.1, **meters)
+        res[mode] = ([ret[i].avg for i in range(2, 10)], {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad})
+        if mode == "auto":
+            g = opt._gsl_graphed[(id(m), id(crit))]
+            assert (g.eager_steps, g.captures, g.replays) == (1, 1, 5)
+    assert res[False][0] == res["auto"][0]
+    for n in res[False][1]:
+        assert torch.equal(res[False][1][n], res["auto"][1][n]), n

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph")
     a = ap.parse_args()
     import loralib as lora
     from gslora_hip.optim import FusedAdamW
@@ -43,7 +44,9 @@ def main():
     y = torch.cat([torch.randint(0, 80, (B,)), torch.randint(80, 100, (B,))]).cuda()
     proto = torch.randn(100, 768, device="cuda")
     crit = torch.nn.CrossEntropyLoss()
-    step = lambda: gs_lora_step(m, opt, crit, x[:B], y[:B], x[B:], y[B:], beta=0.15, alpha=1e-4, BND=105.0, use_prototype=True,
+    from gslora_hip.step import GraphedStep
+    stepper = GraphedStep(m, opt, crit) if a.graph else (lambda *t, **k: gs_lora_step(m, opt, crit, *t, **k))
+    step = lambda: stepper(x[:B], y[:B], x[B:], y[B:], beta=0.15, alpha=1e-4, BND=105.0, use_prototype=True,
                                 proto_table=proto, w_f=0.05, w_r=0.05, BND_pro=18.0)
     for _ in range(a.warmup):
         step()
@@ -56,7 +59,7 @@ def main():
     # model flops per image (fwd 1x + bwd: dX for 11 of 12 blocks' dense GEMMs, no dense dW): reported for orientation only
     T, D, F, L = 197, 768, 3072, 12
     fwd = L * (2 * T * D * 3 * D + 2 * T * D * D + 4 * T * D * F + 4 * T * T * D) + 2 * T * D * 768
-    print(json.dumps({"workload": f"ViT-B/16 224px r={a.rank} forget step, batch {B}+{B}, {a.dtype}", "images_per_s": round(2 * B * a.steps / el, 2),
+    print(json.dumps({"workload": f"ViT-B/16 224px r={a.rank} forget step, batch {B}+{B}, {a.dtype}" + (", HIP graph" if a.graph else ""), "images_per_s": round(2 * B * a.steps / el, 2),
                       "ms_per_step": round(1e3 * el / a.steps, 3), "fwd_gflop_per_image": round(fwd / 1e9, 2),
                       "meters": [round(v, 4) for v in pack.tolist()]}))
 
