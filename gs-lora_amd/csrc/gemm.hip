@@ -165,6 +165,96 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
     }
   }
 }
+// MUL epilogue (dX * GELU'): the aux operand is as large as the output. Loading it in fragment layout has the same partial-line
+// problem as the stores had, so here the f32 accumulators are staged (same wave-private region, 64 rows x 68 floats), read back
+// row-contiguous, and aux is loaded / the result stored as full 128-byte rows (16 B per lane). Same arithmetic as epi_math<MUL>:
+// bf16( alpha * acc * f32(aux) ), one rounding — bit-identical to the fragment-layout path.
+constexpr int CLF = 68;    // floats per staged row (272 B: 16-byte aligned)
+template <int NI>
+__device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+  const int crow = lane >> 3, cch = lane & 7;
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
+  bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
+#pragma unroll
+  for (int ib = 0; ib < NI; ib += 4) {
+    uint4 ax[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {      // aux rows of this 64-row chunk: issued first, consumed after the LDS round trip
+      const int m = min(mw + ib * 16 + r * 8 + crow, e.M - 1), n = min(nw + cch * 8, e.N - 8);
+      ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + n);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t v = acc[ib + ii][j];
+        if (e.alpha != 1.0f) v *= e.alpha;
+        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+      }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = r * 8 + crow;
+      const int m = mw + ib * 16 + row, n = nw + cch * 8;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
+      const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
+        o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+      }
+      if (m < e.M && n < e.N) *reinterpret_cast<uint4*>(out + (size_t)m * e.ldo + n) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+// BIAS_RES_F32 epilogue (out-proj / FFN2 forward: x + drop(acc + bias), f32 stream): same staging, the residual is loaded and the
+// result stored as full 256-byte rows (16 lanes x 16 B per row, 4 rows per instruction) instead of 64-byte fragment rows.
+// Arithmetic identical to epi_math<BIAS_RES_F32>: (alpha * acc + bias) * mask + res.
+template <int NI>
+__device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+  const int crow = lane >> 4, cq = lane & 15;      // copy phase: row-in-group, 4-float column group
+  float* out = reinterpret_cast<float*>(e.out);
+  const int n = nw + cq * 4;
+  f32x4_t b4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (n < e.N) b4 = *reinterpret_cast<const f32x4_t*>(e.bias + n);
+#pragma unroll
+  for (int ib = 0; ib < NI; ib += 4) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {          // 32 rows at a time: 8 residual loads in flight per lane
+      f32x4_t rs[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int m = min(mw + ib * 16 + half * 32 + r * 4 + crow, e.M - 1);
+        rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4_t v = acc[ib + ii][j];
+            if (e.alpha != 1.0f) v *= e.alpha;
+            *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = half * 32 + r * 4 + crow;
+        const int m = mw + ib * 16 + row;
+        const f32x4_t c = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cq * 4);
+        float dm[4];
+        drop_mul4(e.drop, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, dm);
+        f32x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
+        if (m < e.M && n < e.N) *reinterpret_cast<f32x4_t*>(out + (size_t)m * e.ldo + n) = o;
+      }
+    }
+  }
+}
 constexpr int CST_WAVE = 2 * 64 * CLD;            // bf16 elements of staging per wave (two outputs)
 constexpr int CST_BLOCK8 = 8 * CST_WAVE;          // 8 waves: 147 456 bytes
 
@@ -686,9 +776,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
   }
+  if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
+    if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
+      epilogue_staged_res_f32<8>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+      return;
+    }
+  }
   if constexpr (!epi_out_is_f32<EPI>()) {
     if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
+      if constexpr (EPI == GSL_EPI_MUL) {
+        if (e.N >= 8) {
+          epilogue_staged_mul<8>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+          return;
+        }
+      }
       epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
       return;
     }
