@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
   if (abl == 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
+  const int ktf = T >> 4;      // key tiles below this index are completely valid
   const int nwaves = blockDim.x >> 6;
   bf16x8_t qn0, qn1;   // Q fragments of the NEXT query tile: their global-load latency hides under this tile's work
   {
@@ -138,21 +139,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
       acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 0, fc), qf0, acc);
       acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 1, fc), qf1, acc);
+      // the softmax is VALU-bound (52 scores per lane and query tile): the running max is taken on the raw scores (scale > 0), the
+      // scale and log2(e) are folded into one fma in front of v_exp_f32, and only key tiles >= T/16 (a wave-uniform test) hold padded keys
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + fc * 4 + r;
-        acc[r] = (key < T) ? acc[r] * scale : -3.0e38f;
+        if (kt >= ktf) { if (kt * 16 + fc * 4 + r >= T) acc[r] = -3.0e38f; }
         m = fmaxf(m, acc[r]);
       }
       s[kt] = acc;
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float c2 = scale * 1.4426950408889634f, mc = m * c2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m); l += s[kt][r]; }
+      for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mc)); l += s[kt][r]; }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     Frag pf[NKT / 2];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
       // acc[r] = O[q = fr][d = dt*16 + fc*4 + r]
       if (qr < T) store4bf(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + fc * 4, acc, inv);
     }
-    if (fc == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m + __logf(l);
+    if (fc == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m * scale + __logf(l);
   }
 }
 
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   if (abl == 1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
+  const int ktf = T >> 4;      // key tiles below this index are completely valid
   const int nwaves = blockDim.x >> 6;
   for (int qt = wave; qt < nqt; qt += nwaves) {
     asm volatile("" ::: "memory");   // 8 waves per block: keep the fragment reads in the loop (<= 256 registers)
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    const float lq = lse[((size_t)b * H + h) * T + qrc];
+    const float c2 = scale * 1.4426950408889634f, lq2 = lse[((size_t)b * H + h) * T + qrc] * 1.4426950408889634f;
     Frag dsf[NKT / 2];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
       dp = mfma16(lds_frag_rm(Vs, kt * 16 + fr, 1, fc), dof1.v, dp);
       float ds[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + fc * 4 + r;
-        const float p = (key < T) ? __expf(sa[r] * scale - lq) : 0.f;
-        ds[r] = p * (dp[r] - dl) * scale;
+      for (int r = 0; r < 4; ++r) {      // dS without the softmax scale: it is applied once to the 16 dQ accumulators below
+        float p = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lq2));
+        if (kt >= ktf) { if (kt * 16 + fc * 4 + r >= T) p = 0.f; }
+        ds[r] = p * (dp[r] - dl);
       }
       if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.y = pack2bf(ds[2], ds[3]); }
       else { dsf[kt / 2].u.z = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.w = pack2bf(ds[2], ds[3]); }
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_tr<VLD>(Kt, dt * 16 + fr, pr, fc), dsf[pr].v, acc);
-      if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, 1.0f);
+      if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, scale);
     }
     if (fc == 0 && qr < T) delta[((size_t)b * H + h) * T + qr] = dl;
   }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
     stage_transposed<TP>(Ot, dob, ldo, T);
   }
   for (int t = threadIdx.x; t < TP; t += blockDim.x) {
-    lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] : 3.0e38f;   // padded queries -> p = 0
+    lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;   // log2 units; padded queries -> p = 0
     del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
   }
   __syncthreads();
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nkt = (T + 15) / 16;
   const int nwaves = blockDim.x >> 6;
+  const float c2 = scale * 1.4426950408889634f;
   // Each wave owns TWO adjacent key tiles: every Q / dO / Q^T / dO^T fragment read from LDS feeds two MFMAs (one per
   // key tile). The kernel is LDS-bandwidth-bound (1 KB of fragment reads per MFMA when a wave owns a single tile).
   for (int kp = wave; kp * 2 < nkt; kp += nwaves) {
@@ -324,8 +329,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
           float p[4], ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            p[r] = __expf(sa[r] * scale - lv[r]);
-            ds[r] = p[r] * (dp[r] - dv[r]) * scale;
+            p[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lv[r]));
+            ds[r] = p[r] * (dp[r] - dv[r]);          // softmax scale applied once to the dK accumulators at the store
           }
           if (half == 0) {
             pf[t].u.x = pack2bf(p[0], p[1]); pf[t].u.y = pack2bf(p[2], p[3]);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           bf16_t* base = dqkv + ((size_t)b * T + kr[t]) * ld + h * HD + dt * 16 + fc * 4;
-          store4bf(base + H * HD, adk[t][dt], 1.0f);
+          store4bf(base + H * HD, adk[t][dt], scale);
           store4bf(base + 2 * H * HD, adv[t][dt], 1.0f);
         }
       }
