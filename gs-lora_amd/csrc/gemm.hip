@@ -42,13 +42,24 @@ struct EpiArgs {
 
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
 // N % 4 == 0 is enforced by the host wrapper. v = primary output, g = second output (GELU' of BIAS_GELU).
+// bp: the 4 bias values of columns n..n+3 already in registers (the staged epilogues load them once per wave: a per-fragment
+// global load + s_waitcnt vmcnt(0) serialises the VALU-bound epilogue), or nullptr to load them here.
+// alpha is honoured by the STORE / STORE_F32 / MUL epilogues only (the only callers that pass alpha != 1 are the LoRA
+// down-projections); the host wrapper rejects alpha != 1 for the others.
 template <int EPI, typename T>
-__device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4]) {
+__device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4], const float* bp = nullptr) {
   const size_t off = (size_t)m * e.ldo + n;
   const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
-  if (e.alpha != 1.0f) {
+  if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32 || EPI == GSL_EPI_MUL) {
+    if (e.alpha != 1.0f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
+      for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
+    }
+  }
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_PATCH) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = bp ? bp[i] : e.bias[n + i];
   }
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32) {
     if (e.bias) {
@@ -60,13 +71,13 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     Elem<float>::ld4(e.res + off, r);
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (v[i] + e.bias[n + i]) * dm[i] + r[i];
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
   } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
     float dm[4];
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float a = v[i] + e.bias[n + i];
+      const float a = v[i] + bq[i];
       float ga, gpa;
       if constexpr (sizeof(T) == 2) gelu_pair_fast(a, ga, gpa);      // bf16 speed mode
       else { ga = gelu_f(a); gpa = gelu_grad_f(a); }                  // f32 parity mode: exact erf
@@ -84,7 +95,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float base = (tok == 0) ? e.cls[n + i] : (v[i] + e.bias[n + i]);
+      const float base = (tok == 0) ? e.cls[n + i] : (v[i] + bq[i]);
       v[i] = (base + e.pos[(size_t)tok * e.N + n + i]) * dm[i];
     }
   }
@@ -114,11 +125,23 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
 constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-way at worst on the ds_write_b64
 // SEQ = false: both BIAS_GELU outputs staged side by side (2 x 64 rows per wave). SEQ = true: one 64-row region per wave,
 // the second output waits in registers and is staged after the first was copied out (half the LDS: two workgroups per CU).
-template <int EPI, int NI, bool SEQ = false>
-__device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane) {
+// bias_lds: this wave's 64 bias values staged in LDS by the caller (the 128-register SEQ kernel cannot afford 16 more VGPRs), or
+// nullptr: the lane's 16 values are loaded into registers once.
+template <int EPI, int NI, bool SEQ, bool FULL>
+__device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
+                                                          const float* bias_lds) {
   constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
+  float bj[4][4];        // this lane's bias values for its 4 column fragments
+  if (!bias_lds) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw + j * 16 + fc * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bj[j][i] = (e.bias && (FULL || n < e.N)) ? e.bias[n + i] : 0.f;
+    }
+  }
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
     uint2 held[4][4];   // second output, packed, when SEQ
@@ -129,7 +152,15 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
         const int i = ib + ii;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
         const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
-        if (m < e.M && n < e.N) epi_math<EPI, bf16_t>(e, m, n, v, g);
+        if (FULL || (m < e.M && n < e.N)) {
+          if (bias_lds) {
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias_lds + j * 16 + fc * 4);
+            const float bl[4] = {b4[0], b4[1], b4[2], b4[3]};
+            epi_math<EPI, bf16_t>(e, m, n, v, g, bl);
+          } else {
+            epi_math<EPI, bf16_t>(e, m, n, v, g, e.bias ? bj[j] : nullptr);
+          }
+        }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
         *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         if constexpr (NOUT == 2) {
@@ -150,7 +181,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
       for (int r = 0; r < 8; ++r) {
         const int row = r * 8 + crow;
         const int m = mw + ib * 16 + row, n = nw + cch * 8;
-        if (m < e.M && n < e.N) {
+        if (FULL || (m < e.M && n < e.N)) {
           const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
           bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
           if (dst) *reinterpret_cast<uint4*>(dst + (size_t)m * e.ldo + n) = val;
@@ -163,6 +194,17 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
         }
       }
     }
+  }
+}
+// tiles completely inside the matrix (all of them when M % 256 == 0, N % 128 == 0) skip every per-fragment bounds test
+template <int EPI, int NI, bool SEQ = false>
+__device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
+                                                     const float* bias_lds = nullptr) {
+  if constexpr (SEQ) {      // the 128-register kernel: two inlined copies of the epilogue make the allocator spill (measured: 81 VGPRs)
+    epilogue_staged_bf16_impl<EPI, NI, SEQ, false>(e, acc, cst, mw, nw, lane, bias_lds);
+  } else {
+    if (mw + NI * 16 <= e.M && nw + 64 <= e.N) epilogue_staged_bf16_impl<EPI, NI, SEQ, true>(e, acc, cst, mw, nw, lane, bias_lds);
+    else epilogue_staged_bf16_impl<EPI, NI, SEQ, false>(e, acc, cst, mw, nw, lane, bias_lds);
   }
 }
 // MUL epilogue (dX * GELU'): the aux operand is as large as the output. Loading it in fragment layout has the same partial-line
@@ -951,12 +993,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
   resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[SM9];
+  __shared__ __attribute__((aligned(16))) float bias_s[128];     // the tile's 128 bias values (read per fragment in the epilogue)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + 127) / 128;
   const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * 256, n0 = (tile % nbn) * 128;
+  if (tid < 128) bias_s[tid] = (e.bias && n0 + tid < e.N) ? e.bias[n0 + tid] : 0.f;      // visible after the K loop's barriers
   const int nk1 = K1 / BK9, nk = nk1 + K2 / BK9;
   const int lrow = lane >> 2, lc = lane & 3;
 
@@ -1021,7 +1065,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* _
   if constexpr (!epi_out_is_f32<EPI>()) {
     if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the ring: reuse it for C staging
-      epilogue_staged_bf16<EPI, 4, true>(e, acc, smem + wave * (64 * CLD), m0 + wm * 64, n0 + wn * 64, lane);
+      epilogue_staged_bf16<EPI, 4, true>(e, acc, smem + wave * (64 * CLD), m0 + wm * 64, n0 + wn * 64, lane, bias_s + wn * 64);
       return;
     }
   }
@@ -1086,9 +1130,11 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage, 8 = 256x256 8-phase ping-pong,
     // 9 = 256x128x32 ring with two workgroups per CU. Defaults measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md):
-    // the VALU-heavy BIAS_GELU epilogue wants the two-workgroup tile, N >= 512 the 256x256 tile, skinny N the ring.
+    // N >= 512 wants the 256x256 8-phase tile (also for the VALU-heavy BIAS_GELU epilogue since its bias values are preloaded and
+    // full tiles skip the bounds tests: 871 us vs 941 us for the two-workgroup tile 9), skinny N the ring.
     const char* ev = getenv("GSL_GEMM_VARIANT");
-    const int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (EPI == GSL_EPI_BIAS_GELU ? 9 : (e.N >= 512 ? 8 : 3)));
+    int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (e.N >= 512 ? 8 : 3));
+    if (EPI == GSL_EPI_BIAS_GELU && !ev && e.M >= 1024) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
     if (variant == 9) {
