@@ -38,6 +38,7 @@ struct EpiArgs {
   DropCfg drop;
   int M, N;
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
+  int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
 };
 
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int krot = e.krot ? (tile % nbn) % nk : 0;
   const int lrow = lane >> 3, lc = lane & 7;
   constexpr int HT = 128 * BK;     // half-tile, bf16 elements
 
@@ -656,9 +658,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     constexpr bool isA = PIECE & 1;
     constexpr int half = PIECE >> 1;
     bf16_t* dst = smem + (kt & 1) * STG + (isA ? 0 : BM4 * BK) + half * HT;
+    int kk = kt + krot;                 // K tile actually fetched in loop step kt
+    if (kk >= nk) kk -= nk;
     const bf16_t* base; int ld, k0;
-    if (kt < nk1) { base = isA ? A1 : W1; ld = isA ? lda1 : ldw1; k0 = kt * BK; }
-    else { base = isA ? A2 : W2; ld = isA ? lda2 : ldw2; k0 = (kt - nk1) * BK; }
+    if (kk < nk1) { base = isA ? A1 : W1; ld = isA ? lda1 : ldw1; k0 = kk * BK; }
+    else { base = isA ? A2 : W2; ld = isA ? lda2 : ldw2; k0 = (kk - nk1) * BK; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
@@ -1194,6 +1198,7 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
+  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -1228,6 +1233,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   e.alpha = 1.0f; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
+  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
