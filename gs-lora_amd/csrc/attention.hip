@@ -11,10 +11,10 @@
 //     in B-operand layout for the second matmul (Oᵀ = Vᵀ Pᵀ) — no LDS round trip for P.
 //   * the k-slot permutation trick: B-operand slot (g, idx) of the second MFMA holds key
 //     32*pair + 16*(idx/4) + 4*g + idx%4 — exactly what the C layout of two adjacent score tiles
-//     delivers — and the A operand (Vᵀ, from a transposed LDS image) is gathered with the same
-//     permutation (two ds_read_b64), so the contraction is unchanged.
-//   * backward is two kernels with no atomics: dQ (waves own query tiles; needs K, Kᵀ, V in LDS)
-//     and dK/dV (waves own key tiles; needs Q, Qᵀ, dO, dOᵀ in LDS); probabilities are recomputed
+//     delivers — and the A operand (Vᵀ) is gathered from the row-major V panel with the same
+//     permutation by two LDS transpose reads (ds_read_b64_tr_b16), so the contraction is unchanged.
+//   * backward is two kernels with no atomics: dQ (waves own query tiles; K and V panels in LDS)
+//     and dK/dV (waves own key tiles; Q and dO panels in LDS); probabilities are recomputed
 //     from the saved log-sum-exp (flash-style), delta = rowsum(dO∘O) is produced by the dQ kernel.
 // f32 path (parity mode): thread-per-row VALU kernels with LDS-broadcast panels; exact f32.
 #include <stdlib.h>
@@ -49,45 +49,24 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
     *reinterpret_cast<uint4*>(dst + t * KLD + c * 8) = v;
   }
 }
-// stage the same panel transposed: dst[d][t], leading dim VLD = TP + 8, zero columns >= T.
-// Each thread owns an 8 (keys) x 8 (d) block: eight 16-byte global loads, an in-register 8x8 transpose of the
-// packed bf16 pairs, eight 16-byte LDS stores. This replaces 64 two-byte scattered LDS writes per thread.
-template <int TP>
-__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long ld, int T) {
-  constexpr int VLD = TP + 8, NKB = TP / 8;
-  for (int idx = threadIdx.x; idx < NKB * 8; idx += blockDim.x) {
-    const int c = idx & 7, kb = idx >> 3;   // 8 lanes cover one 128-byte row: coalesced global loads (the LDS stores conflict, but are few)
-    uint32_t w[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = kb * 8 + i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
-      w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint32_t o[4];
-#pragma unroll
-      for (int p2 = 0; p2 < 4; ++p2) {
-        const uint32_t a = w[2 * p2][j >> 1], b = w[2 * p2 + 1][j >> 1];
-        o[p2] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-      }
-      *reinterpret_cast<uint4*>(dst + (c * 8 + j) * VLD + kb * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-  }
-}
-
 __device__ __forceinline__ bf16x8_t lds_frag_rm(const bf16_t* base, int row, int ks, int fc) {
   return *reinterpret_cast<const bf16x8_t*>(base + row * KLD + ks * 32 + fc * 8);
 }
-// A-operand from a transposed image: row r, k-slots (fc, idx) -> columns pair*32 + 16*(idx/4) + 4*fc + idx%4
-template <int VLD>
-__device__ __forceinline__ bf16x8_t lds_frag_tr(const bf16_t* base, int row, int pair, int fc) {
-  Frag f;
-  const bf16_t* p = base + row * VLD + pair * 32 + fc * 4;
-  f.h[0] = *reinterpret_cast<const uint2*>(p);
-  f.h[1] = *reinterpret_cast<const uint2*>(p + 16);
+// A operand X^T[dt*16 + fr][keys] in the k-slot permutation (slot (g, idx) = key 32*pair + 16*(idx/4) + 4*g + idx%4), gathered from the
+// ROW-MAJOR panel X[key][KLD] with gfx950's LDS transpose read (ds_read_b64_tr_b16).
+// Within a 16-lane group lane i supplies the address of 4 contiguous elements (row i/4, columns 4*(i%4)..) of a 4 x 16 block and lane
+// l receives column l%16 of that block (probed on MI355X, tools/probes/tr_read_probe.hip): with block rows = keys
+// 32*pair + 16*q + 4*g .. +3 (g = lane group, q = which of the two reads) lane l ends up with X[those keys][dt*16 + l%16] in k-slots
+// 4q..4q+3 — the permutation above. No transposed LDS image, no register-transposed staging pass
+// (that pass and the second copy cost 21 % of the backward: 1103 -> 870 us at B = 1024).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
+__device__ __forceinline__ bf16x8_t lds_frag_trr(const bf16_t* base, int dt, int pair, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const bf16_t* p = base + (pair * 32 + 4 * g + (i >> 2)) * KLD + dt * 16 + (i & 3) * 4;
+  union { v4s_t h[2]; bf16x8_t v; } f;
+  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(p));
+  f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(p + 16 * KLD));
   return f.v;
 }
 __device__ __forceinline__ bf16x8_t gl_frag(const bf16_t* rowptr, int ks, int fc) {
@@ -103,15 +82,15 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
 template <int NKT>
 __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int T, int H, float scale, int abl) {
-  constexpr int TP = NKT * 16, VLD = TP + 8;
+  constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * VLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
   if (abl != 2) {
     stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
-    stage_transposed<TP>(Vt, qb + 2 * H * HD, ld, T);
+    stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
   }
   __syncthreads();
   if (abl == 1) return;
@@ -169,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
     for (int dt = 0; dt < 4; ++dt) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_tr<VLD>(Vt, dt * 16 + fr, pr, fc), pf[pr].v, acc);
+      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(Vs, dt, pr, lane), pf[pr].v, acc);
       // acc[r] = O[q = fr][d = dt*16 + fc*4 + r]
       if (qr < T) store4bf(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + fc * 4, acc, inv);
     }
@@ -185,17 +164,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
                                                                int H, float scale, int abl) {
-  constexpr int TP = NKT * 16, VLD = TP + 8;
+  constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[HD * VLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
   if (abl != 2) {
     stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
     stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
-    stage_transposed<TP>(Kt, qb + H * HD, ld, T);
   }
   __syncthreads();
   if (abl == 1) return;
@@ -248,7 +225,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     for (int dt = 0; dt < 4; ++dt) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_tr<VLD>(Kt, dt * 16 + fr, pr, fc), dsf[pr].v, acc);
+      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(Ks, dt, pr, lane), dsf[pr].v, acc);
       if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, scale);
     }
     if (fc == 0 && qr < T) delta[((size_t)b * H + h) * T + qr] = dl;
@@ -262,11 +239,9 @@ template <int NKT>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl) {
-  constexpr int TP = NKT * 16, VLD = TP + 8;
+  constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Os[TP * KLD];   // dO row-major
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[HD * VLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Ot[HD * VLD];   // dO transposed
   __shared__ __attribute__((aligned(16))) float lse_s[TP];
   __shared__ __attribute__((aligned(16))) float del_s[TP];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -276,8 +251,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
   if (abl != 2) {
     stage_rowmajor<TP>(Qs, qb, ld, T);
     stage_rowmajor<TP>(Os, dob, ldo, T);
-    stage_transposed<TP>(Qt, qb, ld, T);
-    stage_transposed<TP>(Ot, dob, ldo, T);
   }
   for (int t = threadIdx.x; t < TP; t += blockDim.x) {
     lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;   // log2 units; padded queries -> p = 0
@@ -343,7 +316,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t ot = lds_frag_tr<VLD>(Ot, dt * 16 + fr, qp, fc), qtf = lds_frag_tr<VLD>(Qt, dt * 16 + fr, qp, fc);
+        const bf16x8_t ot = lds_frag_trr(Os, dt, qp, lane), qtf = lds_frag_trr(Qs, dt, qp, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           adv[t][dt] = mfma16(ot, pf[t].v, adv[t][dt]);     // dV^T[d][key]
