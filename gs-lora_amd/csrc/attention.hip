@@ -235,8 +235,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 // =====================================================================================
 // backward dK/dV (bf16): waves own key tiles
 // =====================================================================================
-template <int NKT>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+// NT = key tiles owned by a wave: 2 halves the LDS fragment traffic per MFMA (157 VGPRs, one workgroup per CU), 1 fits 128 VGPRs and
+// two workgroups per CU — the kernel is latency-bound, so occupancy wins (default for T > 64; GSL_ATTN_NT development knob).
+template <int NKT, int NT>
+__global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl) {
   constexpr int TP = NKT * 16;
@@ -262,28 +264,28 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
   const int nkt = (T + 15) / 16;
   const int nwaves = blockDim.x >> 6;
   const float c2 = scale * 1.4426950408889634f;
-  // Each wave owns TWO adjacent key tiles: every Q / dO / Q^T / dO^T fragment read from LDS feeds two MFMAs (one per
+  // NT = 2: each wave owns TWO adjacent key tiles: every Q / dO / Q^T / dO^T fragment read from LDS feeds two MFMAs (one per
   // key tile). The kernel is LDS-bandwidth-bound (1 KB of fragment reads per MFMA when a wave owns a single tile).
-  for (int kp = wave; kp * 2 < nkt; kp += nwaves) {
-    bf16x8_t kf[2][2], vf[2][2];
-    int kr[2];
+  for (int kp = wave; kp * NT < nkt; kp += nwaves) {
+    bf16x8_t kf[NT][2], vf[NT][2];
+    int kr[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      kr[t] = (kp * 2 + t) * 16 + fr;
+    for (int t = 0; t < NT; ++t) {
+      kr[t] = (kp * NT + t) * 16 + fr;
       const int krc = min(kr[t], T - 1);
       const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
       const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
       kf[t][0] = gl_frag(krow, 0, fc); kf[t][1] = gl_frag(krow, 1, fc);
       vf[t][0] = gl_frag(vrow, 0, fc); vf[t][1] = gl_frag(vrow, 1, fc);
     }
-    f32x4_t adk[2][4], adv[2][4];
+    f32x4_t adk[NT][4], adv[NT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { adk[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int qp = 0; qp < NKT / 2; ++qp) {
-      Frag pf[2], dsf[2];
+      Frag pf[NT], dsf[NT];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qt = 2 * qp + half;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
         const float4 d4 = *reinterpret_cast<const float4*>(&del_s[qt * 16 + fc * 4]);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
           f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
           sa = mfma16(q0, kf[t][0], sa);   // S[q = qt*16+fc*4+r][key = fr of tile t]
           sa = mfma16(q1, kf[t][1], sa);
@@ -318,14 +320,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8_t ot = lds_frag_trr(Os, dt, qp, lane), qtf = lds_frag_trr(Qs, dt, qp, lane);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
           adv[t][dt] = mfma16(ot, pf[t].v, adv[t][dt]);     // dV^T[d][key]
           adk[t][dt] = mfma16(qtf, dsf[t].v, adk[t][dt]);   // dK^T[d][key]
         }
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       if (kr[t] < T) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -600,10 +602,12 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     bf16_t* dq = (bf16_t*)dqkv;
     if (T <= 64) {
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
-      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
+      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
     } else {
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
-      hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<14>, grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
+      { const char* nt = getenv("GSL_ATTN_NT");     // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us
+        if (!nt || atoi(nt) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
+        else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 2>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl()); }
     }
   } else if (dtype == GSL_F32) {
     const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;
