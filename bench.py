@@ -25,6 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E, same guide
 FULL = dict(image_size=112, patch_size=8, dim=512, depth=6, heads=8, mlp_dim=2048, num_class=100, lora_rank=8)
 HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-4, BND=105.0, BND_pro=18.0, pro_f=0.01, pro_r=0.01)
 
@@ -152,6 +153,7 @@ def main():
         flops = sum(fl) / max(1, len(fl))
         M = prof["ffn1"][0][2] if prof["ffn1"] else 2 * B * 197
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        alg_bytes = int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)     # A + LoRA segment read, h + GELU' written (bf16)
         traffic = None
         try:   # HBM bytes per launch of the roofline kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -167,10 +169,14 @@ def main():
             "config": {"workload": f"ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8, per-GPU batch {B} remain + "
                                    f"{B} forget (112x112 synthetic), dropout {args.dropout}, prototype term on, FusedAdamW",
                        "global_batch": world * 2 * B, "tokens_per_image": 197, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gsl_gemm_nt<BIAS_GELU> (fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout, fwd)",
-                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            # The fused FFN1 GEMM writes TWO [M, 2048] bf16 outputs (h and GELU'): 430 GFLOP over 1.885 GB of algorithmic bytes is
+            # 228 FLOP/B, below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B) -> HBM is the roof that bounds it.
+            "roofline": {"bound": "hbm", "kernel": "gsl_gemm_nt<BIAS_GELU> (fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout, fwd)",
+                         "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if avg_ms > 0 else 0.0,
                          "launches_timed": len(durs), "rows_per_launch": M, "avg_ms": round(avg_ms, 4), "traffic": traffic,
-                         "algorithmic_bytes": int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)},
+                         "algorithmic_bytes": alg_bytes, "arithmetic_intensity_flop_per_byte": round(flops / alg_bytes, 1),
+                         "mfma_tflops": round(ach, 2), "mfma_frac_of_peak": round(ach / PEAK_BF16_TFLOPS, 4)},
             "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
             "hip_graph": bool(args.graph and world == 1),

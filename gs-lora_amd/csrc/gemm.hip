@@ -38,6 +38,7 @@ struct EpiArgs {
   DropCfg drop;
   int M, N;
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
+  int stmode;  // output store flavour of the staged bf16 epilogue (development knob GSL_STORE_MODE, see store_stream16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
 };
 
@@ -118,6 +119,16 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   }
 }
 
+// 16-byte output store. mode 0: plain (write-back, the line stays in the XCD's L2), 1: non-temporal hint, 2: sc1 (the line is dropped
+// from L2): the GEMM outputs are streamed once and are 4x larger than the operand panels they would otherwise evict.
+__device__ __forceinline__ void store_stream16(void* p, const uint4 v, int mode) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t w = {v.x, v.y, v.z, v.w};
+  if (mode == 1) __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
+  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+  else *reinterpret_cast<u32x4_t*>(p) = w;
+}
+
 // bf16-output epilogue of one wave's (NI*16 rows) x 64 columns sub-tile, staged through a wave-private LDS region so
 // that global stores are 16 bytes per lane over FULL 128-byte rows (8 lanes per row, 8 rows per instruction).
 // Measured: the fragment-layout 8-byte stores touch 16 partial (32-byte) lines per instruction and bound the K = 512
@@ -185,11 +196,11 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         if (FULL || (m < e.M && n < e.N)) {
           const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
           bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
-          if (dst) *reinterpret_cast<uint4*>(dst + (size_t)m * e.ldo + n) = val;
+          if (dst) store_stream16(dst + (size_t)m * e.ldo + n, val, e.stmode);
           if constexpr (NOUT == 2 && !SEQ) {
             if (e.out2) {
               const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n) = val2;
+              store_stream16(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n, val2, e.stmode);
             }
           }
         }
@@ -248,7 +259,7 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
         const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
         o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
       }
-      if (m < e.M && n < e.N) *reinterpret_cast<uint4*>(out + (size_t)m * e.ldo + n) = make_uint4(o[0], o[1], o[2], o[3]);
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), e.stmode);
     }
   }
 }
@@ -293,7 +304,7 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
         f32x4_t o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
-        if (m < e.M && n < e.N) *reinterpret_cast<f32x4_t*>(out + (size_t)m * e.ldo + n) = o;
+        if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
       }
     }
   }
@@ -1199,6 +1210,7 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
+  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -1234,6 +1246,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
+  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
