@@ -151,6 +151,95 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
   }
 }
 
+// ---- MFMA form of the partial sums (bf16 operands, N % 256 == 0): G^T-free contraction over the ROW index.
+// The contraction runs over m, the slow index of both row-major operands, so the fragments cannot come straight from global
+// memory; a [32 rows][256 cols] slab of Y and the matching [32][16] slab of U go through LDS (padded rows) and are gathered as
+// MFMA operands with gfx950's LDS transpose read (ds_read_b64_tr_b16: lane l of a 16-lane group receives column l of a 4 x 16
+// block, see attention.hip) — A = Y^T fragment (row = column n of Y), B = U fragment (column j), k-slots = the same 8 rows for both.
+// One block = 4 waves x 64 columns; global loads of the next slab are in flight during the 4 MFMAs per wave of the current one.
+// The VALU kernel above needs 8*R FMAs per row and thread: at r = 16 (ViT-B/16) it is VALU-bound, and at N = 512 it reaches only
+// 3 TB/s; this one is bound by the Y stream alone. Writes the same part[split][n][R] layout (the reductions below are shared).
+typedef short lg_v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lg_v4s_t* lg_lds_v4s_p;
+typedef __attribute__((ext_vector_type(8))) __bf16 lg_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float lg_f32x4_t;
+constexpr int LGM_CN = 256, LGM_YLD = LGM_CN + 16, LGM_ULD = 32, LGM_K = 32;
+
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ U, int ldu,
+                                                             float* __restrict__ part, int M, int N, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) bf16_t ys[2][LGM_K * LGM_YLD];
+  __shared__ __attribute__((aligned(16))) bf16_t us[2][LGM_K * LGM_ULD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * LGM_CN, split = blockIdx.y;
+  const int r0 = split * rows_per_split, r1 = min(M, r0 + rows_per_split);
+  const int lc = tid & 31, lr = tid >> 5;
+  uint4 yreg[4], ureg = make_uint4(0, 0, 0, 0);
+  auto gload = [&](int rb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rb + lr + 8 * i;
+      yreg[i] = (r < r1) ? *reinterpret_cast<const uint4*>(Y + (size_t)r * N + n0 + lc * 8) : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 64) {
+      const int r = rb + (tid >> 1);
+      ureg = (r < r1) ? *reinterpret_cast<const uint4*>(U + (size_t)r * ldu + (tid & 1) * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&ys[buf][(lr + 8 * i) * LGM_YLD + lc * 8]) = yreg[i];
+    if (tid < 64) *reinterpret_cast<uint4*>(&us[buf][(tid >> 1) * LGM_ULD + (tid & 1) * 8]) = ureg;
+  };
+  lg_f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = lg_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, i16 = lane & 15;
+  const int trow = 4 * g + (i16 >> 2), tcol = (i16 & 3) * 4;       // this lane's piece of a 4 x 16 block (transpose-read address)
+  gload(r0);
+  lstore(0);
+  __syncthreads();
+  int it = 0;
+  for (int rb = r0; rb < r1; rb += LGM_K, ++it) {
+    const int buf = it & 1;
+    const bool more = rb + LGM_K < r1;
+    if (more) gload(rb + LGM_K);
+    union { lg_v4s_t h[2]; lg_bf16x8_t v; } bf;
+    bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(&us[buf][trow * LGM_ULD + tcol]));
+    bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(&us[buf][(trow + 16) * LGM_ULD + tcol]));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      union { lg_v4s_t h[2]; lg_bf16x8_t v; } af;
+      const bf16_t* p = &ys[buf][trow * LGM_YLD + wave * 64 + t * 16 + tcol];
+      af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(p));
+      af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(p + 16 * LGM_YLD));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc[t], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // acc[t][r] = G[n = n0 + wave*64 + t*16 + 4g + r][j = lane & 15]
+  if (i16 < R) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wave * 64 + t * 16 + 4 * g + r;
+        part[((size_t)split * N + n) * R + i16] = acc[t][r];
+      }
+  }
+}
+static inline void lgm_plan(int M, int N, int& bx, int& nsplit, int& rps) {
+  bx = N / LGM_CN;
+  int target = 1024 / bx;                       // ~4 blocks per CU in total
+  if (target < 1) target = 1;
+  int steps = (M + LGM_K - 1) / LGM_K;          // 32-row slabs
+  nsplit = steps < target ? steps : target;
+  rps = ((steps + nsplit - 1) / nsplit) * LGM_K;
+  nsplit = (M + rps - 1) / rps;
+}
+static inline bool lgm_usable(int M, int N, int ldu, int dtype) { return dtype == GSL_BF16 && (N % LGM_CN) == 0 && ldu >= 16 && M >= 64; }
+
 // level 1: thread (idx, sb) sums LG_FAN consecutive splits  -> part2[sb][idx]
 __global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ part2,
                                                                 int NR, int nsplit) {
@@ -197,6 +286,12 @@ extern "C" long gsl_lora_grad_ws_elems(int M, int N, int r) {
     const long slabs = (long)nsplit + (nsplit + LG_FAN - 1) / LG_FAN;
     if (slabs > best) best = slabs;
   }
+  if ((N % LGM_CN) == 0) {
+    int bx, nsplit, rps;
+    lgm_plan(M, N, bx, nsplit, rps);
+    const long slabs = (long)nsplit + (nsplit + LG_FAN - 1) / LG_FAN;
+    if (slabs > best) best = slabs;
+  }
   return best * (long)N * R;
 }
 
@@ -210,6 +305,23 @@ extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, lo
   hipStream_t st = as_stream(s);
   const int R = (r <= 8) ? 8 : 16;
   int CG, bx, nsplit, rps;
+  { const char* ev = getenv("GSL_LORA_GRAD_MFMA");      // development knob: 0 forces the VALU kernel
+    const bool want = !ev || atoi(ev) != 0;
+    if (want && lgm_usable(M, N, ldu, dtype) && (reinterpret_cast<uintptr_t>(U) % 16) == 0 && (reinterpret_cast<uintptr_t>(Y) % 16) == 0 &&
+        ((size_t)ldu * 2) % 16 == 0) {
+      lgm_plan(M, N, bx, nsplit, rps);
+      if (R == 8) hipLaunchKernelGGL(lora_grad_mfma_kernel<8>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, (const bf16_t*)U, ldu, ws, M, N, rps);
+      else hipLaunchKernelGGL(lora_grad_mfma_kernel<16>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, (const bf16_t*)U, ldu, ws, M, N, rps);
+      int rc0 = check_launch("gsl_lora_grad(mfma partial)");
+      if (rc0) return rc0;
+      float* part2m = ws + (size_t)nsplit * N * R;
+      const int totm = N * R, nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
+      hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((totm + 255) / 256, nslabm), dim3(256), 0, st, ws, part2m, totm, nsplit);
+      if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
+      else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
+      return check_launch("gsl_lora_grad(reduce)");
+    }
+  }
   lg_plan(M, N, V, R, CG, bx, nsplit, rps);
   const int RP = 256 / CG;
   const size_t red_bytes = (size_t)(RP - 1) * CG * V * R * sizeof(float);
