@@ -264,6 +264,29 @@ __global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __r
   *g = accumulate ? (*g + s) : s;
 }
 
+// single-launch, fixed-order reduction of the MFMA kernel's partials: a block owns 64 outputs, its 4 waves each sum every 4th
+// split, the 4 sub-sums are combined through LDS in wave order (deterministic), output strides (+ accumulate) applied on the way out
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ part, float* G, long gsn, long gsj, int N, int r,
+                                                               int nsplit, int accumulate) {
+  __shared__ float sm[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + l, NR = N * R;
+  float s = 0.f;
+  if (idx < NR)
+    for (int sp = w; sp < nsplit; sp += 4) s += part[(size_t)sp * NR + idx];
+  sm[w][l] = s;
+  __syncthreads();
+  if (w == 0 && idx < NR) {
+    const float t = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    const int n = idx / R, j = idx % R;
+    if (j < r) {
+      float* g = G + (size_t)n * gsn + (size_t)j * gsj;
+      *g = accumulate ? (*g + t) : t;
+    }
+  }
+}
+
 static inline void lg_plan(int M, int N, int V, int R, int& CG, int& bx, int& nsplit, int& rps) {
   const int ncol = N / V;
   CG = ncol >= 256 ? 256 : ((ncol > 64 || R > 8) ? 128 : 64);   // keeps the phase-combine LDS <= 48 KB
@@ -314,8 +337,14 @@ extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, lo
       else hipLaunchKernelGGL(lora_grad_mfma_kernel<16>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, (const bf16_t*)U, ldu, ws, M, N, rps);
       int rc0 = check_launch("gsl_lora_grad(mfma partial)");
       if (rc0) return rc0;
+      const int totm = N * R;
+      if (nsplit <= 160 && totm >= 8192) {     // few splits, many outputs: one launch (measured 166 -> 162 us at N = 2048; at N = 512 the two-level form wins)
+        if (R == 8) hipLaunchKernelGGL(lora_grad_reduce_kernel<8>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+        else hipLaunchKernelGGL(lora_grad_reduce_kernel<16>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+        return check_launch("gsl_lora_grad(reduce)");
+      }
       float* part2m = ws + (size_t)nsplit * N * R;
-      const int totm = N * R, nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
+      const int nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
       hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((totm + 255) / 256, nslabm), dim3(256), 0, st, ws, part2m, totm, nsplit);
       if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
       else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
