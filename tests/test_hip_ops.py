@@ -362,3 +362,78 @@ def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
     ops.gemm_nt(c(A), c(W), out2, epilogue=L.EPI_STORE_F32, A2=t2, W2=c(Q64))
     ops.gemm_nt_lora(c(A), c(W), c(P), c(Q), s, tout, outf, epilogue=L.EPI_BIAS_RES_F32, bias=torch.zeros(N).cuda(), res=torch.zeros(M, N).cuda())
     assert relerr(outf.cpu(), out2.cpu()) < 2e-3
+
+
+# ---- entry points added for HIP-graph replay and launch-count reduction ---------------------------------------------------
+def test_adamw_dev_bit_identical_to_value_form(ops):
+    """gsl_adamw_flat_dev (step count / lr read from device memory) == gsl_adamw_flat for the same (step, lr)."""
+    n = 10_001
+    p0, g, m0, v0 = (rnd(n, seed=s).cuda() for s in (1, 2, 3, 4))
+    v0 = v0.abs()
+    for step, lr in ((1, 1e-2), (7, 5e-3), (1234, 1.24647e-5)):
+        pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+        pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+        ops.adamw_flat(pa, g, ma, va, lr, 0.9, 0.999, 1e-8, 0.05, step)
+        ops.adamw_flat_dev(pb, g, mb, vb, torch.tensor([lr], device="cuda", dtype=torch.float32), 0.9, 0.999, 1e-8, 0.05,
+                           torch.tensor([step], device="cuda", dtype=torch.int64))
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), step
+
+
+def test_dropout_seed_on_device_equals_seed_by_value(ops):
+    """bit 31 of `site` turns `seed` into a device pointer: same masks, same outputs — for the GEMM epilogues, LayerNorm-bwd and the
+    mask helper."""
+    from gslora_hip import _lib as L
+    seed = (0x5EED << 20) + 77
+    sdev = torch.tensor([seed], device="cuda", dtype=torch.int64)
+    k1 = ops.dropout_mask(4096, 0.1, seed, 9, "cuda")
+    k2 = ops.dropout_mask(4096, 0.1, sdev.data_ptr(), 9 | L.SEED_ON_DEVICE, "cuda")
+    assert torch.equal(k1, k2) and 0.05 < 1.0 - k1.float().mean().item() < 0.15
+    M, N, K = 1280, 512, 256
+    A = rnd(M, K, seed=5).cuda().bfloat16(); W = (rnd(N, K, seed=6) * K ** -0.5).cuda().bfloat16()
+    bias, res = rnd(N, seed=7).cuda(), rnd(M, N, seed=8).cuda()
+    outs = []
+    for sd, st in ((seed, 3), (sdev.data_ptr(), 3 | L.SEED_ON_DEVICE)):
+        o = torch.empty(M, N, device="cuda")
+        ops.gemm_nt(A, W, o, epilogue=L.EPI_BIAS_RES_F32, bias=bias, res=res, p_drop=0.1, seed=sd, site=st)
+        h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); gp = torch.empty_like(h)
+        ops.gemm_nt(A, W, h, epilogue=L.EPI_BIAS_GELU, bias=bias, out2=gp, p_drop=0.1, seed=sd, site=st)
+        outs.append((o, h, gp))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0], res + (A.float() @ W.float().t() + bias))      # dropout really is on
+    D = 512
+    dy = rnd(64, D, seed=9).cuda().bfloat16(); x = rnd(64, D, seed=10).cuda(); dres = rnd(64, D, seed=11).cuda()
+    gam = rnd(D, seed=12).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, D, 64, D, gam, gam, 1e-5, torch.bfloat16)
+    r1 = ops.layernorm_bwd(dy, x, D, gam, mean, rstd, dres, p_drop=0.1, seed=seed, site=5)
+    r2 = ops.layernorm_bwd(dy, x, D, gam, mean, rstd, dres, p_drop=0.1, seed=sdev.data_ptr(), site=5 | L.SEED_ON_DEVICE)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+
+
+def test_pack_pad_batch_equals_single_packs(ops):
+    srcs = [rnd(8, 512, seed=1).cuda(), rnd(2048, 8, seed=2).cuda(), rnd(16, 768, seed=3).cuda()]
+    geoms = [(512, 1, 8, 512, 64, 512), (8, 1, 2048, 8, 2048, 64), (1, 768, 768, 16, 768, 32)]       # si, sj, rows, cols, rows_out, ld_out
+    singles = [ops.pack_pad(s_, si, sj, r_, c_, ro, ld, torch.bfloat16) for s_, (si, sj, r_, c_, ro, ld) in zip(srcs, geoms)]
+    outs = [torch.full_like(t, 7.0) for t in singles]
+    table, mx = ops.pack_desc_table([(s_, si, sj, r_, c_, 1.0, o) for s_, (si, sj, r_, c_, ro, ld), o in zip(srcs, geoms, outs)], "cuda")
+    ops.pack_pad_batch(table, len(outs), mx, torch.bfloat16)
+    for a, b in zip(singles, outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,r", [(3000, 512, 8), (4096, 768, 16), (1000, 256, 4)])
+def test_lora_grad_mfma_matches_valu_kernel(ops, M, N, r, monkeypatch):
+    """The matrix-core reduction (N % 256 == 0, bf16) against the VALU kernel and an fp32 reference, ragged last slab included."""
+    Y = rnd(M, N, seed=21).cuda().bfloat16()
+    U = torch.zeros(M, 64, device="cuda", dtype=torch.bfloat16)
+    U[:, :r] = rnd(M, r, seed=22).cuda().bfloat16()
+    ref = Y.float().cpu().t() @ U[:, :r].float().cpu()
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GSL_LORA_GRAD_MFMA", mode)
+        G = torch.zeros(N, r, device="cuda")
+        ops.lora_grad(Y, U, G, r, 1, r, accumulate=False)
+        ops.lora_grad(Y, U, G, r, 1, r, accumulate=True)
+        got[mode] = G.cpu() / 2
+        assert relerr(got[mode], ref) < 2e-5, mode
+    assert relerr(got["1"], got["0"]) < 2e-6
