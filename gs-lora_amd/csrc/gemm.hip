@@ -5,14 +5,15 @@
 // [x | s·(x Aᵀ)] · [W | B]ᵀ  ==  x Wᵀ + s·(x Aᵀ) Bᵀ, so the adapter costs one extra K tile on the
 // matrix cores instead of two skinny GEMMs and an elementwise add.
 //
-// bf16 path (v_mfma_f32_16x16x32_bf16, f32 accumulate), three tile shapes sharing one epilogue:
-//   128x128x64, 4 waves, one 32 KB LDS stage (small M); 256x128x64, 8 waves, 3-stage ring with counted vmcnt + raw
-//   s_barrier; 256x256x64, 8 waves of 128x64, 2 stages. Operands are swapped in the MFMA (mfma(W, A)) so each lane owns 4
-//   consecutive output columns of one row -> 8/16-byte epilogue stores. Global->LDS staging is the LDS-DMA
-//   (global_load_lds_dwordx4); the 16-byte-chunk XOR swizzle (chunk ^= row & 7) is applied on the DMA source address
-//   and again on the ds_read_b128 fragment read (0 bank conflicts measured). Block ids are remapped so the N-tiles of
-//   one A row-panel run on one XCD. What was tried and measured (register staging, BK=32 4-stage ring, L2 prefetch wave,
-//   main-loop ablation, PMC) is in profiles/r01_gemm_ab.md.
+// bf16 path (v_mfma_f32_16x16x32_bf16, f32 accumulate). Production tiles: 256x256x64 with the 8-phase ping-pong schedule
+//   (gemm_bf16_p8_kernel, N >= 512; also the in-kernel-LoRA form), 256x128x64 3-stage ring (skinny N), 128x128x64 single stage
+//   (M < 1024). Kept as measured alternatives behind GSL_GEMM_VARIANT: the single-phase 256x256 kernels (4) and the 256x128x32
+//   two-workgroups-per-CU tile (9). Operands are swapped in the MFMA (mfma(W, A)) so each lane owns 4 consecutive output columns
+//   of one row. Global->LDS staging is the LDS-DMA (global_load_lds_dwordx4); the 16-byte-chunk XOR swizzle (chunk ^= row & 7) is
+//   applied on the DMA source address and again on the ds_read_b128 fragment read (0 bank conflicts measured). Block ids are
+//   remapped so the N-tiles of one A row-panel run on one XCD, and N-tile j starts its K loop at K tile j. Epilogue operands
+//   (outputs, residual, GELU') go through a wave-private LDS staging area and touch HBM as full rows; outputs use non-temporal
+//   stores. What was tried and measured is in profiles/r01_gemm_ab.md and DESIGN.md section 4.
 // f32 path (parity mode): 64x64x16 tile, 4x4 outputs per thread, sequential fmaf over k.
 #include <stdlib.h>
 
