@@ -27,7 +27,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int HD = 64;    // head dim
-constexpr int KLD = 72;   // row-major LDS leading dim in bf16 elements (144 B rows: conflict-light b128 reads)
+// Row-major LDS panels are read two ways: ds_read_b128 row fragments (16-lane groups = 16 consecutive rows, 4 banks each) and
+// ds_read_b64_tr_b16 transpose reads (32-lane halves = 8 consecutive rows, 8 banks each). 160-byte rows (40 banks) make the 8 rows
+// of a transpose read land on 8 disjoint bank octets; the row reads would then collide for rows r and r+8, so the 16-byte chunk
+// index is XOR-ed with bit 3 of the row (all four rows of a transpose block share that bit, the block just swaps its two chunks).
+// PMC before (144-byte rows, no swizzle): SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE in all three kernels.
+constexpr int KLD = 80;
+__device__ __forceinline__ int lds_off(int row, int col) {      // element offset of (row, col) in a swizzled panel; col % 8 preserved
+  return row * KLD + (((col >> 3) ^ ((row >> 3) & 1)) << 3) + (col & 7);
+}
 
 union Frag {
   uint4 u;
@@ -46,11 +54,11 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
     const int t = idx >> 3, c = idx & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (t < T) v = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + c * 8);
-    *reinterpret_cast<uint4*>(dst + t * KLD + c * 8) = v;
+    *reinterpret_cast<uint4*>(dst + lds_off(t, c * 8)) = v;
   }
 }
 __device__ __forceinline__ bf16x8_t lds_frag_rm(const bf16_t* base, int row, int ks, int fc) {
-  return *reinterpret_cast<const bf16x8_t*>(base + row * KLD + ks * 32 + fc * 8);
+  return *reinterpret_cast<const bf16x8_t*>(base + lds_off(row, ks * 32 + fc * 8));
 }
 // A operand X^T[dt*16 + fr][keys] in the k-slot permutation (slot (g, idx) = key 32*pair + 16*(idx/4) + 4*g + idx%4), gathered from the
 // ROW-MAJOR panel X[key][KLD] with gfx950's LDS transpose read (ds_read_b64_tr_b16).
@@ -63,10 +71,10 @@ typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
 __device__ __forceinline__ bf16x8_t lds_frag_trr(const bf16_t* base, int dt, int pair, int lane) {
   const int g = lane >> 4, i = lane & 15;
-  const bf16_t* p = base + (pair * 32 + 4 * g + (i >> 2)) * KLD + dt * 16 + (i & 3) * 4;
+  const int row = pair * 32 + 4 * g + (i >> 2), col = dt * 16 + (i & 3) * 4;
   union { v4s_t h[2]; bf16x8_t v; } f;
-  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(p));
-  f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(p + 16 * KLD));
+  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(base + lds_off(row, col)));
+  f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(base + lds_off(row + 16, col)));
   return f.v;
 }
 __device__ __forceinline__ bf16x8_t gl_frag(const bf16_t* rowptr, int ks, int fc) {
@@ -88,21 +96,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  bf16x8_t qn0, qn1;   // Q fragments of the NEXT query tile: their global-load latency hides under this tile's work
+  {                    // (the first tile's are issued before the panel staging and land under it)
+    const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ld;
+    qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
+  }
   if (abl != 2) {
     stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
     stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
   }
   __syncthreads();
   if (abl == 1) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   const int ktf = T >> 4;      // key tiles below this index are completely valid
   const int nwaves = blockDim.x >> 6;
-  bf16x8_t qn0, qn1;   // Q fragments of the NEXT query tile: their global-load latency hides under this tile's work
-  {
-    const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ld;
-    qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
-  }
   for (int qt = wave; qt < nqt; qt += nwaves) {
     asm volatile("" ::: "memory");   // keep the K / V^T fragment reads inside the loop (LICM would pin 224 VGPRs)
     const int qr = qt * 16 + fr;
@@ -170,26 +178,34 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nwaves = blockDim.x >> 6;
+  // this wave's first query tile: Q / dO / O fragments come straight from global memory; issued before the panel staging so that
+  // their latency lands under it (a wave owns at most two tiles when T = 197)
+  bf16x8_t qf0, qf1;
+  Frag dof0, dof1, of0, of1;
+  auto load_tile = [&](int qt) {
+    const int qrc = min(qt * 16 + fr, T - 1);
+    const bf16_t* qrow = qb + (size_t)qrc * ld;
+    const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
+    const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
+    qf0 = gl_frag(qrow, 0, fc); qf1 = gl_frag(qrow, 1, fc);
+    dof0.v = gl_frag(dorow, 0, fc); dof1.v = gl_frag(dorow, 1, fc);
+    of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
+  };
+  load_tile(wave);
   if (abl != 2) {
     stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
     stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
   }
   __syncthreads();
   if (abl == 1) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nqt = (T + 15) / 16;
   const int ktf = T >> 4;      // key tiles below this index are completely valid
-  const int nwaves = blockDim.x >> 6;
   for (int qt = wave; qt < nqt; qt += nwaves) {
     asm volatile("" ::: "memory");   // 8 waves per block: keep the fragment reads in the loop (<= 256 registers)
     const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
-    const bf16_t* qrow = qb + (size_t)qrc * ld;
-    const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
-    const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
-    const bf16x8_t qf0 = gl_frag(qrow, 0, fc), qf1 = gl_frag(qrow, 1, fc);
-    Frag dof0, dof1, of0, of1;
-    dof0.v = gl_frag(dorow, 0, fc); dof1.v = gl_frag(dorow, 1, fc);
-    of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
+    if (qt != wave) load_tile(qt);
     float dl = 0.f;
     {
       const uint32_t a[8] = {dof0.u.x, dof0.u.y, dof0.u.z, dof0.u.w, dof1.u.x, dof1.u.y, dof1.u.z, dof1.u.w};
@@ -250,6 +266,23 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
   const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nwaves = blockDim.x >> 6;
+  // K / V fragments of the wave's key tiles come straight from global memory: the first group is issued before the panel staging
+  bf16x8_t kf[NT][2], vf[NT][2];
+  int kr[NT];
+  auto load_keys = [&](int kp) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      kr[t] = (kp * NT + t) * 16 + fr;
+      const int krc = min(kr[t], T - 1);
+      const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
+      const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+      kf[t][0] = gl_frag(krow, 0, fc); kf[t][1] = gl_frag(krow, 1, fc);
+      vf[t][0] = gl_frag(vrow, 0, fc); vf[t][1] = gl_frag(vrow, 1, fc);
+    }
+  };
+  load_keys(wave);
   if (abl != 2) {
     stage_rowmajor<TP>(Qs, qb, ld, T);
     stage_rowmajor<TP>(Os, dob, ldo, T);
@@ -260,24 +293,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
   }
   __syncthreads();
   if (abl == 1) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nkt = (T + 15) / 16;
-  const int nwaves = blockDim.x >> 6;
   const float c2 = scale * 1.4426950408889634f;
   // NT = 2: each wave owns TWO adjacent key tiles: every Q / dO / Q^T / dO^T fragment read from LDS feeds two MFMAs (one per
   // key tile). The kernel is LDS-bandwidth-bound (1 KB of fragment reads per MFMA when a wave owns a single tile).
   for (int kp = wave; kp * NT < nkt; kp += nwaves) {
-    bf16x8_t kf[NT][2], vf[NT][2];
-    int kr[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      kr[t] = (kp * NT + t) * 16 + fr;
-      const int krc = min(kr[t], T - 1);
-      const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
-      const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
-      kf[t][0] = gl_frag(krow, 0, fc); kf[t][1] = gl_frag(krow, 1, fc);
-      vf[t][0] = gl_frag(vrow, 0, fc); vf[t][1] = gl_frag(vrow, 1, fc);
-    }
+    if (kp != wave) load_keys(kp);
     f32x4_t adk[NT][4], adv[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
