@@ -132,11 +132,15 @@ def main():
         step()
     fence()
     ops.PROFILE = {"ffn1": []}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step HIP events (no sync inside the timed region)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         pack = step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -180,6 +184,8 @@ def main():
             "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
             "hip_graph": bool(args.graph and world == 1),
+            "ms_per_step_events": {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
+                                   "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
