@@ -1149,8 +1149,11 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     // N >= 512 wants the 256x256 8-phase tile (also for the VALU-heavy BIAS_GELU epilogue since its bias values are preloaded and
     // full tiles skip the bounds tests: 871 us vs 941 us for the two-workgroup tile 9), skinny N the ring.
     const char* ev = getenv("GSL_GEMM_VARIANT");
-    int variant = ev ? atoi(ev) : (e.M < 1024 ? 1 : (e.N >= 512 ? 8 : 3));
-    if (EPI == GSL_EPI_BIAS_GELU && !ev && e.M >= 1024) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
+    // fewer than 128 tiles of 256x256 cannot fill the 256 CUs: the 128x128 kernel (4x the workgroups) wins there (measured at M = 1576:
+    // 15-44 us vs 19-58 us per GEMM); from ~150 tiles on the 8-phase kernel is ahead.
+    const long tiles256 = (long)((e.M + 255) / 256) * ((e.N + 255) / 256);
+    int variant = ev ? atoi(ev) : ((e.M < 1024 || tiles256 < 128) ? 1 : (e.N >= 512 ? 8 : 3));
+    if (EPI == GSL_EPI_BIAS_GELU && !ev && variant == 8) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
     if (variant == 9) {
