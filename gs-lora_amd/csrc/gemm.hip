@@ -171,7 +171,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
             const float bl[4] = {b4[0], b4[1], b4[2], b4[3]};
             epi_math<EPI, bf16_t>(e, m, n, v, g, bl);
           } else {
-            epi_math<EPI, bf16_t>(e, m, n, v, g, e.bias ? bj[j] : nullptr);
+            epi_math<EPI, bf16_t>(e, m, n, v, g, bj[j]);      // (a pointer select here would push the arrays into scratch memory)
           }
         }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
