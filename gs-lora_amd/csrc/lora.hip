@@ -56,7 +56,7 @@ template <> struct LgRaw<float> {
 // block = 256 threads = CG column groups x RP row phases (RP = 256 / CG in {1,2,4}); the RP phases walk
 // interleaved rows of the block's row range and are combined through LDS in a fixed order.
 template <typename T, int R>
-__global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restrict__ Y, const T* __restrict__ U, int ldu,
+__global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restrict__ Y, long ldy, const T* __restrict__ U, int ldu,
                                                                 float* __restrict__ part, int M, int N, int rows_per_split,
                                                                 int CG) {
   constexpr int V = LgVec<T>::V;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
 #pragma unroll
       for (int k = 0; k < LGF; ++k) {
         const int r = min(phase + k * RP, nr - 1);
-        cur[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * N);
+        cur[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * ldy);
       }
     }
     __syncthreads();
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
 #pragma unroll
         for (int k = 0; k < LGF; ++k) {     // prefetch the next batch (clamped rows: harmless re-reads at the tail)
           const int r = min(rr + (LGF + k) * RP, nr - 1);
-          nxt[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * N);
+          nxt[k] = *reinterpret_cast<const raw_t*>(ycol + (size_t)(rb + r) * ldy);
         }
 #pragma unroll
         for (int k = 0; k < LGF; ++k) {
@@ -166,7 +166,7 @@ typedef __attribute__((ext_vector_type(4))) float lg_f32x4_t;
 constexpr int LGM_CN = 256, LGM_YLD = LGM_CN + 16, LGM_ULD = 32, LGM_K = 32;
 
 template <int R>
-__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ U, int ldu,
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
                                                              float* __restrict__ part, int M, int N, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) bf16_t ys[2][LGM_K * LGM_YLD];
   __shared__ __attribute__((aligned(16))) bf16_t us[2][LGM_K * LGM_ULD];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rb + lr + 8 * i;
-      yreg[i] = (r < r1) ? *reinterpret_cast<const uint4*>(Y + (size_t)r * N + n0 + lc * 8) : make_uint4(0, 0, 0, 0);
+      yreg[i] = (r < r1) ? *reinterpret_cast<const uint4*>(Y + (size_t)r * ldy + n0 + lc * 8) : make_uint4(0, 0, 0, 0);
     }
     if (tid < 64) {
       const int r = rb + (tid >> 1);
@@ -318,9 +318,9 @@ extern "C" long gsl_lora_grad_ws_elems(int M, int N, int r) {
   return best * (long)N * R;
 }
 
-extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj, int M, int N, int r,
+extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj, int M, int N, int r,
                              int dtype, int accumulate, float* ws, gsl_stream_t s) {
-  GSL_CHECK_ARG(Y && U && G && ws && M > 0 && N > 0, "null/size");
+  GSL_CHECK_ARG(Y && U && G && ws && M > 0 && N > 0 && ldy >= N, "null/size");
   GSL_CHECK_ARG(r >= 1 && r <= 16 && ldu >= 16 && (ldu % 8) == 0, "r in [1,16], ldu >= 16 (zero-padded)");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
   const int V = (dtype == GSL_BF16) ? 8 : 4;
@@ -331,10 +331,10 @@ extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, lo
   { const char* ev = getenv("GSL_LORA_GRAD_MFMA");      // development knob: 0 forces the VALU kernel
     const bool want = !ev || atoi(ev) != 0;
     if (want && lgm_usable(M, N, ldu, dtype) && (reinterpret_cast<uintptr_t>(U) % 16) == 0 && (reinterpret_cast<uintptr_t>(Y) % 16) == 0 &&
-        ((size_t)ldu * 2) % 16 == 0) {
+        ((size_t)ldu * 2) % 16 == 0 && ((size_t)ldy * 2) % 16 == 0) {
       lgm_plan(M, N, bx, nsplit, rps);
-      if (R == 8) hipLaunchKernelGGL(lora_grad_mfma_kernel<8>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, (const bf16_t*)U, ldu, ws, M, N, rps);
-      else hipLaunchKernelGGL(lora_grad_mfma_kernel<16>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, (const bf16_t*)U, ldu, ws, M, N, rps);
+      if (R == 8) hipLaunchKernelGGL(lora_grad_mfma_kernel<8>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, ws, M, N, rps);
+      else hipLaunchKernelGGL(lora_grad_mfma_kernel<16>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, ws, M, N, rps);
       int rc0 = check_launch("gsl_lora_grad(mfma partial)");
       if (rc0) return rc0;
       const int totm = N * R;
@@ -356,7 +356,7 @@ extern "C" int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, lo
   const size_t red_bytes = (size_t)(RP - 1) * CG * V * R * sizeof(float);
   float* part2 = ws + (size_t)nsplit * N * R;
 #define LAUNCH(TT, RR)                                                                                                   \
-  hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(256), red_bytes, st, (const TT*)Y, (const TT*)U, \
+  hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(256), red_bytes, st, (const TT*)Y, ldy, (const TT*)U, \
                      ldu, ws, M, N, rps, CG)
   if (dtype == GSL_BF16) { if (R == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
   else { if (R == 8) LAUNCH(float, 8); else LAUNCH(float, 16); }

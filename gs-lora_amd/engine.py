@@ -34,8 +34,7 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
     proto_table = _losses.prototype_table(prototype_dict, device) if use_prototype else None
     use_structure = not (epoch < cfg.get("ALPHA_EPOCH", 0))
     group_type = cfg.get("GROUP_TYPE", "block")
-    if cfg.get("GROUP_POS", "FFN") != "FFN":
-        raise NotImplementedError("gs-lora_amd covers GROUP_POS='FFN'")
+    _check_group_pos(model, cfg.get("GROUP_POS", "FFN"))
     # few-shot inversion: iterate the LONGER forget loader, cycle the remain loader (engine.py:53-236)
     swap = bool(cfg.get("few_shot")) and len(dataloader_forget) > len(dataloader_remain)
     outer, inner = (dataloader_forget, dataloader_remain) if swap else (dataloader_remain, dataloader_forget)
@@ -94,7 +93,17 @@ def evaluate(model, testloader_forget, testloader_remain, device, batch, epoch, 
     return out
 
 
+def _check_group_pos(model, group_pos):
+    """group_pos follows the model's lora_pos (reference engine.py:585-658: the group names are taken from one or the other)."""
+    site = getattr(_unwrap(model), "lora_pos", "FFN")
+    if group_pos not in ("FFN", "Attention"):
+        raise ValueError("group_pos must be 'FFN' or 'Attention'")
+    if group_pos != site:
+        raise ValueError(f"group_pos={group_pos!r} but the model was built with lora_pos={site!r}")
+
+
 def get_structure_loss(model: torch.nn.Module, num_layers: int = 6, group_type: str = "block", group_pos: str = "FFN"):
-    if group_pos != "FFN":
-        raise NotImplementedError("gs-lora_amd covers group_pos='FFN'")
+    """Group lasso over the FFN adapter groups (block / lora / matrix) or, with group_pos='Attention', over one
+    (to_qkv.lora_A, to_qkv.lora_B) group per block (reference :651-656, group_type ignored there)."""
+    _check_group_pos(model, group_pos)
     return _losses.structure_loss(_unwrap(model), group_type)

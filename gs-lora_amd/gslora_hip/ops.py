@@ -143,8 +143,10 @@ _ws_cache = {}
 
 
 def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
-    """G[n*gsn + j*gsj] (+)= sum_m Y[m,n] U[m,j]; G is a view into the flat f32 gradient bucket."""
-    _need(Y, U)
+    """G[n*gsn + j*gsj] (+)= sum_m Y[m,n] U[m,j]; G is a view into the flat f32 gradient bucket. Y / U may be column blocks of wider
+    row-major tensors (unit column stride)."""
+    if not (Y.is_cuda and U.is_cuda and Y.stride(1) == 1 and U.stride(1) == 1):
+        raise RuntimeError("lora_grad: operands must be CUDA tensors with unit column stride")
     M, N = Y.shape
     lib = L.load()
     need = lib.gsl_lora_grad_ws_elems(M, N, r)
@@ -153,8 +155,8 @@ def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=Y.device, dtype=torch.float32)
         _ws_cache[key] = ws
-    L.check(lib.gsl_lora_grad(_p(Y), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype), 1 if accumulate else 0,
-                              _p(ws), _stream()), "gsl_lora_grad")
+    L.check(lib.gsl_lora_grad(_p(Y), Y.stride(0), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype),
+                              1 if accumulate else 0, _p(ws), _stream()), "gsl_lora_grad")
 
 
 def cosface_prep(W):

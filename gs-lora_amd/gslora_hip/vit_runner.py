@@ -19,12 +19,15 @@ SITE_EMB = 1_000_000
 
 class BlockSpec:
     """One pre-norm transformer block as the kernels see it: x1 = x + drop(Wo attn(LN1 x) + bo), x2 = x1 + drop(W2' drop(gelu(W1' LN2 x1)))."""
-    __slots__ = ("ln1", "qkv_w", "qkv_b", "out", "ln2", "l1", "l2")
+    __slots__ = ("ln1", "qkv_w", "qkv_b", "out", "ln2", "l1", "l2", "qkv_lora")
 
-    def __init__(self, ln1, qkv_w, qkv_b, out, ln2, l1, l2):
+    def __init__(self, ln1, qkv_w, qkv_b, out, ln2, l1, l2, qkv_lora=None):
         self.ln1, self.qkv_w, self.qkv_b, self.out, self.ln2, self.l1, self.l2 = ln1, qkv_w, qkv_b, out, ln2, l1, l2
+        self.qkv_lora = qkv_lora      # loralib.MergedLinear with r > 0 (--lora_pos Attention): adapters on q / k / v instead of the FFN
 
     def lora_params(self):
+        if self.qkv_lora is not None:
+            return (self.qkv_lora.lora_A, self.qkv_lora.lora_B)
         return (self.l1.lora_A, self.l1.lora_B, self.l2.lora_A, self.l2.lora_B)
 
 
@@ -37,9 +40,10 @@ class ModelSpec:
                     LN eps 1e-6, scale head_dim^-0.5, nn.Linear head with bias, the label argument is ignored."""
     __slots__ = ("patch_size", "num_tokens", "dim", "heads", "attn_scale", "ln_eps", "dropout_p", "emb_dropout_p", "lora_rank",
                  "patch_w", "patch_is_conv", "patch_b", "cls", "pos", "blocks", "final_ln", "head_kind", "head_w", "head_b",
-                 "cos_s", "cos_m")
+                 "cos_s", "cos_m", "lora_site")
 
     def __init__(self, **kw):
+        kw.setdefault("lora_site", "ffn")      # "ffn" (GS-LoRA) or "attention" (--lora_pos Attention ablation)
         for k in self.__slots__:
             setattr(self, k, kw[k])
 
@@ -69,6 +73,7 @@ class LoraBucket:
         self.tnumel = torch.tensor([p.numel() for p in self.params], device=dev, dtype=torch.int64)
         self.tgroup_block = torch.tensor(self.groups, device=dev, dtype=torch.int32)
         self.ngroups_block = len(layers)
+        self.per_layer = len(layers[0])
         self._gtables = {}
 
     def valid(self):
@@ -78,7 +83,7 @@ class LoraBucket:
     def group_table(self, group_type="block"):
         """tensor->group ids for engine.get_structure_loss groupings (engine.py:585-650)."""
         L_ = self.ngroups_block
-        if group_type == "block":
+        if group_type == "block" or self.per_layer != 4:      # attention adapters: always one (A, B) group per block (engine.py:651-656)
             return self.tgroup_block, L_
         if group_type in self._gtables:
             return self._gtables[group_type]
@@ -183,6 +188,35 @@ class ViTRunner:
             ent["version"] = param._version
         return ent["out"]
 
+    def qkv_lora_ops(self, i, ml, dtype):
+        """Operands of the three q / k / v adapters of one MergedLinear, as ONE LoRA K segment (r3 = 3r <= 64 live columns):
+          A_rows [64, dim]      rows g*r+j = A_g[j, :]                       (u = s * xn A_all^T)
+          Bblk  [3*inner, 64]   row g*inner+n, column g*r+j = B_g[n, j]      (qkv += u Bblk^T: block diagonal)
+          BblkT [64, 3*inner]                                                 (v = s * dqkv Bblk)
+          AT    [dim, 64]       column g*r+j = A_g[j, :]                      (dxn1 += v A_all)"""
+        r, ng = ml.r, len(ml.enable_lora)
+        if ng * r > PADK:
+            raise NotImplementedError("gs-lora_amd: 3 * lora_rank must not exceed 64 for --lora_pos Attention")
+
+        def build(_):
+            A, B = ml.lora_A.detach(), ml.lora_B.detach()
+            inner = B.shape[0] // ng
+            a_rows = torch.zeros(PADK, A.shape[1], device=A.device, dtype=torch.float32)
+            a_rows[:ng * r] = A
+            bblk = torch.zeros(B.shape[0], PADK, device=A.device, dtype=torch.float32)
+            for g in range(ng):
+                bblk[g * inner:(g + 1) * inner, g * r:(g + 1) * r] = B[g * inner:(g + 1) * inner]
+            cast = (lambda t: t.contiguous()) if dtype == torch.float32 else (lambda t: ops.cast(t.contiguous(), dtype))
+            return dict(A_rows=cast(a_rows), Bblk=cast(bblk), BblkT=cast(bblk.t()), AT=cast(a_rows.t()))
+        key = (f"qkvlora{i}", dtype)
+        ent = self._lcache.get(key)
+        tag = (ml.lora_A.data_ptr(), ml.lora_A._version, ml.lora_B._version, ml.lora_A.device)
+        if ent is None or ent[0] != tag:
+            with torch.no_grad():
+                ent = (tag, build(None))
+            self._lcache[key] = ent
+        return ent[1]
+
     def refresh_lora_packs(self, dtype):
         """One launch for every registered pack whose source changed (the optimizer touches all LoRA tensors each step)."""
         ents = [e for k, e in self._packs.items() if k[2] == dtype]
@@ -253,7 +287,8 @@ class ViTRunner:
             seed, sflag = (self.drop_seed << 20) + self.drop_calls, 0
         self.ensure_bucket(sp)
         r = sp.lora_rank
-        if r > 0:
+        attn_site = r > 0 and sp.lora_site == "attention"
+        if r > 0 and not attn_site:
             self.refresh_lora_packs(dt)
         s_lora = (1.0 / r) if r > 0 else 0.0
         eps = sp.ln_eps
@@ -270,7 +305,16 @@ class ViTRunner:
             n1, n2 = blk.ln1, blk.ln2
             xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
             qkv = torch.empty(M, 3 * H * 64, device=img.device, dtype=dt)
-            ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, bias=None if blk.qkv_b is None else blk.qkv_b.detach())
+            uq = None
+            if attn_site and not blk.qkv_lora.merged:      # q / k / v adapters: one block-diagonal LoRA K segment
+                qo = self.qkv_lora_ops(i, blk.qkv_lora, dt)
+                uq = torch.empty(M, PADK, device=img.device, dtype=dt)
+                ops.gemm_nt(xn, qo["A_rows"], uq, alpha=s_lora)
+                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, A2=uq, W2=qo["Bblk"],
+                            bias=None if blk.qkv_b is None else blk.qkv_b.detach())
+            else:
+                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, bias=None if blk.qkv_b is None else blk.qkv_b.detach())
+            xn_keep = xn if (attn_site and save) else None
             del xn
             o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale)
             x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
@@ -279,7 +323,7 @@ class ViTRunner:
             xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
             l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
-            lora_on = r > 0 and not l1.merged
+            lora_on = r > 0 and not attn_site and not l1.merged
             u1 = u2 = None
             h = torch.empty(M, mlp, device=img.device, dtype=dt)
             gp = torch.empty(M, mlp, device=img.device, dtype=dt) if save else None
@@ -306,7 +350,7 @@ class ViTRunner:
                             bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
-                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on))
+                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq))
             x = x2
         hn = sp.final_ln
         if linear_head:      # plain classifier: logits for every call, no normalisation, no margin
@@ -331,6 +375,8 @@ class ViTRunner:
         if bucket is None:
             return
         bucket.attach_grads()
+        if sp.lora_site == "attention":
+            return self._backward_attention_site(saved, dlogits, demb)
         dt = saved["dt"]
         B, seed, p_drop, sflag = saved["B"], saved["seed"], saved["p_drop"], saved["sflag"]
         T, D, H = sp.num_tokens, sp.dim, sp.heads
@@ -424,3 +470,82 @@ class ViTRunner:
             saved["layers"][i] = None   # free this layer's activations
         if not torch.cuda.is_current_stream_capturing():
             self.build_pack_tables(dt)    # every pack of the step is registered now: the next forward refreshes them in one launch
+
+    def _backward_attention_site(self, saved, dlogits, demb):
+        """Backward when the adapters sit on the QKV projection (--lora_pos Attention; reference vit_face.py:349-355 with
+        loralib.MergedLinear): the FFN is a plain frozen sub-layer (dX only), every block's attention needs its dqkv, and the chain
+        stops after the LoRA gradients of block 0. Same kernels as the FFN-site path."""
+        sp, bucket = saved["spec"], self.bucket
+        dt = saved["dt"]
+        B, seed, p_drop, sflag = saved["B"], saved["seed"], saved["p_drop"], saved["sflag"]
+        T, D, H = sp.num_tokens, sp.dim, sp.heads
+        r = sp.lora_rank
+        s_lora = 1.0 / r
+        nl = len(saved["layers"])
+        hn = sp.final_ln
+        linear_head = sp.head_kind == "linear"
+        if dlogits is not None:
+            dlogits = dlogits.contiguous().float()
+        if demb is not None:
+            demb = demb.contiguous().float()
+        if dlogits is not None and saved["Wn"] is None:
+            raise RuntimeError("backward through logits requires a forward with labels")
+        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
+                               saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head)
+        gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
+        dev = dx.device
+        cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
+        for i in reversed(range(nl)):
+            st = saved["layers"][i]
+            blk = sp.blocks[i]
+            l1, l2, ml = blk.l1, blk.l2, blk.qkv_lora
+            if st["uq"] is None:
+                raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
+            mlp = l1.weight.shape[0]
+            sparse = (i == nl - 1)      # only the cls rows of the last block carry gradient (see the FFN-site path)
+            if sparse:
+                dyb, gp = cls_rows(dxb, D), cls_rows(st["gp"], mlp)
+            else:
+                dyb, gp = dxb, st["gp"]
+            Mrows = dyb.shape[0]
+            # ---- frozen FFN sub-layer: dX only
+            da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
+            ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, aux=gp)
+            dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
+            ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2)
+            del da
+            n2 = blk.ln2
+            if sparse:
+                dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
+                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
+            else:
+                dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
+            del dxn2
+            # ---- attention sub-layer with the q / k / v adapters
+            d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
+            ops.gemm_nt(dx1b, self.wT(f"wo{i}", blk.out.weight, dt), d_o)
+            if sparse:
+                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+            else:
+                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+            del d_o, dx1b
+            qo = self.qkv_lora_ops(i, ml, dt)
+            v = torch.empty(B * T, PADK, device=dev, dtype=dt)
+            ops.gemm_nt(dqkv, qo["BblkT"], v, alpha=s_lora)                      # v[:, g*r+j] = s * dqkv_g . B_g[:, j]
+            ng, inner = len(ml.enable_lora), H * 64
+            gA, gB = gv[id(ml.lora_A)], gv[id(ml.lora_B)]
+            for g in range(ng):
+                ops.lora_grad(st["xn"], v[:, g * r:], gA[g * r:(g + 1) * r], 1, D, r)                       # dA_g[j, c]
+                ops.lora_grad(dqkv[:, g * inner:(g + 1) * inner], st["uq"][:, g * r:], gB[g * inner:(g + 1) * inner], r, 1, r)   # dB_g[n, j]
+            if i == 0:
+                break      # nothing below the block-0 QKV projection is trainable
+            dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)
+            ops.gemm_nt(dqkv, self.wT(f"qkv{i}", blk.qkv_w, dt), dxn1, A2=v, W2=qo["AT"])
+            del dqkv, v
+            n1 = blk.ln1
+            dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
+                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag)
+            saved["layers"][i] = None

@@ -75,16 +75,59 @@ class Linear(nn.Linear):
 
 
 class MergedLinear(nn.Linear):
-    """r = 0 only (lora_pos='FFN'): identical to a bias-less/bias nn.Linear parameter holder.
-    r > 0 is the `--lora_pos Attention` ablation of the reference — outside the hot path."""
+    """Parameter holder with loralib 0.1.2's MergedLinear state machine (reference call site vit_face.py:349-355:
+    `enable_lora=[True, True, True], bias=False`). r = 0 (lora_pos='FFN') is a plain linear holder; r > 0 (--lora_pos Attention)
+    carries one rank-r adapter per output group: lora_A [3r, in] (rows g*r.. of group g), lora_B [out, r] (rows of group g),
+    delta_W rows of group g = B_g @ A_g, scaling = lora_alpha / r. eval() merges in place, train() un-merges. The arithmetic runs in
+    ViTRunner (QKV GEMM with a block-diagonal LoRA K segment)."""
 
     def __init__(self, in_features, out_features, r=0, lora_alpha=1, lora_dropout=0.0, enable_lora=(False,),
                  fan_in_fan_out=False, merge_weights=True, **kwargs):
-        if r != 0:
-            raise NotImplementedError("gs-lora_amd: MergedLinear with r > 0 (--lora_pos Attention) is not implemented")
+        if lora_dropout != 0.0 or fan_in_fan_out:
+            raise NotImplementedError("gs-lora_amd loralib.MergedLinear: lora_dropout / fan_in_fan_out are not used by GS-LoRA")
         super().__init__(in_features, out_features, **kwargs)
-        self.r = 0
-        self.merged = False
+        assert out_features % len(enable_lora) == 0, "The length of enable_lora must divide out_features"
+        self.enable_lora = list(enable_lora)
+        self.r, self.lora_alpha = r, lora_alpha
+        self.merged, self.merge_weights = False, merge_weights
+        if r > 0 and any(self.enable_lora):
+            if not all(self.enable_lora):
+                raise NotImplementedError("gs-lora_amd loralib.MergedLinear: every output group carries an adapter in GS-LoRA")
+            ng = len(self.enable_lora)
+            self.lora_A = nn.Parameter(self.weight.new_zeros((r * ng, in_features)))
+            self.lora_B = nn.Parameter(self.weight.new_zeros((out_features, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+        else:
+            self.r = 0
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        if hasattr(self, "lora_A"):
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+            nn.init.zeros_(self.lora_B)
+
+    def _delta(self):
+        ng, r = len(self.enable_lora), self.r
+        A = self.lora_A.detach().view(ng, r, self.in_features)
+        B = self.lora_B.detach().view(ng, self.out_features // ng, r)
+        return torch.bmm(B, A).reshape(self.out_features, self.in_features) * self.scaling
+
+    def train(self, mode=True):
+        super().train(mode)
+        if self.merge_weights and self.r > 0:
+            with torch.no_grad():
+                if mode and self.merged:
+                    self.weight.sub_(self._delta())
+                    self.merged = False
+                elif not mode and not self.merged:
+                    self.weight.add_(self._delta())
+                    self.merged = True
+        return self
+
+    def forward(self, *a, **k):
+        raise RuntimeError("loralib.MergedLinear (gs-lora_amd) is a parameter holder; call ViT_face.forward (fused HIP path)")
 
 
 def mark_only_lora_as_trainable(model, bias="none"):

@@ -84,11 +84,14 @@ class Attention(_Holder):
 class Transformer(_Holder):
     def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout, lora_rank, up=False, lora_pos="FFN"):
         super().__init__()
-        if lora_pos != "FFN":
-            raise NotImplementedError("gs-lora_amd implements lora_pos='FFN' (the GS-LoRA configuration)")
+        if lora_pos not in ("FFN", "Attention"):
+            raise ValueError("lora_pos must be 'FFN' (GS-LoRA) or 'Attention' (the reference's ablation)")
+        # reference :400-425: the adapters sit either on the two FFN linears or on the QKV projection, never on both
         self.layers = nn.ModuleList([
-            nn.ModuleList([Residual(PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout, lora_rank=0))),
-                           Residual(PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout, lora_rank=lora_rank)))])
+            nn.ModuleList([Residual(PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout,
+                                                           lora_rank=lora_rank if lora_pos == "Attention" else 0))),
+                           Residual(PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout,
+                                                             lora_rank=lora_rank if lora_pos == "FFN" else 0)))])
             for _ in range(depth)])
         self.up = up
         self.depth = depth
@@ -190,6 +193,7 @@ class ViT_face(HipModelMixin, nn.Module):
         self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
         self.num_tokens = num_patches + 1
         self.lora_rank = lora_rank
+        self.lora_pos = lora_pos
         self.attn_scale = dim ** -0.5
         self.dropout_p, self.emb_dropout_p = float(dropout), float(emb_dropout)
         self.compute_dtype = _DTYPES[os.environ.get("GSLORA_DTYPE", "bf16").lower()]
@@ -209,14 +213,16 @@ class ViT_face(HipModelMixin, nn.Module):
         blocks = []
         for attn, ff in self.transformer.layers:
             a, f = attn.fn, ff.fn
-            blocks.append(BlockSpec(a.norm, a.fn.to_qkv.weight, None, a.fn.to_out[0], f.norm, f.fn.net[0], f.fn.net[3]))
+            blocks.append(BlockSpec(a.norm, a.fn.to_qkv.weight, None, a.fn.to_out[0], f.norm, f.fn.net[0], f.fn.net[3],
+                                    qkv_lora=a.fn.to_qkv if self.lora_pos == "Attention" and self.lora_rank > 0 else None))
         has_loss = self.loss_type == "CosFace"
         return ModelSpec(patch_size=self.patch_size, num_tokens=self.num_tokens, dim=self.dim, heads=self.heads,
                          attn_scale=self.attn_scale, ln_eps=1e-5, dropout_p=self.dropout_p, emb_dropout_p=self.emb_dropout_p,
                          lora_rank=self.lora_rank, patch_w=self.patch_to_embedding.weight, patch_is_conv=False,
                          patch_b=self.patch_to_embedding.bias, cls=self.cls_token, pos=self.pos_embedding, blocks=blocks,
                          final_ln=self.mlp_head[0], head_kind="cosface", head_w=self.loss.weight if has_loss else None,
-                         head_b=None, cos_s=self.loss.s if has_loss else 64.0, cos_m=self.loss.m if has_loss else 0.35)
+                         head_b=None, cos_s=self.loss.s if has_loss else 64.0, cos_m=self.loss.m if has_loss else 0.35,
+                         lora_site="attention" if self.lora_pos == "Attention" else "ffn")
 
     # ---- reference API ---------------------------------------------------------------------------
     def forward(self, img, label=None, mask=None):

@@ -107,9 +107,11 @@ int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, c
                           int B, int T, int H, float scale, int dtype, gsl_stream_t s);
 
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
- * Y[dtype] [M,N], U[dtype] [M,ldu] (first r columns used, r <= 16). ws f32 >= gsl_lora_grad_ws_elems(). */
+ * Y[dtype] [M,N] with row stride ldy >= N elements (a column block of a wider tensor is allowed), U[dtype] [M,ldu] (first r columns
+ * used, r <= 16; columns r..15 must be readable zeros or belong to other adapters whose products are discarded).
+ * ws f32 >= gsl_lora_grad_ws_elems(). */
 long gsl_lora_grad_ws_elems(int M, int N, int r);
-int gsl_lora_grad(const void* Y, const void* U, int ldu, float* G, long gsn, long gsj,
+int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj,
                   int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
 
 /* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35).

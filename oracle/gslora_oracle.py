@@ -56,12 +56,20 @@ def lora_linear(x, W, bias, A, B, r, merged):
     return y
 
 
+def merged_delta(A, B, r):
+    """loralib 0.1.2 MergedLinear.merge_AB with enable_lora=[True]*3: rows of output group g = B_g @ A_g
+    (A [3r, in] rows g*r.., B [out, r] rows of group g) — the grouped conv1d written as a batched matmul."""
+    ng = A.shape[0] // r
+    return torch.bmm(B.view(ng, -1, r), A.view(ng, r, -1)).reshape(B.shape[0], A.shape[1])
+
+
 def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None):
     """ViT_face.forward (vit_face.py:523-548) with Transformer (:442-446), Attention
     (:358-379, scale = dim**-0.5 :346), FeedForward (:329-335, exact-erf GELU) and
     CosFace (:171-208). Dropout is the identity here (parity runs use p=0; eval mode).
     Returns (logits|None, emb)."""
     p, d, hds, r = cfg["patch_size"], cfg["dim"], cfg["heads"], cfg["lora_rank"]
+    attn_lora = cfg.get("lora_pos", "FFN") == "Attention"
     x = patchify(img.float(), p)
     x = F.linear(x, st["patch_to_embedding.weight"], st["patch_to_embedding.bias"])
     b, n, _ = x.shape
@@ -73,6 +81,8 @@ def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None):
         f = f"transformer.layers.{i}.1.fn"
         xn = F.layer_norm(x, (d,), st[f"{a}.norm.weight"], st[f"{a}.norm.bias"], LN_EPS)
         qkv = F.linear(xn, st[f"{a}.fn.to_qkv.weight"])
+        if attn_lora and not merged:      # loralib.MergedLinear: one rank-r adapter per q / k / v group, scaling 1/r
+            qkv = qkv + (xn @ merged_delta(st[f"{a}.fn.to_qkv.lora_A"], st[f"{a}.fn.to_qkv.lora_B"], r).t()) * (1.0 / r)
         q, k, v = qkv.chunk(3, dim=-1)
         sp = lambda t: t.reshape(b, n + 1, hds, -1).permute(0, 2, 1, 3)
         q, k, v = sp(q), sp(k), sp(v)
@@ -81,11 +91,12 @@ def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None):
         o = torch.einsum("bhij,bhjd->bhid", attn, v).permute(0, 2, 1, 3).reshape(b, n + 1, -1)
         x = F.linear(o, st[f"{a}.fn.to_out.0.weight"], st[f"{a}.fn.to_out.0.bias"]) + x
         xn = F.layer_norm(x, (d,), st[f"{f}.norm.weight"], st[f"{f}.norm.bias"], LN_EPS)
+        rf = 0 if attn_lora else r
         h = lora_linear(xn, st[f"{f}.fn.net.0.weight"], st[f"{f}.fn.net.0.bias"],
-                        st[f"{f}.fn.net.0.lora_A"], st[f"{f}.fn.net.0.lora_B"], r, merged)
+                        st.get(f"{f}.fn.net.0.lora_A"), st.get(f"{f}.fn.net.0.lora_B"), rf, merged)
         h = F.gelu(h)
         y = lora_linear(h, st[f"{f}.fn.net.3.weight"], st[f"{f}.fn.net.3.bias"],
-                        st[f"{f}.fn.net.3.lora_A"], st[f"{f}.fn.net.3.lora_B"], r, merged)
+                        st.get(f"{f}.fn.net.3.lora_A"), st.get(f"{f}.fn.net.3.lora_B"), rf, merged)
         x = y + x
     x = x[:, 0]  # pool='cls' (vit_face.py:540)
     emb = F.layer_norm(x, (d,), st["mlp_head.0.weight"], st["mlp_head.0.bias"], LN_EPS)
@@ -107,6 +118,11 @@ def merge_lora(st, cfg, sign=+1.0):
     """loralib Linear.train(False)/train(True): W += / -= (B@A)/r in place."""
     r = cfg["lora_rank"]
     out = dict(st)
+    if cfg.get("lora_pos", "FFN") == "Attention":
+        for i in range(cfg["depth"]):
+            pre = f"transformer.layers.{i}.0.fn.fn.to_qkv"
+            out[f"{pre}.weight"] = st[f"{pre}.weight"] + sign * merged_delta(st[f"{pre}.lora_A"], st[f"{pre}.lora_B"], r) / r
+        return out
     for i in range(cfg["depth"]):
         for j in (0, 3):
             pre = f"transformer.layers.{i}.1.fn.fn.net.{j}"
@@ -121,6 +137,8 @@ def lora_groups(cfg, group_type="block"):
     """Group naming of engine_cl.get_structure_loss (engine_cl.py:388-394) and
     engine.get_structure_loss block/lora/matrix (engine.py:585-650)."""
     L = cfg["depth"]
+    if cfg.get("lora_pos", "FFN") == "Attention":      # engine.py:651-656, util/cal_norm.py:108-120: one (A, B) group per block
+        return [[f"transformer.layers.{i}.0.fn.fn.to_qkv.lora_A", f"transformer.layers.{i}.0.fn.fn.to_qkv.lora_B"] for i in range(L)]
     n = lambda i, j, ab: f"transformer.layers.{i}.1.fn.fn.net.{j}.lora_{ab}"
     if group_type == "block":
         return [[n(i, 0, "A"), n(i, 0, "B"), n(i, 3, "A"), n(i, 3, "B")] for i in range(L)]

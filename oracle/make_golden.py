@@ -65,7 +65,8 @@ def build_reference_model(cfg, state_np, dropout=0.0):
     from vit_pytorch_face import ViT_face
     model = ViT_face(loss_type="CosFace", GPU_ID=[0], num_class=cfg["num_class"], image_size=cfg["image_size"],
                      patch_size=cfg["patch_size"], dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"],
-                     mlp_dim=cfg["mlp_dim"], dropout=dropout, emb_dropout=dropout, lora_rank=cfg["lora_rank"])
+                     mlp_dim=cfg["mlp_dim"], dropout=dropout, emb_dropout=dropout, lora_rank=cfg["lora_rank"],
+                     lora_pos=cfg.get("lora_pos", "FFN"))
     sd = {k: torch.tensor(v) for k, v in state_np.items()}
     missing, unexpected = model.load_state_dict(sd, strict=True), None
     import loralib as lora
@@ -93,6 +94,7 @@ def run_case(tag, cfg, batch, out, hyper, n_steps=3):
     from util.cal_norm import get_norm_of_lora
 
     state = recipe.make_state(cfg)
+    gpos = cfg.get("lora_pos", "FFN")
     model = build_reference_model(cfg, state)
     assert [n for n, _ in model.named_parameters()] == list(recipe.param_shapes(cfg).keys()), "name order drift"
 
@@ -121,7 +123,8 @@ def run_case(tag, cfg, batch, out, hyper, n_steps=3):
     with torch.no_grad():
         logits_e, emb_e = model(xs_r[0], ys_r[0])
         res["eval_logits"], res["eval_emb"] = logits_e.numpy(), emb_e.numpy()
-        res["merged_w_l0_net0"] = model.state_dict()["transformer.layers.0.1.fn.fn.net.0.weight"].numpy().copy()
+        wkey = "transformer.layers.0.0.fn.fn.to_qkv.weight" if gpos == "Attention" else "transformer.layers.0.1.fn.fn.net.0.weight"
+        res["merged_w_l0_net0"] = model.state_dict()[wkey].numpy().copy()
     model.train()
     with torch.no_grad():
         logits_rt, _ = model(xs_r[0], ys_r[0])
@@ -131,11 +134,11 @@ def run_case(tag, cfg, batch, out, hyper, n_steps=3):
 
     # ---- loss pieces -------------------------------------------------------------------------
     res["structure_loss"] = np.float32(engine_cl.get_structure_loss(model).item()) if cfg["depth"] == 6 else np.float32(-1)
-    for gt in ("block", "lora", "matrix"):
+    for gt in (("block",) if gpos == "Attention" else ("block", "lora", "matrix")):
         res[f"structure_loss_engine_{gt}"] = np.float32(
-            engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type=gt, group_pos="FFN").item())
+            engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type=gt, group_pos=gpos).item())
         res[f"cal_norm_{gt}"] = np.array(
-            [float(v) for v in get_norm_of_lora(model, type="L2", group_num=cfg["depth"], group_type=gt, group_pos="FFN")],
+            [float(v) for v in get_norm_of_lora(model, type="L2", group_num=cfg["depth"], group_type=gt, group_pos=gpos)],
             dtype=np.float32)
     with torch.no_grad():
         _, emb_f = model(xs_f[0], ys_f[0])
@@ -189,7 +192,7 @@ def run_case(tag, cfg, batch, out, hyper, n_steps=3):
         lo_r, em_r = model(xs_r[0], ys_r[0])
         lo_f, em_f = model(xs_f[0], ys_f[0])
         ce_r, ce_f = crit(lo_r, ys_r[0]), crit(lo_f, ys_f[0])
-        sl = engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type="block", group_pos="FFN")
+        sl = engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type="block", group_pos=gpos)
         kl_f = engine_cl.get_prototype_loss(em_f, ys_f[0], proto_dict)
         kl_r = engine_cl.get_prototype_loss(em_r, ys_r[0], proto_dict)
         pro = hyper["pro_f_weight"] * torch.relu(hyper["BND_pro"] - kl_f) + hyper["pro_r_weight"] * kl_r
@@ -206,7 +209,7 @@ def run_case(tag, cfg, batch, out, hyper, n_steps=3):
         lo_f, em_f = model(xs_f[0], ys_f[0])
         kl_f = engine_cl.get_prototype_loss(em_f, ys_f[0], proto_dict)
         kl_r = engine_cl.get_prototype_loss(em_r, ys_r[0], proto_dict)
-        sl = engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type="block", group_pos="FFN")
+        sl = engine_single.get_structure_loss(model, num_layers=cfg["depth"], group_type="block", group_pos=gpos)
         total = (hyper["beta"] * torch.relu(5.0 - crit(lo_f, ys_f[0])) + crit(lo_r, ys_r[0]) + hyper["alpha"] * sl
                  + hyper["pro_f_weight"] * torch.relu(0.1 - kl_f) + hyper["pro_r_weight"] * kl_r)
         model.zero_grad()
@@ -258,10 +261,14 @@ def main():
     torch.set_num_threads(8)
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
-    run_case("small_b5", recipe.cfg_small(), 5, out, HYPER)
-    run_case("small2_b3", recipe.cfg_small2(), 3, out, HYPER)
-    run_case("full_b2", recipe.cfg_full(), 2, out, HYPER)
-    host_kats(out)
+    only = sys.argv[1:]       # e.g. `python oracle/make_golden.py attn_small_b3` regenerates one fixture
+    cases = [("small_b5", recipe.cfg_small(), 5), ("small2_b3", recipe.cfg_small2(), 3), ("full_b2", recipe.cfg_full(), 2),
+             ("attn_small_b3", recipe.cfg_small_attn(), 3)]      # --lora_pos Attention (reference MergedLinear on to_qkv)
+    for tag, cfg, b in cases:
+        if not only or tag in only:
+            run_case(tag, cfg, b, out, HYPER)
+    if not only:
+        host_kats(out)
 
 
 if __name__ == "__main__":

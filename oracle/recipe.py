@@ -57,6 +57,13 @@ def cfg_small(lora_rank=4, num_class=10):
                 mlp_dim=128, num_class=num_class, lora_rank=lora_rank, channels=3)
 
 
+def cfg_small_attn(lora_rank=8, num_class=12):
+    """cfg_small2 with the adapters on the QKV projection instead of the FFN (--lora_pos Attention)."""
+    c = cfg_small2(lora_rank, num_class)
+    c["lora_pos"] = "Attention"
+    return c
+
+
 def cfg_small2(lora_rank=8, num_class=12):
     """Second small model: 2 heads, 3 layers, ragged token count (48px/8 -> 37 tokens)."""
     return dict(image_size=48, patch_size=8, dim=128, depth=3, heads=2, dim_head=64,
@@ -68,6 +75,7 @@ def param_shapes(cfg):
     (probe of vit_pytorch_face/vit_face.py:449-521)."""
     d, h, dh, mlp, r = cfg["dim"], cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], cfg["lora_rank"]
     inner = h * dh
+    attn_lora = cfg.get("lora_pos", "FFN") == "Attention"
     npatch = (cfg["image_size"] // cfg["patch_size"]) ** 2
     pdim = cfg["channels"] * cfg["patch_size"] ** 2
     sh = {}
@@ -81,18 +89,23 @@ def param_shapes(cfg):
         sh[f"{a}.norm.weight"] = (d,)
         sh[f"{a}.norm.bias"] = (d,)
         sh[f"{a}.fn.to_qkv.weight"] = (3 * inner, d)
+        if attn_lora:      # --lora_pos Attention: loralib.MergedLinear(enable_lora=[True]*3) on to_qkv (vit_face.py:349-355)
+            sh[f"{a}.fn.to_qkv.lora_A"] = (3 * r, d)
+            sh[f"{a}.fn.to_qkv.lora_B"] = (3 * inner, r)
         sh[f"{a}.fn.to_out.0.weight"] = (d, inner)
         sh[f"{a}.fn.to_out.0.bias"] = (d,)
         sh[f"{f}.norm.weight"] = (d,)
         sh[f"{f}.norm.bias"] = (d,)
         sh[f"{f}.fn.net.0.weight"] = (mlp, d)
         sh[f"{f}.fn.net.0.bias"] = (mlp,)
-        sh[f"{f}.fn.net.0.lora_A"] = (r, d)
-        sh[f"{f}.fn.net.0.lora_B"] = (mlp, r)
+        if not attn_lora:
+            sh[f"{f}.fn.net.0.lora_A"] = (r, d)
+            sh[f"{f}.fn.net.0.lora_B"] = (mlp, r)
         sh[f"{f}.fn.net.3.weight"] = (d, mlp)
         sh[f"{f}.fn.net.3.bias"] = (d,)
-        sh[f"{f}.fn.net.3.lora_A"] = (r, mlp)
-        sh[f"{f}.fn.net.3.lora_B"] = (d, r)
+        if not attn_lora:
+            sh[f"{f}.fn.net.3.lora_A"] = (r, mlp)
+            sh[f"{f}.fn.net.3.lora_B"] = (d, r)
     sh["mlp_head.0.weight"] = (d,)
     sh["mlp_head.0.bias"] = (d,)
     sh["loss.weight"] = (cfg["num_class"], d)

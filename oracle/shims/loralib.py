@@ -13,7 +13,8 @@ published semantics (microsoft/LoRA, loralib/layers.py @0.1.2) are restated here
     train(True):  if merged: W -= (B@A)*scaling ; merged=False
     train(False): if not merged: W += (B@A)*scaling ; merged=True
     forward: r>0 and not merged -> F.linear(x,W,b) + (drop(x) @ A.T @ B.T)*scaling else F.linear(x,W,b)
-  MergedLinear(..., r=0, enable_lora, bias) with r=0 == nn.Linear
+  MergedLinear(..., r, enable_lora, bias): r=0 == nn.Linear; r>0 (only with --lora_pos Attention) = one adapter per enabled
+    output group via grouped conv1d (see the class docstring)
   mark_only_lora_as_trainable(model, bias='none'): requires_grad=False for names without 'lora_'
 """
 import math
@@ -69,15 +70,60 @@ class Linear(nn.Linear):
 
 
 class MergedLinear(nn.Linear):
-    """Only the r=0 form is reachable from the GS-LoRA FFN configuration (lora_pos='FFN')."""
+    """loralib 0.1.2 MergedLinear (reference call site vit_face.py:349-355: enable_lora=[True,True,True], bias=False;
+    r > 0 only with --lora_pos Attention): one rank-r adapter per enabled output group, applied as a grouped conv1d.
+      lora_A [r * n_enabled, in], lora_B [out / n_groups * n_enabled, r], scaling = lora_alpha / r
+      delta_W = zero_pad(conv1d(lora_A[None], lora_B[..., None], groups=n_enabled)[0])   -> [out, in]; group g rows = B_g @ A_g
+      forward (not merged): F.linear(x, W, b) + (x @ delta_W.T) * scaling ; train()/eval() un-merge / merge like Linear."""
 
     def __init__(self, in_features, out_features, r=0, lora_alpha=1, lora_dropout=0.0,
                  enable_lora=(False,), fan_in_fan_out=False, merge_weights=True, **kwargs):
         nn.Linear.__init__(self, in_features, out_features, **kwargs)
-        if r != 0:
-            raise NotImplementedError("MergedLinear r>0 (lora_pos='Attention') is out of scope of the oracle")
-        self.r = 0
-        self.merged = False
+        assert out_features % len(enable_lora) == 0, "The length of enable_lora must divide out_features"
+        self.r, self.lora_alpha = r, lora_alpha
+        self.enable_lora = list(enable_lora)
+        self.merged, self.merge_weights = False, merge_weights
+        if r > 0 and any(enable_lora):
+            self.lora_A = nn.Parameter(self.weight.new_zeros((r * sum(enable_lora), in_features)))
+            self.lora_B = nn.Parameter(self.weight.new_zeros((out_features // len(enable_lora) * sum(enable_lora), r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+            ind = self.weight.new_zeros((out_features,), dtype=torch.bool).view(len(enable_lora), -1)
+            ind[torch.tensor(self.enable_lora, dtype=torch.bool), :] = True
+            self.lora_ind = ind.view(-1)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.Linear.reset_parameters(self)
+        if hasattr(self, "lora_A"):
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+            nn.init.zeros_(self.lora_B)
+
+    def zero_pad(self, x):
+        result = x.new_zeros((len(self.lora_ind), *x.shape[1:]))
+        result[self.lora_ind] = x
+        return result
+
+    def merge_AB(self):
+        delta_w = F.conv1d(self.lora_A.unsqueeze(0), self.lora_B.unsqueeze(-1), groups=sum(self.enable_lora)).squeeze(0)
+        return self.zero_pad(delta_w)
+
+    def train(self, mode=True):
+        nn.Linear.train(self, mode)
+        if self.r > 0 and any(self.enable_lora) and self.merge_weights:
+            if mode and self.merged:
+                self.weight.data -= self.merge_AB() * self.scaling
+                self.merged = False
+            elif not mode and not self.merged:
+                self.weight.data += self.merge_AB() * self.scaling
+                self.merged = True
+        return self
+
+    def forward(self, x):
+        result = F.linear(x, self.weight, bias=self.bias)
+        if self.r > 0 and any(self.enable_lora) and not self.merged:
+            result = result + (x @ self.merge_AB().T) * self.scaling
+        return result
 
 
 def mark_only_lora_as_trainable(model, bias="none"):

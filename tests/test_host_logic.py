@@ -79,10 +79,22 @@ def test_lora_merge_state_machine_and_init():
     assert l2.merged                                  # the flag survives deepcopy (EMA path of the CL driver)
     l.train()
     assert not l.merged and torch.allclose(l.weight, w0, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        lora.MergedLinear(64, 192, r=4, enable_lora=[True, True, True], bias=False)
     ml = lora.MergedLinear(64, 192, r=0, enable_lora=[True, True, True], bias=False)
     assert ml.bias is None and [n for n, _ in ml.named_parameters()] == ["weight"]
+    # r > 0 (--lora_pos Attention): loralib's grouped adapters — shapes, merge round trip against the restated loralib of the oracle
+    from oracle.shims import loralib as shim
+    mq = lora.MergedLinear(64, 192, r=4, enable_lora=[True, True, True], bias=False)
+    assert [n for n, _ in mq.named_parameters()] == ["weight", "lora_A", "lora_B"]
+    assert mq.lora_A.shape == (12, 64) and mq.lora_B.shape == (192, 4) and mq.scaling == 0.25 and not mq.weight.requires_grad
+    with torch.no_grad():
+        mq.lora_B.normal_()
+    ref = shim.MergedLinear(64, 192, r=4, enable_lora=[True, True, True], bias=False)
+    ref.load_state_dict(mq.state_dict())
+    wq0 = mq.weight.clone()
+    mq.eval(); ref.eval()
+    assert mq.merged and torch.allclose(mq.weight, ref.weight, atol=1e-7) and not torch.allclose(mq.weight, wq0)
+    mq.train()
+    assert not mq.merged and torch.allclose(mq.weight, wq0, atol=1e-6)
 
 
 def test_model_eval_train_merges_every_ffn_linear():

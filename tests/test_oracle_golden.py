@@ -10,7 +10,8 @@ import torch
 from oracle import gslora_oracle as O
 from oracle import recipe
 
-CASES = {"small_b5": (recipe.cfg_small(), 5), "small2_b3": (recipe.cfg_small2(), 3), "full_b2": (recipe.cfg_full(), 2)}
+CASES = {"small_b5": (recipe.cfg_small(), 5), "small2_b3": (recipe.cfg_small2(), 3), "full_b2": (recipe.cfg_full(), 2),
+         "attn_small_b3": (recipe.cfg_small_attn(), 3)}      # --lora_pos Attention
 HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, BND_pro=2.0, pro_f_weight=0.05, pro_r_weight=0.1)
 
 
@@ -36,7 +37,8 @@ def test_forward_matches_reference(tag, golden_dir):
     assert np.abs(emb2.numpy() - g["fwd_emb_nolabel"]).max() < 1e-5
     # eval mode == merged weights
     stm = O.merge_lora(st, cfg)
-    assert np.abs(stm["transformer.layers.0.1.fn.fn.net.0.weight"].numpy() - g["merged_w_l0_net0"]).max() < 1e-7
+    wkey = "transformer.layers.0.0.fn.fn.to_qkv.weight" if cfg.get("lora_pos") == "Attention" else "transformer.layers.0.1.fn.fn.net.0.weight"
+    assert np.abs(stm[wkey].numpy() - g["merged_w_l0_net0"]).max() < 1e-7
     le, ee = O.vit_forward(stm, xr, yr, cfg, merged=True)
     assert np.abs(le.numpy() - g["eval_logits"]).max() < 2e-5
     assert np.abs(ee.numpy() - g["eval_emb"]).max() < 1e-5
@@ -47,7 +49,7 @@ def test_loss_pieces_match_reference(tag, golden_dir):
     cfg, b = CASES[tag]
     g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
     st = O.to_torch(recipe.make_state(cfg))
-    for gt in ("block", "lora", "matrix"):
+    for gt in (("block",) if cfg.get("lora_pos") == "Attention" else ("block", "lora", "matrix")):
         assert abs(O.structure_loss(st, cfg, gt).item() - float(g[f"structure_loss_engine_{gt}"])) < 1e-4
         assert np.abs(O.cal_norm_of_lora(st, cfg, gt).numpy() - g[f"cal_norm_{gt}"]).max() < 1e-5
     if cfg["depth"] == 6:
@@ -60,7 +62,7 @@ def test_loss_pieces_match_reference(tag, golden_dir):
     assert abs(O.prototype_kl(er, yr, proto).item() - float(g["proto_kl_r"])) < 1e-5
 
 
-@pytest.mark.parametrize("tag", ["small_b5", "small2_b3"])
+@pytest.mark.parametrize("tag", ["small_b5", "small2_b3", "attn_small_b3"])
 def test_grads_small_match_reference(tag, golden_dir):
     cfg, b = CASES[tag]
     g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
