@@ -1,12 +1,14 @@
 """Step helpers of the reference's util/utils.py that sit on the GS-LoRA path
 (AverageMeter :316-332, train_accuracy :354-368, count_trainable_parameters :423-425,
 reinitialize_lora_parameters :428-441, calculate_prototypes :502-549, replace_ffn_with_lora :552-577,
-modify_head :580-621, resume_head :623-636), backed by the HIP model.
+modify_head :580-621, resume_head :623-636, create_few_shot_dataset :457-499, get_unique_classes :444-454), backed by the HIP model.
 Data plumbing and face verification of that file are out of scope."""
 import copy
 import datetime
 import math
 import os
+import random
+from collections import defaultdict
 
 import torch
 import torch.nn as nn
@@ -78,6 +80,48 @@ def calculate_prototypes(backbone, dataset, batch_size=32, device="cuda", aug_nu
             counts.index_add_(0, labels, torch.ones_like(labels, dtype=torch.float32))
     sums, counts = sums.cpu(), counts.cpu()
     return {int(c): (sums[c] / counts[c]) for c in torch.nonzero(counts).flatten().tolist()}
+
+
+class CustomSubset(torch.utils.data.Subset):
+    """Subset that keeps `targets` / `classes` of the parent (reference image_iter.py:124-137)."""
+
+    def __init__(self, dataset, indices):
+        super().__init__(dataset, indices)
+        self.targets = dataset.targets
+        self.classes = dataset.classes
+
+    def __getitem__(self, idx):
+        return self.dataset[self.indices[idx]]
+
+    def __len__(self):
+        return len(self.indices)
+
+
+def get_unique_classes(subset, original_dataset):
+    """(class names, number of classes) of a subset (reference :444-454)."""
+    return subset.classes, len(subset.classes)
+
+
+def create_few_shot_dataset(dataset, n_shot, seed=None):
+    """n_shot random samples per class, shuffled — the same `random` call sequence as the reference (:457-499), so a given seed
+    selects the same indices (tests/golden/host_kats.npz)."""
+    if seed is not None:
+        random.seed(seed)
+    if not hasattr(dataset, "targets"):
+        raise AttributeError("The dataset object needs to have a 'targets' attribute to access the labels.")
+    targets = dataset.targets
+    if isinstance(targets, torch.Tensor):
+        targets = targets.tolist()
+    by_class = defaultdict(list)
+    for idx, label in enumerate(targets):
+        by_class[label].append(idx)
+    picked = []
+    for cls, indices in by_class.items():
+        if len(indices) < n_shot:
+            raise ValueError(f"Class {cls} has fewer samples than {n_shot}.")
+        picked.extend(random.sample(indices, n_shot))
+    random.shuffle(picked)
+    return CustomSubset(dataset, picked)
 
 
 def get_time():

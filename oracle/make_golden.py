@@ -250,8 +250,21 @@ def host_kats(out):
     logits = torch.tensor(recipe.uniform("kat_logits", (7, 10), 3))
     target = torch.tensor(recipe.make_labels({"num_class": 10}, 7, seed=3))
     acc = rutil.train_accuracy(logits, target, topk=(1,))
+    # few-shot sampler (util/utils.py:457-499) on a synthetic label list: 12 classes x 9 samples, 4 shots, seed 2024
+    class _DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.targets = [(7 * i + 3) % 12 for i in range(108)]
+            self.classes = [f"c{i}" for i in range(12)]
+
+        def __len__(self):
+            return len(self.targets)
+
+        def __getitem__(self, i):
+            return torch.tensor([float(i)]), self.targets[i]
+    fs = rutil.create_few_shot_dataset(_DS(), 4, seed=2024)
     np.savez(os.path.join(out, "host_kats.npz"), class_order=np.array(order), meter=np.array([m.val, m.avg, m.sum, m.count]),
-             train_acc=np.float32(acc.item()))
+             train_acc=np.float32(acc.item()), few_shot_indices=np.array(list(fs.indices), dtype=np.int64),
+             few_shot_first=np.array([float(fs[0][0]), float(fs[0][1]), float(len(fs))]))
     print("[golden] host_kats")
 
 
@@ -267,7 +280,7 @@ def main():
     for tag, cfg, b in cases:
         if not only or tag in only:
             run_case(tag, cfg, b, out, HYPER)
-    if not only:
+    if not only or "host_kats" in only:
         host_kats(out)
 
 

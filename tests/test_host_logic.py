@@ -271,3 +271,31 @@ def test_modified_vit_tree_names_and_surgery(tmp_path, monkeypatch):
 def test_vit_b16_parameter_count():
     from vit_pytorch_face.modified_VIT import vit_b_16
     assert sum(p.numel() for p in vit_b_16().parameters()) == 86_567_656      # torchvision's published vit_b_16 size
+
+
+def test_few_shot_sampler_matches_reference(golden_dir):
+    """util.utils.create_few_shot_dataset draws the same indices as the reference for a given seed (golden from the real function)."""
+    from image_iter import CustomSubset
+    from util.utils import create_few_shot_dataset, get_unique_classes
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.targets = [(7 * i + 3) % 12 for i in range(108)]
+            self.classes = [f"c{i}" for i in range(12)]
+
+        def __len__(self):
+            return len(self.targets)
+
+        def __getitem__(self, i):
+            return torch.tensor([float(i)]), self.targets[i]
+    g = np.load(os.path.join(golden_dir, "host_kats.npz"))
+    fs = create_few_shot_dataset(DS(), 4, seed=2024)
+    assert isinstance(fs, CustomSubset) and list(fs.indices) == list(g["few_shot_indices"])
+    assert [float(fs[0][0]), float(fs[0][1]), float(len(fs))] == list(g["few_shot_first"])
+    assert get_unique_classes(fs, None) == ([f"c{i}" for i in range(12)], 12)
+    counts = {}
+    for i in fs.indices:
+        counts[fs.targets[i]] = counts.get(fs.targets[i], 0) + 1
+    assert set(counts.values()) == {4}
+    with pytest.raises(ValueError):
+        create_few_shot_dataset(DS(), 10, seed=1)
