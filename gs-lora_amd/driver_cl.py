@@ -16,6 +16,7 @@ Sequence per task i:
   get_norm_of_lora(model); model.eval(); torch.save(state_dict) ; model.train()
 """
 import argparse
+import copy
 import os
 import random
 import sys
@@ -67,6 +68,9 @@ def get_args(argv=None):
     p.add_argument("--small", action="store_true", help="shrunken model (48 px, dim 128, depth 3) for tests")
     p.add_argument("--outdir", default=None)
     p.add_argument("--seed", type=int, default=1337)
+    p.add_argument("--average_weight", action="store_true", help="EMA model of the reference (:502-507, :1058-1098)")
+    p.add_argument("--ema_epoch", type=int, default=30)
+    p.add_argument("--ema_decay", type=float, default=0.9)
     return p.parse_args(argv)
 
 
@@ -106,6 +110,11 @@ def main(argv=None):
     x_all, y_all = synthetic_dataset(args.num_class, args.samples_per_class, geo["image_size"], args.seed)
     x_te, y_te = synthetic_dataset(args.num_class, 2, geo["image_size"], args.seed + 1)
     num_first = args.num_class - args.per_forget_cls           # classes not yet forgotten after task 0
+    ema_model = None
+    if args.average_weight:                                   # :502-507: a deep copy taken in eval() — its adapters are flagged MERGED
+        model.eval()
+        ema_model = copy.deepcopy(model).to(dev)
+        model.train()
     report = []
     for task_i in range(args.num_tasks):                      # :515
         if task_i > 0:                                        # :524-536
@@ -128,7 +137,7 @@ def main(argv=None):
         forget_before = engine_cl.eval_data(model, te_f, dev, f"forget-{task_i}-before")
         remain_before = engine_cl.eval_data(model, te_r, dev, f"remain-{task_i}-before")
         model.train()
-        batch, best_h, lrs = 0, 0.0, []
+        batch, best_h, lrs, ema_acc = 0, 0.0, [], None
         for epoch in range(args.epochs):                      # :1006
             scheduler.step(epoch)
             lrs.append(optimizer.param_groups[0]["lr"])
@@ -142,6 +151,20 @@ def main(argv=None):
                 use_prototype=True, prototype_dict=protos, prototype_weight_forget=args.pro_f_weight,
                 prototype_weight_remain=args.pro_r_weight, **m)
             batch, best_h = ret[0], ret[1]
+            if ema_model is not None:                         # :1058-1098. Reproduced as written: the TRAIN-mode (un-merged) parameters
+                with torch.no_grad():                         # are copied / averaged into a model whose adapters stay flagged merged.
+                    snap = copy.deepcopy(model)
+                    ema_model.eval()
+                    if epoch == args.ema_epoch:
+                        for p_, e_ in zip(snap.parameters(), ema_model.parameters()):
+                            e_.data = p_.data.detach()
+                    elif epoch > args.ema_epoch:
+                        for p_, e_ in zip(snap.parameters(), ema_model.parameters()):
+                            e_.data = e_.data.detach() * args.ema_decay + p_.data.detach() * (1 - args.ema_decay)
+                    if epoch >= args.ema_epoch:
+                        ema_acc = (engine_cl.eval_data(ema_model, te_f, dev, f"forget-ema-{task_i}", batch),
+                                   engine_cl.eval_data(ema_model, te_r, dev, f"remain-ema-{task_i}", batch))
+                model.train()
         norms = [float(v) for v in get_norm_of_lora(model, type="L2", group_num=geo["depth"], group_type="block")]   # :1100-1106
         forget_after = engine_cl.eval_data(model, te_f, dev, f"forget-{task_i}-after")
         remain_after = engine_cl.eval_data(model, te_r, dev, f"remain-{task_i}-after")
@@ -149,10 +172,11 @@ def main(argv=None):
         torch.save(model.state_dict(), os.path.join(out, "task-level", f"Backbone_task_{task_i}.pth"))
         model.train()
         report.append(dict(task=task_i, forget_cls=forget_cls, steps=batch, lrs=lrs, norms=norms, total_loss=ret[6].avg if ret[6].count else None,
-                           forget_before=forget_before, forget_after=forget_after, remain_before=remain_before, remain_after=remain_after))
+                           forget_before=forget_before, forget_after=forget_after, remain_before=remain_before, remain_after=remain_after,
+                           ema_acc=ema_acc))
         print(f"[task {task_i}] steps={batch} lr={lrs} norms={[round(v, 3) for v in norms]} "
               f"forget {forget_before:.1f}->{forget_after:.1f}  remain {remain_before:.1f}->{remain_after:.1f}")
-    return report, out, model
+    return report, out, (model if ema_model is None else (model, ema_model))
 
 
 if __name__ == "__main__":

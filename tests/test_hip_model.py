@@ -420,6 +420,28 @@ def test_own_cl_driver_two_tasks(tmp_path):
     assert (ref - got).abs().max() < 1e-4
 
 
+def test_own_cl_driver_ema_model_reproduces_reference_quirk(tmp_path):
+    """--average_weight (reference train_own_forget_cl.py:502-507, 1058-1098): the EMA model is a deep copy taken in eval() — its
+    adapters stay flagged merged — into which the TRAIN-mode (un-merged) parameters are copied / averaged. Reproduced, not fixed: at
+    epoch == ema_epoch the EMA model therefore evaluates the frozen backbone without the current adapters."""
+    import driver_cl
+    rep, out, (model, ema) = driver_cl.main(["--small", "--num_class", "20", "--num_tasks", "1", "--per_forget_cls", "4", "--epochs", "2",
+                                             "--batch_size", "16", "--samples_per_class", "4", "--dtype", "fp32", "--dropout", "0.0",
+                                             "--average_weight", "--ema_epoch", "1", "--outdir", str(tmp_path)])
+    assert rep[0]["ema_acc"] is not None and all(0.0 <= a <= 100.0 for a in rep[0]["ema_acc"])
+    assert all(blk.l1.merged and blk.l2.merged for blk in ema.hip_spec().blocks)
+    x = torch.rand(3, 3, 48, 48).cuda(); y = torch.tensor([1, 2, 3]).cuda()
+    base = copy.deepcopy(model).train()           # the trained model with its adapters zeroed = frozen backbone only
+    with torch.no_grad():
+        for n, p in base.named_parameters():
+            if n.endswith("lora_B"):
+                p.zero_()
+        want, _ = base(x, y)
+        ema.eval()
+        got, _ = ema(x, y)
+    assert (want - got).abs().max() < 1e-4
+
+
 def _fresh(cfg, dtype="fp32"):
     from gslora_hip.optim import FusedAdamW
     m = build(cfg, dtype).train()
