@@ -437,3 +437,28 @@ def test_lora_grad_mfma_matches_valu_kernel(ops, M, N, r, monkeypatch):
         got[mode] = G.cpu() / 2
         assert relerr(got[mode], ref) < 2e-5, mode
     assert relerr(got["1"], got["0"]) < 2e-6
+
+
+def test_data_prefetcher_ring_delivers_batches_in_order(ops):
+    """Pinned-buffer ring on a copy stream: host batches arrive on the device in order and intact (more batches than ring slots, a
+    ragged last batch), `(None, None)` marks exhaustion, device-resident batches pass through, prefetch=False takes the plain path."""
+    from util.data_prefetcher import data_prefetcher
+    host = [(torch.full((4 if i < 6 else 2, 3, 8, 8), float(i)), torch.full((4 if i < 6 else 2,), i, dtype=torch.int64)) for i in range(7)]
+    for prefetch in (True, False):
+        pf = data_prefetcher(host, torch.device("cuda"), prefetch=prefetch)
+        seen = []
+        while True:
+            x, y = pf.next()
+            if x is None:
+                assert y is None
+                break
+            assert x.is_cuda and y.is_cuda
+            seen.append((x.clone(), y.clone()))
+        assert len(seen) == 7
+        for i, (x, y) in enumerate(seen):
+            assert x.shape[0] == (4 if i < 6 else 2) and bool((x == float(i)).all()) and bool((y == i).all())
+        assert pf.next() == (None, None)
+    dev_batches = [(torch.ones(2, 3, device="cuda") * i, torch.tensor([i, i], device="cuda")) for i in range(3)]
+    pf = data_prefetcher(dev_batches, torch.device("cuda"), prefetch=True)
+    x0, _ = pf.next()
+    assert x0.data_ptr() == dev_batches[0][0].data_ptr()
