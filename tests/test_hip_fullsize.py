@@ -1,0 +1,108 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL size (configs[1]: ViT-P8S8 depth 6, r = 8, batch 512 + 512,
+bf16 speed mode) — where the CPU oracle is too slow to serve as a checker:
+  * exact linearity of the backward in the upstream gradient (scaling the loss by 2 scales every LoRA gradient by exactly 2),
+  * fused (remain + forget in one forward) == two forwards, bit for bit on the logits,
+  * LayerNorm invariants of the embedding, softmax-gradient rows summing to zero, group norms summing to the structure loss,
+  * dropout: same seed -> identical activations, keep rate 0.9 +- 0.001, masks differ between sites,
+  * batch-permutation invariance of the summed LoRA gradient (up to the summation order)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B = 512
+
+
+@pytest.fixture(scope="module")
+def full():
+    import loralib as lora
+    from vit_pytorch_face import ViT_face
+    torch.manual_seed(1337)
+    m = ViT_face(loss_type="CosFace", GPU_ID=[0], num_class=100, image_size=112, patch_size=8, dim=512, depth=6, heads=8, mlp_dim=2048,
+                 dropout=0.0, emb_dropout=0.0, lora_rank=8)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0.0, 0.02)
+    lora.mark_only_lora_as_trainable(m)
+    m = m.cuda().set_compute_dtype("bf16").train()
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randint(0, 256, (2 * B, 3, 112, 112), generator=g, dtype=torch.uint8).float() / 255.0).cuda()
+    y = torch.randint(0, 100, (2 * B,), generator=g).cuda()
+    return m, x, y
+
+
+def lora_grad_vector(m):
+    return torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).clone()
+
+
+def loss_of(m, x, y, scale=1.0):
+    from gslora_hip import losses
+    lo, em = m(x, y)
+    return scale * (losses.ce_sum_top1(lo, y)[0] / x.shape[0] + 1e-3 * em.float().pow(2).mean()), lo, em
+
+
+def test_backward_is_exactly_linear_in_the_upstream_gradient(full):
+    m, x, y = full
+    m.zero_grad()
+    loss_of(m, x, y, 1.0)[0].backward()
+    g1 = lora_grad_vector(m)
+    m.zero_grad()
+    loss_of(m, x, y, 2.0)[0].backward()
+    g2 = lora_grad_vector(m)
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert torch.equal(g2, 2.0 * g1)          # power-of-two scaling commutes with every bf16 / f32 rounding on the path
+
+
+def test_fused_forward_equals_two_forwards_and_ln_invariants(full):
+    m, x, y = full
+    with torch.no_grad():
+        lo, em = m(x, y)
+        lo_a, em_a = m(x[:B], y[:B])
+        lo_b, em_b = m(x[B:], y[B:])
+    assert torch.equal(lo[:B], lo_a) and torch.equal(lo[B:], lo_b) and torch.equal(em[:B], em_a) and torch.equal(em[B:], em_b)
+    # mlp_head LayerNorm has gamma = 1, beta = 0 at construction: every embedding row is standardised
+    assert em.mean(1).abs().max() < 1e-4 and (em.var(1, unbiased=False) - 1).abs().max() < 1e-3
+    # CosFace: |logit| <= s * (1 + m)
+    assert lo.abs().max() <= 64.0 * 1.35 + 1e-3
+
+
+def test_loss_kernels_invariants_at_full_batch(full):
+    from gslora_hip import losses, ops
+    m, x, y = full
+    with torch.no_grad():
+        lo, _ = m(x, y)
+    lo = lo.float().contiguous()
+    coef = torch.ones(1, device="cuda")
+    dl = ops.ce_bwd(lo, y, coef, 1.0)
+    assert dl.sum(1).abs().max() < 1e-5                                   # softmax - onehot: rows sum to zero
+    assert abs(dl.gather(1, y[:, None]).sum().item() + (1 - torch.softmax(lo, 1).gather(1, y[:, None])).sum().item()) < 1e-2
+    rep = losses.group_report(m, "block", tau=0.0)
+    sl = losses.structure_loss(m, "block")
+    assert abs(rep["group_norm"].sum().item() - sl.item()) < 1e-5 * max(1.0, sl.item())
+    want = torch.stack([torch.sqrt(sum((p.detach().float() ** 2).sum() for p in blk.lora_params())) for blk in m.hip_spec().blocks])
+    assert torch.equal(rep["mask"].bool().cpu(), (want > 0).cpu()) and (rep["group_norm"] - want).abs().max() < 1e-4
+
+
+def test_dropout_determinism_and_rate_at_full_size(full):
+    from gslora_hip import ops
+    n = 2 * B * 197 * 2048                                                # one FFN hidden activation of the full batch
+    k1 = ops.dropout_mask(n, 0.1, 1234, 5, "cuda")
+    k2 = ops.dropout_mask(n, 0.1, 1234, 5, "cuda")
+    k3 = ops.dropout_mask(n, 0.1, 1234, 9, "cuda")
+    assert torch.equal(k1, k2) and not torch.equal(k1, k3)
+    rate = k1.float().mean().item()
+    assert abs(rate - 0.9) < 1e-3
+    agree = (k1 == k3).float().mean().item()                              # independent sites: agreement = 0.9^2 + 0.1^2
+    assert abs(agree - 0.82) < 2e-3
+
+
+def test_summed_gradient_is_invariant_to_batch_order(full):
+    m, x, y = full
+    m.zero_grad()
+    loss_of(m, x, y)[0].backward()
+    g1 = lora_grad_vector(m)
+    perm = torch.randperm(2 * B, generator=torch.Generator().manual_seed(3)).cuda()
+    m.zero_grad()
+    loss_of(m, x[perm], y[perm])[0].backward()
+    g2 = lora_grad_vector(m)
+    assert float((g1 - g2).norm() / g1.norm()) < 2e-3                      # only the (bf16-operand, f32-accumulate) summation order differs
