@@ -140,6 +140,7 @@ def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale):
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
@@ -153,7 +154,9 @@ def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
     key = (Y.device.index,)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(need, device=Y.device, dtype=torch.float32)
+        if ws is not None:
+            _ws_retired.append(ws)      # a captured HIP graph may still launch with the old workspace: never free it
+        ws = torch.empty(max(need, 1 << 22), device=Y.device, dtype=torch.float32)
         _ws_cache[key] = ws
     L.check(lib.gsl_lora_grad(_p(Y), Y.stride(0), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype),
                               1 if accumulate else 0, _p(ws), _stream()), "gsl_lora_grad")

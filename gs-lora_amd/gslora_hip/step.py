@@ -119,12 +119,15 @@ class GraphedStep:
     also refreshes the operand caches) followed by a fresh capture. Replays are bit-identical to eager steps (same kernels, same
     seeds; tests/test_hip_graph.py). Single process only: with torch.distributed initialised the step stays eager."""
 
+    MAX_GRAPHS = 3      # captured configurations kept (e.g. the regular batch and the ragged last batches of the two loaders)
+
     def __init__(self, model, optimizer, criterion):
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
         self.net = model.module if isinstance(model, nn.DataParallel) else model
         self._frozen = [p for n, p in self.net.named_parameters() if "lora_" not in n]
-        self.key = self.pending = self.graph = self.static = None
-        self.seed_dev, self._seed_val, self._nfwd = None, None, 0
+        self.graphs = {}            # key -> dict(graph, static, nfwd), insertion-ordered (oldest evicted)
+        self.pending = None         # key seen once (ran eagerly); captured at its second sighting
+        self.seed_dev, self._seed_val = None, None
         self.replays = self.captures = self.eager_steps = 0
 
     def _key(self, x_r, y_r, x_f, y_f, kw):
@@ -145,14 +148,21 @@ class GraphedStep:
         if not self._usable():
             return self._eager(x_r, y_r, x_f, y_f, kw)
         key = self._key(x_r, y_r, x_f, y_f, kw)
-        if key != self.key:
+        ent = self.graphs.get(key)
+        if ent is None:
             if key != self.pending or not self.optimizer.graph_capturable():
                 # first sighting of this configuration: one eager step (warms operand caches, optimizer state, gradient bucket)
-                self.pending, self.key, self.graph = key, None, None
+                self.pending = key
                 return self._eager(x_r, y_r, x_f, y_f, kw)
-            self._capture(x_r, y_r, x_f, y_f, kw)
-            self.key, self.pending = key, None
-        xr, yr, xf, yf = self.static[:4]
+            ent = self._capture(x_r, y_r, x_f, y_f, kw)
+            frozen_now = key[6]
+            for k in [k for k in self.graphs if k[6] != frozen_now]:      # graphs captured against older frozen weights are stale
+                del self.graphs[k]
+            while len(self.graphs) >= self.MAX_GRAPHS:
+                del self.graphs[next(iter(self.graphs))]
+            self.graphs[key] = ent
+            self.pending = None
+        xr, yr, xf, yf = ent["static"][:4]
         xr.copy_(x_r, non_blocking=True)
         yr.copy_(y_r, non_blocking=True)
         xf.copy_(x_f, non_blocking=True)
@@ -164,32 +174,33 @@ class GraphedStep:
         if self._seed_val != want:
             self.seed_dev.fill_(want)
             self._seed_val = want
-        self.graph.replay()
-        r.drop_calls += self._nfwd
-        self._seed_val += self._nfwd
+        ent["graph"].replay()
+        r.drop_calls += ent["nfwd"]
+        self._seed_val += ent["nfwd"]
         self.optimizer.graph_replayed()
         self.replays += 1
-        return self.static[4].clone()
+        return ent["static"][4].clone()
 
     def _capture(self, x_r, y_r, x_f, y_f, kw):
         r = self.net.runner()
-        self.static = [x_r.clone(), y_r.clone(), x_f.clone(), y_f.clone(), None]
+        static = [x_r.clone(), y_r.clone(), x_f.clone(), y_f.clone(), None]
         if self.seed_dev is None:
             self.seed_dev = torch.zeros(1, device=x_r.device, dtype=torch.int64)
         self._seed_val = None
         self.optimizer.graph_sync()
         calls0 = r.drop_calls
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         self.optimizer.graph_mode, r.seed_dev = True, self.seed_dev
         try:
-            with torch.cuda.graph(self.graph):
-                self.static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *self.static[:4], **kw)
+            with torch.cuda.graph(graph):
+                static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *static[:4], **kw)
         finally:
             self.optimizer.graph_mode, r.seed_dev = False, None     # eager forwards keep passing the seed by value
-            self._nfwd = r.drop_calls - calls0
+            nfwd = r.drop_calls - calls0
             r.drop_calls = calls0                                     # nothing ran during capture
         self.captures += 1
+        return dict(graph=graph, static=static, nfwd=nfwd)
 
 
 def graphed_step_for(model, optimizer, criterion):

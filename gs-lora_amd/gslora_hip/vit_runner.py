@@ -120,7 +120,7 @@ class ViTRunner:
         self.bucket = None
         self._wcache = {}
         self._lcache = {}
-        self._packs, self._pack_tables = {}, {}
+        self._packs, self._pack_tables, self._retired = {}, {}, []
         self._rank = 0
         self.seed_dev = None      # int64 [1] device tensor: dropout seed of a step that is being captured / replayed as a HIP graph
         self.drop_seed = 0x5EED
@@ -237,6 +237,8 @@ class ViTRunner:
         ents = [e for k, e in self._packs.items() if k[2] == dtype]
         tab = self._pack_tables.get(dtype)
         if ents and (tab is None or tab[2] != len(ents)):
+            if tab is not None:
+                self._retired.append(tab[0])      # a captured HIP graph may still launch with the old table: never free it
             t, mx = ops.pack_desc_table([(e["param"], *e["geom"], 1.0, e["out"]) for e in ents], ents[0]["dev"])
             tab = self._pack_tables[dtype] = (t, mx, len(ents))
         return tab
@@ -254,6 +256,8 @@ class ViTRunner:
         if self.bucket is None or not self.bucket.valid() or any(a is not b for a, b in zip(self.bucket.params, (p for g in layers for p in g))):
             self.bucket = LoraBucket(layers)
             self._lcache.clear()
+            self._retired.extend(t[0] for t in self._pack_tables.values())
+            self._retired.extend(e["out"] for e in self._packs.values())
             self._packs.clear()
             self._pack_tables.clear()
         return self.bucket

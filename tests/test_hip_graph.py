@@ -98,3 +98,27 @@ def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path):
     assert res[False][0] == res["auto"][0]
     for n in res[False][1]:
         assert torch.equal(res[False][1][n], res["auto"][1][n]), n
+
+
+def test_graphs_of_several_batch_shapes_are_kept():
+    """A ragged last batch does not throw away the graph of the regular batch: both configurations are captured once and replayed,
+    bit-identical to eager steps on a twin model."""
+    from gslora_hip.optim import FusedAdamW
+    from gslora_hip.step import GraphedStep, gs_lora_step
+    cfg = recipe.cfg_small2()
+    m1 = build(cfg, "bf16", 0.1)
+    m2 = copy.deepcopy(m1)
+    mk_opt = lambda m: FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    o1, o2 = mk_opt(m1), mk_opt(m2)
+    crit = torch.nn.CrossEntropyLoss()
+    kw = dict(beta=0.15, alpha=1e-2, BND=105.0, use_structure=True, group_type="block")
+    g = GraphedStep(m2, o2, crit)
+    for s, b in enumerate([6, 6, 6, 4, 6, 4, 4, 6]):
+        xr, yr, xf, yf = batch(cfg, b, s)
+        p1 = gs_lora_step(m1, o1, crit, xr, yr, xf, yf, **kw)
+        p2 = g(xr, yr, xf, yf, **kw)
+        assert torch.equal(p1, p2), (s, b)
+    for (n, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()):
+        if a.requires_grad:
+            assert torch.equal(a, c), n
+    assert (g.eager_steps, g.captures, g.replays) == (2, 2, 6) and len(g.graphs) == 2
