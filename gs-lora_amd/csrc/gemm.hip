@@ -267,23 +267,25 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
 // BIAS_RES_F32 epilogue (out-proj / FFN2 forward: x + drop(acc + bias), f32 stream): same staging, the residual is loaded and the
 // result stored as full 256-byte rows (16 lanes x 16 B per row, 4 rows per instruction) instead of 64-byte fragment rows.
 // Arithmetic identical to epi_math<BIAS_RES_F32>: (alpha * acc + bias) * mask + res.
-template <int NI>
+template <int NI, int EPI = GSL_EPI_BIAS_RES_F32>
 __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 4, cq = lane & 15;      // copy phase: row-in-group, 4-float column group
   float* out = reinterpret_cast<float*>(e.out);
   const int n = nw + cq * 4;
-  f32x4_t b4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t b4 = f32x4_t{0.f, 0.f, 0.f, 0.f}, c4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (n < e.N) b4 = *reinterpret_cast<const f32x4_t*>(e.bias + n);
+  if constexpr (EPI == GSL_EPI_PATCH) { if (n < e.N) c4 = *reinterpret_cast<const f32x4_t*>(e.cls + n); }
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {          // 32 rows at a time: 8 residual loads in flight per lane
-      f32x4_t rs[8];
+      f32x4_t rs[8];      // BIAS_RES_F32: the residual rows; PATCH: the position-embedding rows of the tokens (vit_face.py:531-537)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int m = min(mw + ib * 16 + half * 32 + r * 4 + crow, e.M - 1);
-        rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
+        if constexpr (EPI == GSL_EPI_PATCH) rs[r] = *reinterpret_cast<const f32x4_t*>(e.pos + (size_t)(m % e.T) * e.N + min(n, e.N - 4));
+        else rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
       }
       if (half == 0) {
 #pragma unroll
@@ -303,8 +305,14 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
         float dm[4];
         drop_mul4(e.drop, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, dm);
         f32x4_t o;
+        if constexpr (EPI == GSL_EPI_PATCH) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout
+          const bool is_cls = (m % e.T) == 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
+          for (int k = 0; k < 4; ++k) o[k] = ((is_cls ? c4[k] : c[k] + b4[k]) + rs[r][k]) * dm[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
+        }
         if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
       }
     }
@@ -834,10 +842,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
   }
-  if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
-    if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4) {
+  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_PATCH) {
+    if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4 && (EPI != GSL_EPI_PATCH || e.ldo == e.N)) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
-      epilogue_staged_res_f32<8>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+      epilogue_staged_res_f32<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
       return;
     }
   }

@@ -56,7 +56,10 @@ def test_gemm_store_asymmetric(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64)])
+# the last two shapes (170 images x 197 tokens: 131 M-tiles of 256 with a ragged last tile) run the 8-phase 256x256 kernel and its
+# staged full-row epilogues in bf16 mode
+@pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64),
+                                       (33490, 512, 192, 0), (33490, 2048, 512, 64)])
 def test_gemm_epilogues(ops, dt, M, N, K1, K2):
     from gslora_hip import _lib as L
     A1, W1 = rnd(M, K1, seed=1), rnd(N, K1, seed=2, scale=K1 ** -0.5)
@@ -88,8 +91,9 @@ def test_gemm_epilogues(ops, dt, M, N, K1, K2):
     a = (acc + bias).requires_grad_(True)
     g = F.gelu(a)
     gp, = torch.autograd.grad(g.sum(), a)
-    assert (out.float().cpu() - g.detach()).abs().max() < t_abs
-    assert (out2.float().cpu() - gp).abs().max() < t_abs
+    ulp = 0.0 if dt == torch.float32 else 2.0 ** -8       # bf16 outputs: one rounding of the stored value on top of the absolute slack
+    assert ((out.float().cpu() - g.detach()).abs() - ulp * g.detach().abs()).max() < t_abs
+    assert ((out2.float().cpu() - gp).abs() - ulp * gp.abs()).max() < t_abs
     # MUL
     ops.gemm_nt(c(A1), c(W1), out, epilogue=L.EPI_MUL, A2=c(A2), W2=c(W2), aux=c(aux))
     assert relerr(out.float().cpu(), acc * as_dt(aux, dt)) < t_out
