@@ -41,6 +41,11 @@ struct EpiArgs {
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
   int stmode;  // output store flavour of the staged bf16 epilogue (development knob GSL_STORE_MODE, see store_stream16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
+  // gradient-fused MUL epilogue (gsl_gemm_nt_lora_mulgrad): operands of the two LoRA-gradient reductions that consume this tile
+  const bf16_t* gu1; int ldgu1;   // U1 [M, >= 16]: G1[n, j] = sum_m out[m, n] * U1[m, j]
+  const bf16_t* gy2;              // Y2 [M, N] (row stride ldo): G2[n, j] = sum_m Y2[m, n] * t[m, j]
+  float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
+  int gR;                         // 8 or 16
 };
 
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
@@ -262,6 +267,135 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
       }
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), e.stmode);
     }
+  }
+}
+// MUL epilogue with the two LoRA-gradient reductions of its tile fused in (FFN2-dX: out = dZ = (dY W2 + t A2) * GELU'):
+//   G1[n, j] = sum_m dZ[m, n] * U1[m, j]     (dB1: the standalone reduction re-reads the [M, N] tile this epilogue just produced)
+//   G2[n, j] = sum_m Y2[m, n] * t[m, j]      (dA2: Y2 = h has the shape and tiling of aux; t = s dY B2^T already sits in LDS)
+// Both are contractions over the ROW index, i.e. operands with the contraction index slow: the bf16 tiles go through wave-private
+// LDS slabs and are gathered with ds_read_b64_tr_b16 exactly as in lora_grad_mfma_kernel (lora.hip); the matrix pipe is idle
+// during the epilogue, so the 16 MFMAs per 32 rows are free. 32-row chunks keep four disjoint regions per wave:
+//   [f32 accumulators 32 x 68][dZ 32 x 72 bf16][Y2 32 x 72 bf16][U1 32 x 16 bf16]; t lives behind the wave regions as [256][16].
+// The two wave rows are summed through LDS, and every M tile writes its [256 cols][R] partial (fixed-order reduction afterwards).
+constexpr int GF_STAGE_B = 32 * CLF * 4;                        // 8704
+constexpr int GF_Y_B = 32 * CLD * 2;                            // 4608
+constexpr int GF_U_B = 32 * 16 * 2;                             // 1024
+constexpr int GF_WAVE_B = GF_STAGE_B + 2 * GF_Y_B + GF_U_B;     // 18944
+constexpr int GF_T16_B = 256 * 16 * 2;                          // 8192
+constexpr int GF_BLOCK_B = 8 * GF_WAVE_B + GF_T16_B;            // 159744 of the CU's 163840 bytes
+typedef short gf_v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) gf_v4s_t* gf_lds_v4s_p;
+union GfFrag { gf_v4s_t h[2]; bf16x8_t v; };
+template <int NI>
+__device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_t (&acc)[NI][4], char* wreg, char* partner,
+                                                        const bf16_t* t16w, int mw, int nw, int lane, int wm, int mtile) {
+  float* cst = reinterpret_cast<float*>(wreg);
+  bf16_t* yd = reinterpret_cast<bf16_t*>(wreg + GF_STAGE_B);
+  bf16_t* yh = reinterpret_cast<bf16_t*>(wreg + GF_STAGE_B + GF_Y_B);
+  bf16_t* ub = reinterpret_cast<bf16_t*>(wreg + GF_STAGE_B + 2 * GF_Y_B);
+  const int fr = lane & 15, fc = lane >> 4;
+  const int crow = lane >> 3, cch = lane & 7;
+  const int trow = 4 * fc + (fr >> 2), tcol = (fr & 3) * 4;      // this lane's piece of a 4 x 16 block (transpose-read address)
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
+  bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
+  f32x4_t g1[4], g2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) g1[t] = g2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ic = 0; ic < NI / 2; ++ic) {
+    uint4 ax[4], hx[4], u1a, u1b;
+    const int ncl = min(nw + cch * 8, e.N - 8);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mw + ic * 32 + r * 8 + crow;
+      ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)min(m, e.M - 1) * e.ldo + ncl);
+      hx[r] = (m < e.M) ? *reinterpret_cast<const uint4*>(e.gy2 + (size_t)m * e.ldo + ncl) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    {
+      const int m = mw + ic * 32 + (lane & 31);
+      const bf16_t* up = e.gu1 + (size_t)min(m, e.M - 1) * e.ldgu1;
+      u1a = *reinterpret_cast<const uint4*>(up);
+      u1b = *reinterpret_cast<const uint4*>(up + 8);
+      if (m >= e.M) u1a = u1b = make_uint4(0u, 0u, 0u, 0u);      // rows past M contribute nothing (their dZ is finite: clamped operands)
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t v = acc[ic * 2 + ii][j];
+        if (e.alpha != 1.0f) v *= e.alpha;
+        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r * 8 + crow;
+      const int m = mw + ic * 32 + row, n = nw + cch * 8;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
+      const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
+        o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+      }
+      const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, e.stmode);
+      *reinterpret_cast<uint4*>(yd + row * CLD + cch * 8) = ov;
+      *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = hx[r];
+    }
+    if (lane < 32) {
+      *reinterpret_cast<uint4*>(ub + lane * 16) = u1a;
+      *reinterpret_cast<uint4*>(ub + lane * 16 + 8) = u1b;
+    }
+    asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
+    GfFrag b1, b2;
+    b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
+    b1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + (trow + 16) * 16 + tcol));
+    const bf16_t* tb = t16w + ic * 32 * 16;
+    b2.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(tb + trow * 16 + tcol));
+    b2.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(tb + (trow + 16) * 16 + tcol));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      GfFrag a1, a2;
+      const bf16_t* p1 = yd + trow * CLD + t * 16 + tcol;
+      const bf16_t* p2 = yh + trow * CLD + t * 16 + tcol;
+      a1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p1));
+      a1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p1 + 16 * CLD));
+      a2.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p2));
+      a2.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p2 + 16 * CLD));
+      g1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, b1.v, g1[t], 0, 0, 0);
+      g2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2.v, b2.v, g2[t], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+  // g?[t][r] = G?[n = nw + t*16 + 4*fc + r][j = fr]: add the two wave rows (wm = 1 hands over through its own region), then one
+  // [64 cols][R] partial per wave column of the M tile
+  __syncthreads();
+  if (wm == 1) {
+    float* x = reinterpret_cast<float*>(wreg);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[(t * 16 + 4 * fc + r) * 32 + fr] = g1[t][r];
+        x[(t * 16 + 4 * fc + r) * 32 + 16 + fr] = g2[t][r];
+      }
+  }
+  __syncthreads();
+  if (wm == 0 && fr < e.gR) {
+    const float* x = reinterpret_cast<const float*>(partner);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nl = t * 16 + 4 * fc + r, n = nw + nl;
+        if (n < e.N) {
+          const size_t o = ((size_t)mtile * e.N + n) * e.gR + fr;
+          e.gpart1[o] = g1[t][r] + x[nl * 32 + fr];
+          e.gpart2[o] = g2[t][r] + x[nl * 32 + 16 + fr];
+        }
+      }
   }
 }
 // BIAS_RES_F32 epilogue (out-proj / FFN2 forward: x + drop(acc + bias), f32 stream): same staging, the residual is loaded and the
@@ -643,14 +777,19 @@ constexpr int ST4L = (BM4 + BN4 + 16) * BK;
 // LORA = true: the in-kernel LoRA form of gemm_bf16_t256_lora_kernel (below) on this schedule — the 16 rows of P ride along
 // with piece B-h0 (one extra DMA for waves 0 and 1, so their counted wait is vmcnt(7)), the P fragment is read in q0 next to B-h0,
 // and a wave issues its 4 extra MFMAs (2 of its row-half's 8 row fragments x 2 k-steps) in q0 (wn < 2) or q2 (wn >= 2).
-template <int EPI, bool LORA>
+// GRAD = true (MUL epilogue + LORA only): the LoRA-gradient reductions of the tile are fused into the epilogue (epilogue_staged_mulgrad);
+// t is then kept as [256][16] behind the staging regions so that it survives the epilogue.
+template <int EPI, bool LORA, bool GRAD = false>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                            const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                            const bf16_t* __restrict__ A2, int lda2,
                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
   resolve_drop(e.drop);
   constexpr int STG = LORA ? ST4L : ST4;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8];   // stages, then C staging
+  static_assert(!GRAD || (LORA && EPI == GSL_EPI_MUL), "GRAD is the gradient-fused form of the in-kernel-LoRA MUL GEMM");
+  static_assert(!GRAD || 2 * STG * 2 <= 8 * GF_WAVE_B, "t16 must lie behind the K-loop stages");
+  constexpr int SMEM_E = GRAD ? GF_BLOCK_B / 2 : ((2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8);
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_E];   // stages, then C staging
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -806,7 +945,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   }
 #undef GSL_P8_MFMA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
-  if constexpr (LORA) {
+  if constexpr (LORA && GRAD) {
+    // same as below with t kept as [256][16] behind the staging regions (the K-loop stages end before it: no barrier needed first)
+    bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16_t* d = t16 + (wm * 128 + (2 * wn + t) * 16 + fr) * 16 + fc * 4;
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
+    }
+    __syncthreads();
+    if (n0 == 0 && lk.tout) {
+      const int row = tid >> 1, half = tid & 1;
+      if (m0 + row < e.M) {
+        bf16_t* dst = lk.tout + (size_t)(m0 + row) * lk.ldt + half * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint4 v = (half || c >= 2) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(t16 + row * 16 + c * 8);
+          *reinterpret_cast<uint4*>(dst + c * 8) = v;
+        }
+      }
+    }
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(t16 + (wm * 128 + i * 16 + fr) * 16 + (fc & 1) * 8);
+      if (fc >= 2) tf = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};       // k slots 16..31 of the rank-r k-step
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
+    epilogue_staged_mulgrad<8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
+                               t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4);
+    return;
+  } else if constexpr (LORA) {
     // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
     __builtin_amdgcn_s_barrier();                      // stages are free
     bf16_t* tbuf = smem;
@@ -1282,3 +1459,80 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
 #undef GSL_LL
   return check_launch("gsl_gemm_nt_lora");
 }
+
+// =====================================================================================
+// FFN2-dX with its two LoRA-gradient reductions fused into the epilogue (see epilogue_staged_mulgrad).
+// Partials [M tiles][N][R] of both gradients, then a two-level fixed-order reduction into the strided gradient views.
+// =====================================================================================
+constexpr int GF_FAN = 32;
+// level 1: thread (4 consecutive outputs, slab) sums GF_FAN consecutive M-tile partials
+__global__ __launch_bounds__(256) void mulgrad_reduce1_kernel(const float4* __restrict__ part, float4* __restrict__ part2, int NR4, int ntile,
+                                                              long which_stride4, long which_stride4_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NR4) return;
+  const float4* p = part + (size_t)blockIdx.z * which_stride4;
+  const int s0 = blockIdx.y * GF_FAN, s1 = min(ntile, s0 + GF_FAN);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = s0; sp < s1; ++sp) {
+    const float4 v = p[(size_t)sp * NR4 + idx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  part2[(size_t)blockIdx.z * which_stride4_out + (size_t)blockIdx.y * NR4 + idx] = a;
+}
+// level 2: fixed-order sum of the slabs, output strides, optional accumulate; blockIdx.y selects the gradient
+__global__ __launch_bounds__(256) void mulgrad_reduce2_kernel(const float* __restrict__ part2, long which_stride, float* G1, long g1sn, long g1sj,
+                                                              float* G2, long g2sn, long g2sj, int N, int R, int r, int nslab,
+                                                              int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * R) return;
+  const int n = idx / R, j = idx % R;
+  if (j >= r) return;
+  const float* p = part2 + (size_t)blockIdx.y * which_stride;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += p[(size_t)k * N * R + idx];
+  float* g = blockIdx.y ? (G2 + (size_t)n * g2sn + (size_t)j * g2sj) : (G1 + (size_t)n * g1sn + (size_t)j * g1sj);
+  *g = accumulate ? (*g + s) : s;
+}
+extern "C" long gsl_gemm_mulgrad_ws_elems(int M, int N, int r) {
+  const long R = (r <= 8) ? 8 : 16;
+  const long ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;
+  return 2 * (ntile + nslab) * (long)N * R;
+}
+extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+                                        int ldq, float lora_scale, void* tout, int ldt, int M, int N, const void* aux, void* out,
+                                        int ldo, const void* U1, int ldu1, float* G1, long g1sn, long g1sj, const void* Y2, float* G2,
+                                        long g2sn, long g2sj, int r, int accumulate, float* ws, gsl_stream_t s) {
+  GSL_CHECK_ARG(M > 0 && N >= 8 && (N % 8) == 0 && K > 0 && (K % 64) == 0, "M>0, N%8==0, K%64==0");
+  GSL_CHECK_ARG(A && W && P && Q && out && aux && U1 && G1 && Y2 && G2 && ws, "null operand");
+  GSL_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (ldp % 8) == 0 && (ldq % 8) == 0 && ldq >= 32 && (ldo % 8) == 0 && ldo >= N &&
+                (!tout || ((ldt % 8) == 0 && ldt >= 64)) && (ldu1 % 8) == 0 && ldu1 >= 16,
+                "leading dimensions (P [16,K], Q [N,>=32], tout [M,>=64], U1 [M,>=16], out/aux/Y2 [M,ldo])");
+  GSL_CHECK_ARG(r >= 1 && r <= 16, "r in [1,16]");
+  EpiArgs e;
+  e.alpha = 1.0f; e.bias = nullptr; e.res = nullptr; e.aux = aux; e.out = out; e.out2 = nullptr; e.ldo = ldo;
+  e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(0.f, 0, 0); e.M = M; e.N = N;
+  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
+  e.krot = 0;   // every N tile must accumulate t = s A P^T in the same K order: G2 contracts the tile-local t, which has to equal tout bit for bit
+  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  const int R = (r <= 8) ? 8 : 16;
+  const int ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;
+  const size_t NR = (size_t)N * R;
+  e.gu1 = (const bf16_t*)U1; e.ldgu1 = ldu1; e.gy2 = (const bf16_t*)Y2; e.gR = R;
+  e.gpart1 = ws; e.gpart2 = ws + (size_t)ntile * NR;
+  float* part2 = ws + 2 * (size_t)ntile * NR;
+  LoraInk lk;
+  lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
+  const int nb = ntile * ((N + BN4 - 1) / BN4);
+  hipStream_t st = as_stream(s);
+  hipLaunchKernelGGL((gemm_bf16_p8_kernel<GSL_EPI_MUL, true, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,
+                     ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);
+  int rc = check_launch("gsl_gemm_nt_lora_mulgrad");
+  if (rc) return rc;
+  const int NR4 = (int)(NR / 4);
+  hipLaunchKernelGGL(mulgrad_reduce1_kernel, dim3((NR4 + 255) / 256, nslab, 2), dim3(256), 0, st, (const float4*)ws, (float4*)part2, NR4,
+                     ntile, (long)((size_t)ntile * NR / 4), (long)((size_t)nslab * NR / 4));
+  hipLaunchKernelGGL(mulgrad_reduce2_kernel, dim3(((int)NR + 255) / 256, 2), dim3(256), 0, st, part2, (long)((size_t)nslab * NR), G1, g1sn,
+                     g1sj, G2, g2sn, g2sj, N, R, r, nslab, accumulate);
+  return check_launch("gsl_gemm_nt_lora_mulgrad(reduce)");
+}
+

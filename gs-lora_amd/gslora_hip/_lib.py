@@ -26,6 +26,9 @@ SIGNATURES = {
                     _vp, _vp, _i, _f, _u64, _u32, _vp],
     "gsl_gemm_nt_lora": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i,
                          _f, _u64, _u32, _vp],
+    "gsl_gemm_mulgrad_ws_elems": [_i, _i, _i],
+    "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
+                                 _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _f, _u64, _u32, _l, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
@@ -50,7 +53,7 @@ SIGNATURES = {
     "gsl_pack_pad_batch": [_vp, _i, _l, _i, _vp],
     "gsl_dropout_mask": [_vp, _l, _f, _u64, _u32, _vp],
 }
-_RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long}
+_RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long, "gsl_gemm_mulgrad_ws_elems": C.c_long}
 
 _lib = None
 

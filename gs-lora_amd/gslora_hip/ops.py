@@ -88,6 +88,30 @@ def gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, *, epilogue=L.EPI_STORE, bia
     return out
 
 
+def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True):
+    """out = (A W^T + t Q^T) * aux with t = lora_scale * A P^T (as gemm_nt_lora, epilogue MUL) and, from the same tiles,
+    G1[n*g1s[0] + j*g1s[1]] (+)= sum_m out[m,n] U1[m,j] and G2[n*g2s[0] + j*g2s[1]] (+)= sum_m Y2[m,n] t[m,j]."""
+    _need(A, W, P, Q, tout, out, aux, U1, Y2)
+    M, K = A.shape
+    N = W.shape[0]
+    if not (out.stride(0) == aux.stride(0) == Y2.stride(0) and U1.stride(1) == 1):
+        raise RuntimeError("gemm_nt_lora_mulgrad: out / aux / Y2 must share one row stride")
+    lib = L.load()
+    need = lib.gsl_gemm_mulgrad_ws_elems(M, N, r)
+    key = (A.device.index, "mulgrad")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _ws_retired.append(ws)
+        ws = torch.empty(need, device=A.device, dtype=torch.float32)
+        _ws_cache[key] = ws
+    L.check(lib.gsl_gemm_nt_lora_mulgrad(_p(A), A.stride(0), _p(W), W.stride(0), K, _p(P), P.stride(0), _p(Q), Q.stride(0),
+                                         float(lora_scale), _p(tout), 0 if tout is None else tout.stride(0), M, N, _p(aux), _p(out),
+                                         out.stride(0), _p(U1), U1.stride(0), G1.data_ptr(), g1s[0], g1s[1], _p(Y2), G2.data_ptr(),
+                                         g2s[0], g2s[1], r, 1 if accumulate else 0, _p(ws), _stream()), "gsl_gemm_nt_lora_mulgrad")
+    return out
+
+
 def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     _need(x, gamma, beta)
     y = torch.empty(M, D, device=x.device, dtype=dtype)

@@ -8,6 +8,8 @@ This is the host-side "engine" behind vit_pytorch_face.ViT_face.forward: it owns
   * the per-forward activation stash that the hand-written backward consumes.
 Reference semantics: vit_pytorch_face/vit_face.py:523-548 (forward), autograd of the same.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -15,6 +17,8 @@ from . import ops
 
 PADK = 64                                  # LoRA K-segment width fed to the GEMM (r zero-padded to 64)
 SITE_EMB = 1_000_000
+# development knob: 0 = the two [M, mlp] LoRA-gradient reductions run as separate gsl_lora_grad launches instead of inside the FFN2-dX epilogue
+FUSE_LORA_GRAD = os.environ.get("GSL_FUSE_LORA_GRAD", "1") != "0"
 
 
 class BlockSpec:
@@ -423,7 +427,14 @@ class ViTRunner:
             ink = self.lora_in_kernel(dt, Mrows)
             v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
-            if ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
+            fused_grads = ink and FUSE_LORA_GRAD
+            if fused_grads:
+                # v2 = s*dy*B2 is produced inside the dX GEMM, and the two gradient reductions that contract over the rows of its
+                # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
+                ops.gemm_nt_lora_mulgrad(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
+                                         self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, gp,
+                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r)
+            elif ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
                 ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                  self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=L.EPI_MUL, aux=gp)
             else:
@@ -431,7 +442,8 @@ class ViTRunner:
                 ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
                             W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp)
             ops.lora_grad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                # dB2[c, j]
-            ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)                # dA2[j, hid]
+            if not fused_grads:
+                ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)            # dA2[j, hid]
             v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             dxn2 = None
             if ink and i > 0:   # v1 = s*da*B1 is produced inside the FFN1-dX GEMM
@@ -440,7 +452,8 @@ class ViTRunner:
                                  self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols32", dt), s_lora, v1, dxn2)
             else:
                 ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
-            ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)                 # dB1[hid, j]
+            if not fused_grads:
+                ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)             # dB1[hid, j]
             ops.lora_grad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                # dA1[j, c]
             if i == 0:
                 break   # nothing below the layer-0 FFN input is trainable

@@ -81,6 +81,20 @@ int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
                      const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
                      float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
 
+/* The MUL form of gsl_gemm_nt_lora (FFN2-dX: out = (A W^T + t Q^T) * aux, bf16) with the two LoRA-gradient reductions that consume
+ * its tiles fused into the epilogue instead of two gsl_lora_grad launches that re-read [M,N] tensors from HBM:
+ *   G1[n*g1sn + j*g1sj] (+)= sum_m out[m,n] * U1[m,j]      (dB of the up-projection adapter: loralib autograd of vit_face.py:330)
+ *   G2[n*g2sn + j*g2sj] (+)= sum_m Y2[m,n] * t[m,j]        (dA of the down-projection adapter; Y2 = the saved FFN hidden activation)
+ * U1 [M, ldu1 >= 16] bf16 (columns r..15 zero or discarded), Y2 / aux / out [M,N] bf16 with row stride ldo, N % 8 == 0.
+ * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible). */
+long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
+int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
+                             const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
+                             int M, int N, const void* aux, void* out, int ldo,
+                             const void* U1, int ldu1, float* G1, long g1sn, long g1sj,
+                             const void* Y2, float* G2, long g2sn, long g2sj,
+                             int r, int accumulate, float* ws, gsl_stream_t s);
+
 /* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x f32 rows of length D at
  * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
 int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,

@@ -368,6 +368,44 @@ def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
     assert relerr(outf.cpu(), out2.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,r", [(1000, 512, 256, 8), (2560, 768, 128, 16), (4099, 2048, 512, 8)])
+def test_gemm_nt_lora_mulgrad_fused_reductions(ops, M, N, K, r, monkeypatch):
+    """FFN2-dX with both LoRA-gradient reductions of its tiles fused into the epilogue: `out` and `tout` are bit-identical to the
+    unfused MUL GEMM (run without its K-tile rotation: the fused kernel keeps one K order for all N tiles so that the tile-local
+    t it contracts equals tout bit for bit), and the gradients equal gsl_lora_grad on the same bf16 operands (f32 accumulation,
+    different summation order)."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    c = lambda t: t.cuda().to(dt)
+    A, W = c(rnd(M, K, seed=1)), c(rnd(N, K, seed=2, scale=K ** -0.5))
+    P = torch.zeros(16, K); P[:r] = rnd(r, K, seed=3, scale=K ** -0.5)
+    Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
+    P, Q = c(P), c(Q)
+    aux, Y2 = c(rnd(M, N, seed=7)), c(rnd(M, N, seed=8))
+    U1 = torch.zeros(M, 64); U1[:, :r] = rnd(M, r, seed=9)
+    U1 = c(U1)
+    s = 1.0 / r
+    tout0 = torch.empty(M, 64, device="cuda", dtype=dt); out0 = torch.empty(M, N, device="cuda", dtype=dt)
+    monkeypatch.setenv("GSL_KROT", "0")
+    ops.gemm_nt_lora(A, W, P, Q, s, tout0, out0, epilogue=L.EPI_MUL, aux=aux)
+    monkeypatch.delenv("GSL_KROT")
+    G1r = torch.zeros(N, r, device="cuda"); G2r = torch.zeros(r, N, device="cuda")
+    ops.lora_grad(out0, U1, G1r, r, 1, r, accumulate=False)
+    ops.lora_grad(Y2, tout0, G2r, 1, N, r, accumulate=False)
+    for acc_flag in (False, True):
+        tout = torch.full((M, 64), 3.0, device="cuda", dtype=dt); out = torch.empty(M, N, device="cuda", dtype=dt)
+        G1 = torch.full((N, r), 0.5, device="cuda"); G2 = torch.full((r, N), -0.25, device="cuda")
+        ops.gemm_nt_lora_mulgrad(A, W, P, Q, s, tout, out, aux, U1, G1, (r, 1), Y2, G2, (1, N), r, accumulate=acc_flag)
+        assert torch.equal(out, out0) and torch.equal(tout, tout0)
+        e1 = (G1 - (G1r + (0.5 if acc_flag else 0.0))).abs().max().item() / G1r.abs().max().item()
+        e2 = (G2 - (G2r + (-0.25 if acc_flag else 0.0))).abs().max().item() / G2r.abs().max().item()
+        assert e1 < 2e-5 and e2 < 2e-5, (e1, e2)
+    # and against an f64 contraction of the same bf16 values
+    ref1 = (out0.double().t() @ U1[:, :r].double()).float()
+    ref2 = (tout0[:, :r].double().t() @ Y2.double()).float()
+    assert relerr(G1r.cpu(), ref1.cpu()) < 1e-4 and relerr(G2r.cpu(), ref2.cpu()) < 1e-4
+
+
 # ---- entry points added for HIP-graph replay and launch-count reduction ---------------------------------------------------
 def test_adamw_dev_bit_identical_to_value_form(ops):
     """gsl_adamw_flat_dev (step count / lr read from device memory) == gsl_adamw_flat for the same (step, lr)."""
