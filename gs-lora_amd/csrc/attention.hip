@@ -362,6 +362,166 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
 }
 
 // =====================================================================================
+// backward, both phases in one workgroup (bf16, T > 64): the dQ phase (waves own query tiles; K / V panels in LDS) and the dK/dV
+// phase (waves own key tiles; Q / dO panels in the SAME LDS) of one (batch, head) run back to back. The two-kernel form streams
+// qkv and dO from HBM twice (B*H*T*64 panels of 826 MB per launch are far beyond L2 and the 256 MB infinity cache); here the second
+// phase re-reads what the first touched ~10 us earlier (L2 / MALL hits), delta = rowsum(dO * O) never leaves LDS, and one launch
+// disappears. Same arithmetic, same per-element operation order as the two kernels above: bit-identical results.
+// =====================================================================================
+template <int NKT>
+__global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                     bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+  constexpr int TP = NKT * 16;
+  __shared__ __attribute__((aligned(16))) bf16_t P0[TP * KLD];   // phase A: K, phase B: Q
+  __shared__ __attribute__((aligned(16))) bf16_t P1[TP * KLD];   // phase A: V, phase B: dO
+  __shared__ __attribute__((aligned(16))) float lse_s[TP];       // log2 units; padded queries 1e30 -> p = 0
+  __shared__ __attribute__((aligned(16))) float del_s[TP];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
+  const int nwaves = blockDim.x >> 6;
+  const int nqt = (T + 15) / 16;
+  const int ktf = T >> 4;      // key tiles below this index are completely valid
+  const float c2 = scale * 1.4426950408889634f;
+  // ------------------------------------------------------------------ phase A: dQ (and delta, kept in LDS)
+  {
+    bf16x8_t qf0, qf1;
+    Frag dof0, dof1, of0, of1;
+    auto load_tile = [&](int qt) {
+      const int qrc = min(qt * 16 + fr, T - 1);
+      const bf16_t* qrow = qb + (size_t)qrc * ld;
+      const bf16_t* dorow = dob + (size_t)qrc * ldo;
+      const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
+      qf0 = gl_frag(qrow, 0, fc); qf1 = gl_frag(qrow, 1, fc);
+      dof0.v = gl_frag(dorow, 0, fc); dof1.v = gl_frag(dorow, 1, fc);
+      of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
+    };
+    load_tile(wave);
+    stage_rowmajor<TP>(P0, qb + H * HD, ld, T);
+    stage_rowmajor<TP>(P1, qb + 2 * H * HD, ld, T);
+    for (int t = threadIdx.x; t < TP; t += blockDim.x) {
+      lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;
+      del_s[t] = 0.f;
+    }
+    __syncthreads();
+    for (int qt = wave; qt < nqt; qt += nwaves) {
+      asm volatile("" ::: "memory");
+      const int qr = qt * 16 + fr;
+      if (qt != wave) load_tile(qt);
+      float dl = 0.f;
+      {
+        const uint32_t a[8] = {dof0.u.x, dof0.u.y, dof0.u.z, dof0.u.w, dof1.u.x, dof1.u.y, dof1.u.z, dof1.u.w};
+        const uint32_t c[8] = {of0.u.x, of0.u.y, of0.u.z, of0.u.w, of1.u.x, of1.u.y, of1.u.z, of1.u.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          dl += __uint_as_float(a[i] << 16) * __uint_as_float(c[i] << 16);
+          dl += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(c[i] & 0xffff0000u);
+        }
+      }
+      dl += __shfl_xor(dl, 16, 64);
+      dl += __shfl_xor(dl, 32, 64);
+      const float lq2 = lse_s[min(qr, TP - 1)];
+      Frag dsf[NKT / 2];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 0, fc), qf0, sa);
+        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 1, fc), qf1, sa);
+        dp = mfma16(lds_frag_rm(P1, kt * 16 + fr, 0, fc), dof0.v, dp);
+        dp = mfma16(lds_frag_rm(P1, kt * 16 + fr, 1, fc), dof1.v, dp);
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lq2));
+          if (kt >= ktf) { if (kt * 16 + fc * 4 + r >= T) p = 0.f; }
+          ds[r] = p * (dp[r] - dl);
+        }
+        if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.y = pack2bf(ds[2], ds[3]); }
+        else { dsf[kt / 2].u.z = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.w = pack2bf(ds[2], ds[3]); }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(P0, dt, pr, lane), dsf[pr].v, acc);
+        if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, scale);
+      }
+      if (fc == 0 && qr < T) del_s[qr] = dl;
+    }
+  }
+  // ------------------------------------------------------------------ phase B: dK / dV, one key tile per wave and round
+  bf16x8_t kf[2], vf[2];
+  int kr;
+  auto load_keys = [&](int kp) {
+    kr = kp * 16 + fr;
+    const int krc = min(kr, T - 1);
+    const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
+    const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+    kf[0] = gl_frag(krow, 0, fc); kf[1] = gl_frag(krow, 1, fc);
+    vf[0] = gl_frag(vrow, 0, fc); vf[1] = gl_frag(vrow, 1, fc);
+  };
+  load_keys(wave);
+  __syncthreads();             // every wave is done with the K / V panels (and del_s is complete)
+  stage_rowmajor<TP>(P0, qb, ld, T);
+  stage_rowmajor<TP>(P1, dob, ldo, T);
+  __syncthreads();
+  for (int kp = wave; kp < nqt; kp += nwaves) {
+    if (kp != wave) load_keys(kp);
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int qp = 0; qp < NKT / 2; ++qp) {
+      Frag pf, dsf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * qp + half;
+        const bf16x8_t q0 = lds_frag_rm(P0, qt * 16 + fr, 0, fc), q1 = lds_frag_rm(P0, qt * 16 + fr, 1, fc);
+        const bf16x8_t g0 = lds_frag_rm(P1, qt * 16 + fr, 0, fc), g1 = lds_frag_rm(P1, qt * 16 + fr, 1, fc);
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[qt * 16 + fc * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&del_s[qt * 16 + fc * 4]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sa = mfma16(q0, kf[0], sa);
+        sa = mfma16(q1, kf[1], sa);
+        dp = mfma16(g0, vf[0], dp);
+        dp = mfma16(g1, vf[1], dp);
+        float p[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lv[r]));
+          ds[r] = p[r] * (dp[r] - dv[r]);
+        }
+        if (half == 0) {
+          pf.u.x = pack2bf(p[0], p[1]); pf.u.y = pack2bf(p[2], p[3]);
+          dsf.u.x = pack2bf(ds[0], ds[1]); dsf.u.y = pack2bf(ds[2], ds[3]);
+        } else {
+          pf.u.z = pack2bf(p[0], p[1]); pf.u.w = pack2bf(p[2], p[3]);
+          dsf.u.z = pack2bf(ds[0], ds[1]); dsf.u.w = pack2bf(ds[2], ds[3]);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8_t ot = lds_frag_trr(P1, dt, qp, lane), qtf = lds_frag_trr(P0, dt, qp, lane);
+        adv[dt] = mfma16(ot, pf.v, adv[dt]);
+        adk[dt] = mfma16(qtf, dsf.v, adk[dt]);
+      }
+    }
+    if (kr < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16_t* base = dqkv + ((size_t)b * T + kr) * ld + h * HD + dt * 16 + fc * 4;
+        store4bf(base + H * HD, adk[dt], scale);
+        store4bf(base + 2 * H * HD, adv[dt], 1.0f);
+      }
+    }
+  }
+}
+
+// =====================================================================================
 // f32 parity kernels: thread per query / per key, panels broadcast from LDS
 // =====================================================================================
 template <int TP>
@@ -621,7 +781,9 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     if (T <= 64) {
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
       hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
-    } else {
+    } else if (!getenv("GSL_ATTN_BWD_SPLIT") || atoi(getenv("GSL_ATTN_BWD_SPLIT")) == 0) {
+      hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale);
+    } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
       { const char* nt = getenv("GSL_ATTN_NT");     // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us
         if (!nt || atoi(nt) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());

@@ -312,6 +312,20 @@ def test_attention_bwd_cls_equals_dense_backward(ops, dt, B, T, H):
         assert (got - q.grad).abs().max() < 5e-5 * max(1.0, q.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 197, 8), (2, 150, 4), (5, 224, 2)])
+def test_attention_bwd_fused_bit_identical_to_two_kernel_form(ops, B, T, H, monkeypatch):
+    """bf16, T > 64: the single-launch backward (dQ phase then dK/dV phase over the same LDS panels) == the dQ kernel + the dK/dV kernel."""
+    dt = torch.bfloat16
+    scale = 64 ** -0.5
+    qkv = rnd(B * T, 3 * H * 64, seed=21, scale=1.3).cuda().to(dt)
+    o, lse = ops.attention_fwd(qkv, B, T, H, scale)
+    d_o = rnd(B * T, H * 64, seed=22).cuda().to(dt)
+    fused = ops.attention_bwd(qkv, o, d_o, lse, B, T, H, scale)
+    monkeypatch.setenv("GSL_ATTN_BWD_SPLIT", "1")
+    split = ops.attention_bwd(qkv, o, d_o, lse, B, T, H, scale)
+    assert torch.equal(fused, split)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_layernorm_bwd_strided_inplace(ops, dt):
     """cls-row form: x / dres / dx rows are T*D apart, dy and the masked copy are compact."""
