@@ -165,6 +165,147 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
 }
 
 // =====================================================================================
+// forward (bf16, 64 < T <= 208), persistent + wave-specialised: one 16-wave workgroup per CU loops over (batch, head) items.
+// The one-item-per-workgroup kernel above runs its two phases strictly one after the other chip-wide (measured at B = 1024: panel
+// staging alone 112 us, compute alone 165 us, full kernel 277 us = the sum, even with two resident workgroups per CU). Here
+//   * waves 0..12 own one query tile each and only compute: phase 1 = Q K^T + softmax (reads the Q and K panels), phase 2 = P V
+//     (reads the V panel), one workgroup barrier after each phase;
+//   * waves 13..15 only move data: during phase 1 of item i they put V(i) (requested one phase earlier) into LDS and request
+//     Q, K of item i+1 into registers; during phase 2 they put those into LDS and request V(i+1). A panel is overwritten in the
+//     phase in which nobody reads it, and every HBM request has a whole compute phase to land.
+// The loader waves hold up to 72 VGPRs of in-flight data, the compute waves none: the two roles share one register budget (128).
+// Barriers are raw s_barrier + lgkmcnt waits: a __syncthreads() would also drain the loaders' outstanding global loads (vmcnt).
+// =====================================================================================
+__device__ __forceinline__ void wg_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int NKT>
+__global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                  float* __restrict__ lse, int T, int H, float scale, int nitems) {
+  constexpr int TP = NKT * 16;
+  constexpr int NCW = 13;                 // compute waves = query tiles (host: T <= 208)
+  constexpr int NST = 9;                  // loader steps per panel: 24 rows x 8 chunks per step, 9 * 24 = 216 >= 208 rows
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
+  const long ld = 3L * H * HD;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fc = lane >> 4;
+  // rows >= T of the panels are zero for every item: written once
+  for (int idx = threadIdx.x; idx < (TP - T) * 8; idx += 1024) {
+    const int t = T + (idx >> 3), c = idx & 7;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Qs + lds_off(t, c * 8)) = z;
+    *reinterpret_cast<uint4*>(Ks + lds_off(t, c * 8)) = z;
+    *reinterpret_cast<uint4*>(Vs + lds_off(t, c * 8)) = z;
+  }
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ loader waves
+    // (data registers are first-class vector values and every request is unconditional — the last item re-requests itself —
+    // so that the three register sets stay in VGPRs: conditional assignments to uint4 arrays ended up in scratch memory)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const int li = (wave - NCW) * 64 + lane, col = (li & 7) * 8, row0 = li >> 3;
+    u32x4_t dq[NST], dk[NST], dv[NST];
+    int item = blockIdx.x;
+    const bf16_t* qb = qkv + (size_t)(item / H) * T * ld + (item % H) * HD;
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
+      dq[k] = *reinterpret_cast<const u32x4_t*>(qb + g);
+      dk[k] = *reinterpret_cast<const u32x4_t*>(qb + g + H * HD);
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int r = min(row0 + 24 * k, T - 1);      // rows past T - 1 re-write row T - 1 with its own data
+      *reinterpret_cast<u32x4_t*>(Qs + lds_off(r, col)) = dq[k];
+      *reinterpret_cast<u32x4_t*>(Ks + lds_off(r, col)) = dk[k];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * H * HD);
+    wg_barrier_lds();                                   // Q, K of the first item are in LDS
+    for (; item < nitems; item += gridDim.x) {
+      const int nxt = (item + (int)gridDim.x < nitems) ? item + (int)gridDim.x : item;
+      const bf16_t* nb = qkv + (size_t)(nxt / H) * T * ld + (nxt % H) * HD;
+      // phase 1 of `item`: V(item) -> LDS, request Q, K of the next item
+#pragma unroll
+      for (int k = 0; k < NST; ++k) *reinterpret_cast<u32x4_t*>(Vs + lds_off(min(row0 + 24 * k, T - 1), col)) = dv[k];
+      asm volatile("" ::: "memory");      // requests strictly after the deposit: the register sets never live together
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
+        dq[k] = *reinterpret_cast<const u32x4_t*>(nb + g);
+        dk[k] = *reinterpret_cast<const u32x4_t*>(nb + g + H * HD);
+      }
+      wg_barrier_lds();
+      // phase 2 of `item`: Q, K of the next item -> LDS, request its V
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const int r = min(row0 + 24 * k, T - 1);
+        *reinterpret_cast<u32x4_t*>(Qs + lds_off(r, col)) = dq[k];
+        *reinterpret_cast<u32x4_t*>(Ks + lds_off(r, col)) = dk[k];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(nb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * H * HD);
+      wg_barrier_lds();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- compute waves: query tile = wave
+  const int ktf = T >> 4;      // key tiles below this index are completely valid
+  const float c2 = scale * 1.4426950408889634f;
+  const int qr = wave * 16 + fr;
+  wg_barrier_lds();
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / H, h = item % H;
+    const bf16x8_t qf0 = lds_frag_rm(Qs, qr, 0, fc), qf1 = lds_frag_rm(Qs, qr, 1, fc);
+    f32x4_t s[NKT];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 0, fc), qf0, acc);
+      acc = mfma16(lds_frag_rm(Ks, kt * 16 + fr, 1, fc), qf1, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt >= ktf) { if (kt * 16 + fc * 4 + r >= T) acc[r] = -3.0e38f; }
+        m = fmaxf(m, acc[r]);
+      }
+      s[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c2;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mc)); l += s[kt][r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    Frag pf[NKT / 2];
+#pragma unroll
+    for (int pr = 0; pr < NKT / 2; ++pr) {
+      pf[pr].u = make_uint4(pack2bf(s[2 * pr][0], s[2 * pr][1]), pack2bf(s[2 * pr][2], s[2 * pr][3]),
+                            pack2bf(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2bf(s[2 * pr + 1][2], s[2 * pr + 1][3]));
+    }
+    const float inv = 1.0f / l;
+    wg_barrier_lds();                                   // V(item) is in LDS; Q / K panels may be overwritten from here on
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(Vs, dt, pr, lane), pf[pr].v, acc);
+      if (qr < T) store4bf(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + fc * 4, acc, inv);
+    }
+    if (fc == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m * scale + __logf(l);
+    wg_barrier_lds();                                   // Q, K of the next item are in LDS; V may be overwritten
+  }
+}
+
+// =====================================================================================
 // backward dQ (bf16): waves own query tiles
 // =====================================================================================
 template <int NKT>
@@ -748,6 +889,16 @@ extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void*
   return check_launch("gsl_attention_bwd_cls");
 }
 
+static inline int attn_persistent() { const char* e = getenv("GSL_ATTN_PERSISTENT"); return e ? atoi(e) : 1; }   // dev: 0 = one item per workgroup
+static inline int attn_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+    else n = 256;
+  }
+  return n;
+}
 static inline int attn_abl() { const char* e = getenv("GSL_ATTN_ABL"); return e ? atoi(e) : 0; }   // dev: 1 staging only, 2 no staging
 
 // =====================================================================================
@@ -761,6 +912,8 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
+    else if (attn_persistent() && T <= 208 && B * H >= 2 * attn_num_cus())
+      hipLaunchKernelGGL(attn_fwd_bf16_pers_kernel<14>, dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H);
     else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
   } else if (dtype == GSL_F32) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);

@@ -312,6 +312,22 @@ def test_attention_bwd_cls_equals_dense_backward(ops, dt, B, T, H):
         assert (got - q.grad).abs().max() < 5e-5 * max(1.0, q.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,T,H", [(80, 197, 8), (131, 150, 4), (70, 208, 8), (67, 65, 8)])
+def test_attention_fwd_persistent_bit_identical_to_per_item_kernel(ops, B, T, H, monkeypatch):
+    """bf16, 64 < T <= 208, B*H >= 2 x CUs: the persistent wave-specialised forward (3 loader waves + 13 compute waves per CU) must
+    reproduce the one-item-per-workgroup kernel bit for bit (same fragments, same operation order) — including the ragged last round
+    of items and the zero rows of the panels."""
+    dt = torch.bfloat16
+    scale = 64 ** -0.5
+    qkv = rnd(B * T, 3 * H * 64, seed=31, scale=1.3).cuda().to(dt)
+    o1, lse1 = ops.attention_fwd(qkv, B, T, H, scale)
+    o1b, lse1b = ops.attention_fwd(qkv, B, T, H, scale)
+    monkeypatch.setenv("GSL_ATTN_PERSISTENT", "0")
+    o0, lse0 = ops.attention_fwd(qkv, B, T, H, scale)
+    assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
+    assert torch.equal(o1, o1b) and torch.equal(lse1, lse1b)
+
+
 @pytest.mark.parametrize("B,T,H", [(3, 197, 8), (2, 150, 4), (5, 224, 2)])
 def test_attention_bwd_fused_bit_identical_to_two_kernel_form(ops, B, T, H, monkeypatch):
     """bf16, T > 64: the single-launch backward (dQ phase then dK/dV phase over the same LDS panels) == the dQ kernel + the dK/dV kernel."""
