@@ -935,6 +935,8 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
       hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
     } else if (!getenv("GSL_ATTN_BWD_SPLIT") || atoi(getenv("GSL_ATTN_BWD_SPLIT")) == 0) {
+      // (a persistent wave-specialised form like the forward's was measured slower here: 795 vs 736 us at B = 1024 — its four
+      //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
