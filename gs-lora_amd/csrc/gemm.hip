@@ -54,8 +54,10 @@ struct EpiArgs {
 // global load + s_waitcnt vmcnt(0) serialises the VALU-bound epilogue), or nullptr to load them here.
 // alpha is honoured by the STORE / STORE_F32 / MUL epilogues only (the only callers that pass alpha != 1 are the LoRA
 // down-projections); the host wrapper rejects alpha != 1 for the others.
-template <int EPI, typename T>
-__device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4], const float* bp = nullptr) {
+// HASW: w0 is the first-stage dropout hash value of the fragment's first element pair (drop_w0), advanced by the caller with one
+// add per fragment instead of a 64-bit index and a quarter-rate multiply here.
+template <int EPI, typename T, bool HASW = false>
+__device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4], const float* bp = nullptr, uint32_t w0 = 0u) {
   const size_t off = (size_t)m * e.ldo + n;
   const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32 || EPI == GSL_EPI_MUL) {
@@ -82,7 +84,8 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
   } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
     float dm[4];
-    drop_mul4(e.drop, lin, dm);
+    if constexpr (HASW) drop_mul4_w(e.drop, w0, dm);
+    else drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a = v[i] + bq[i];
@@ -160,6 +163,17 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
       for (int i = 0; i < 4; ++i) bj[j][i] = (e.bias && (FULL || n < e.N)) ? e.bias[n + i] : 0.f;
     }
   }
+  // dropout: first-stage hash value of this lane's first fragment; fragment (i, j) is 16 i rows and 16 j columns further, i.e.
+  // 8 N i + 8 j element pairs (N % 4 == 0): one uniform offset and one add per fragment
+  const size_t rowoff0 = (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);     // copy-out: lane's row 0 of the wave tile
+  constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
+  uint32_t wbase = 0u, rowstep = 0u;
+  if constexpr (DROPW) {
+    if (e.drop.thr) {
+      wbase = drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1);
+      rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
+    }
+  }
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
     uint2 held[4][4];   // second output, packed, when SEQ
@@ -171,12 +185,13 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
         const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
         if (FULL || (m < e.M && n < e.N)) {
+          const uint32_t w0 = wbase + ((uint32_t)i * rowstep + (uint32_t)(j * 8) * DROP_PHI);
           if (bias_lds) {
             const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias_lds + j * 16 + fc * 4);
             const float bl[4] = {b4[0], b4[1], b4[2], b4[3]};
-            epi_math<EPI, bf16_t>(e, m, n, v, g, bl);
+            epi_math<EPI, bf16_t, DROPW>(e, m, n, v, g, bl, w0);
           } else {
-            epi_math<EPI, bf16_t>(e, m, n, v, g, bj[j]);      // (a pointer select here would push the arrays into scratch memory)
+            epi_math<EPI, bf16_t, DROPW>(e, m, n, v, g, bj[j], w0);      // (a pointer select here would push the arrays into scratch memory)
           }
         }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
@@ -202,11 +217,13 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         if (FULL || (m < e.M && n < e.N)) {
           const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
           bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
-          if (dst) store_stream16(dst + (size_t)m * e.ldo + n, val, e.stmode);
+          // element offset = this lane's first row + a wave-uniform row step (scalar multiply): no per-store 64-bit multiply
+          const size_t off = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
+          if (dst) store_stream16(dst + off, val, e.stmode);
           if constexpr (NOUT == 2 && !SEQ) {
             if (e.out2) {
               const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
-              store_stream16(reinterpret_cast<bf16_t*>(e.out2) + (size_t)m * e.ldo + n, val2, e.stmode);
+              store_stream16(reinterpret_cast<bf16_t*>(e.out2) + off, val2, e.stmode);
             }
           }
         }

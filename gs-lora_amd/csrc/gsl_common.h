@@ -130,16 +130,22 @@ __device__ __forceinline__ void resolve_drop(DropCfg& d) {
   if (d.seed_ptr && d.thr) { d.key = drop_mix(*d.seed_ptr, d.site); }
   d.seed_ptr = nullptr;
 }
-// one 32-bit hash serves the element pair (2k, 2k+1): low / high 16 bits. Two multiply rounds on the 32-bit pair counter with one
-// xor-shift in between (the high counter word only perturbs the first sum): 5 integer ops per pair — the epilogue that uses it is
-// VALU-bound (profiles/r01_gemm_ab.md), every instruction per element counts. Checked on 4 M consecutive indices: rate, lag-1..4096
-// autocorrelation (< 2e-3) and drop-gap variance (89.7 vs 89.9 geometric) match an ideal Bernoulli stream; dropping the second
-// multiply does NOT (gap variance 50: the high half of k*phi is a low-discrepancy sequence).
-__device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint64_t pair) {
-  uint32_t x = ((uint32_t)pair ^ key) * 0x9E3779B1u + (uint32_t)(pair >> 32);
-  x ^= x >> 15; x *= 0x85EBCA77u;
-  return x;
+// one 32-bit hash serves the element pair (2k, 2k+1): low / high 16 bits. First stage: a Weyl sequence in the pair counter,
+// w(k) = (k + key) * phi mod 2^32 (key = seed/site mix), second stage: xor-shift + multiply. The first stage is LINEAR in k, so a
+// kernel that walks a regular lattice of indices (the GEMM epilogues: rows 16 apart, columns 16 apart) advances w with one add per
+// hash instead of a 64-bit index + a quarter-rate 32-bit multiply (drop_w0 / drop_finish below) — the epilogue that uses it is
+// VALU-bound (profiles/r01_gemm_ab.md), every instruction per element counts. Only the low 32 bits of the pair counter enter (the
+// stream repeats every 2^33 elements; the tensors here have < 2^29). Checked on 16 M consecutive indices, four keys, p = 0.1 / 0.5:
+// rate, lag-1..8192 autocorrelation (< 5e-3), drop-gap variance (90.1 vs 90.0 geometric), per-1024 counts and cross-key joint rate
+// match an ideal Bernoulli stream; dropping the second multiply does NOT (gap variance 50: k*phi alone is a low-discrepancy sequence).
+constexpr uint32_t DROP_PHI = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t drop_finish(uint32_t w) {     // second stage on a first-stage value
+  w ^= w >> 15; w *= 0x85EBCA77u;
+  return w;
 }
+__device__ __forceinline__ uint32_t drop_w0(uint32_t key, uint64_t pair) { return ((uint32_t)pair + key) * DROP_PHI; }
+__device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint64_t pair) { return drop_finish(drop_w0(key, pair)); }
+
 // multiplier to apply to an element: 0 or 1/(1-p)
 __device__ __forceinline__ float drop_mul(const DropCfg& d, uint64_t idx) {
   if (d.thr == 0u) return 1.0f;
@@ -147,14 +153,17 @@ __device__ __forceinline__ float drop_mul(const DropCfg& d, uint64_t idx) {
   const uint32_t s = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return (s < d.thr) ? 0.0f : d.scale;
 }
-// four consecutive elements starting at a multiple of 4: two hashes
-__device__ __forceinline__ void drop_mul4(const DropCfg& d, uint64_t idx, float m[4]) {
+// four consecutive elements starting at a multiple of 4: two hashes; w0 = drop_w0(key, idx >> 1)
+__device__ __forceinline__ void drop_mul4_w(const DropCfg& d, uint32_t w0, float m[4]) {
   if (d.thr == 0u) { m[0] = m[1] = m[2] = m[3] = 1.0f; return; }
-  const uint32_t h0 = drop_hash(d.key, idx >> 1), h1 = drop_hash(d.key, (idx >> 1) + 1);
+  const uint32_t h0 = drop_finish(w0), h1 = drop_finish(w0 + DROP_PHI);
   m[0] = ((h0 & 0xffffu) < d.thr) ? 0.0f : d.scale;
   m[1] = ((h0 >> 16) < d.thr) ? 0.0f : d.scale;
   m[2] = ((h1 & 0xffffu) < d.thr) ? 0.0f : d.scale;
   m[3] = ((h1 >> 16) < d.thr) ? 0.0f : d.scale;
+}
+__device__ __forceinline__ void drop_mul4(const DropCfg& d, uint64_t idx, float m[4]) {
+  drop_mul4_w(d, d.thr ? drop_w0(d.key, idx >> 1) : 0u, m);
 }
 
 // exact-erf GELU and its derivative (nn.GELU default, vit_face.py:331)
