@@ -177,11 +177,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // speed-mode GELU + derivative: Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7), one v_exp shared by the
 // cdf and the pdf (exp(-z^2) with z = |a|/sqrt2 IS exp(-a^2/2)), one v_rcp. ~20 VALU ops instead of ~120.
 __device__ __forceinline__ void gelu_pair_fast(float a, float& g, float& gp) {
-  const float z = fabsf(a) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to an 8-op IEEE divide
-  const float e = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);   // exp(-a^2/2) = 2^(-a^2 * log2(e)/2): one v_exp_f32
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, a));
+  // constants folded so that every step is one VALU op (the epilogue that calls this is VALU-bound): 1 + p z = fma(|a|, p/sqrt2, 1);
+  // the final 1/2 of the cdf sits in the polynomial coefficients: h = (t poly(t) / 2) e = 1 - Phi(|a|), Phi(a) = 1/2 + copysign(1/2 - h, a)
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(a), 0.3275911f * 0.70710678118654752f, 1.0f));   // v_rcp_f32 (1 ulp)
+  const float e = __builtin_amdgcn_exp2f((a * a) * -0.72134752044448170f);   // exp(-a^2/2) = 2^(-a^2 * log2(e)/2): one v_exp_f32
+  const float ph = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f), 0.5f * 1.421413741f), 0.5f * -0.284496736f),
+                            0.5f * 0.254829592f);
+  const float cdf = 0.5f + copysignf(fmaf(-ph, e, 0.5f), a);
   g = a * cdf;
   gp = fmaf(a * 0.39894228040143268f, e, cdf);
 }
