@@ -91,11 +91,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the GS-LoRA step has no CPU fallback)")
+    # development knobs for exercising the world > 1 code path on a 1-GPU box: GSL_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # GSL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device). Never set by the driver.
+    if os.environ.get("GSL_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GSL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gslora_hip import ops

@@ -84,7 +84,10 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         kl_f_sum = kl_r_sum = zero
     g_nr, g_nf = n_r, n_f
     if world > 1:
-        pack = torch.stack([ce_r_sum.detach(), ce_f_sum.detach(), hit_r, hit_f, n_r, n_f, kl_f_sum.detach(), kl_r_sum.detach()])
+        # every entry detached: the collective must not become a node of the autograd graph (the top-1 counters come out of an
+        # autograd Function and would otherwise drag the whole pack, and with it the divisors g_nr / g_nf, into it)
+        pack = torch.stack([ce_r_sum.detach(), ce_f_sum.detach(), hit_r.detach(), hit_f.detach(), n_r, n_f, kl_f_sum.detach(),
+                            kl_r_sum.detach()])
         dist.all_reduce(pack)
         ce_r_sum, ce_f_sum = _globalize(ce_r_sum, pack[0]), _globalize(ce_f_sum, pack[1])
         hit_r, hit_f, g_nr, g_nf = pack[2], pack[3], pack[4], pack[5]
