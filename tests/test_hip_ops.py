@@ -436,6 +436,30 @@ def test_gemm_nt_lora_mulgrad_fused_reductions(ops, M, N, K, r, monkeypatch):
     assert relerr(G1r.cpu(), ref1.cpu()) < 1e-4 and relerr(G2r.cpu(), ref2.cpu()) < 1e-4
 
 
+def test_dropout_mask_matches_the_documented_hash(ops):
+    """DESIGN.md §5 / gsl_common.h: key = mix64(seed, site) (low 32 bits), w = (pair + key) * 0x9E3779B1 mod 2^32 with pair = i // 2,
+    h = (w ^ (w >> 15)) * 0x85EBCA77 mod 2^32, element i keeps iff its 16-bit half of h (low for even i, high for odd i) >= round(p * 2^16).
+    A numpy restatement must reproduce gsl_dropout_mask bit for bit (this pins the stream the epilogues advance incrementally)."""
+    import numpy as np
+    U = np.uint64
+    M64 = (1 << 64) - 1
+
+    def mix(seed, site):
+        z = (seed * 0x9E3779B97F4A7C15 + site * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & M64
+        z ^= z >> 29; z = (z * 0xD6E8FEB86659FD93) & M64; z ^= z >> 32
+        return z & 0xFFFFFFFF
+
+    for (n, p, seed, site) in [(10_000, 0.1, 1234, 5), (4099, 0.5, (0x5EED << 20) + 77, 9), (1 << 20, 0.25, 7, 1_000_000)]:
+        key = mix(seed, site)
+        i = np.arange(n, dtype=np.uint64)
+        w = (((i >> U(1)) + U(key)) * U(0x9E3779B1)) & U(0xFFFFFFFF)
+        h = ((w ^ (w >> U(15))) * U(0x85EBCA77)) & U(0xFFFFFFFF)
+        sample = np.where((i & U(1)) == 0, h & U(0xFFFF), h >> U(16))
+        keep = sample >= U(int(p * 65536.0 + 0.5))
+        got = ops.dropout_mask(n, p, seed, site, "cuda").cpu().numpy().astype(bool)
+        assert (got == keep).all(), (n, p, seed, site, int((got != keep).sum()))
+
+
 # ---- entry points added for HIP-graph replay and launch-count reduction ---------------------------------------------------
 def test_adamw_dev_bit_identical_to_value_form(ops):
     """gsl_adamw_flat_dev (step count / lr read from device memory) == gsl_adamw_flat for the same (step, lr)."""
