@@ -87,13 +87,29 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   if (!logits) return;
   const int lane = tid & 63, wave = tid >> 6;
   const long lab = label ? (long)label[b] : -1;
-  for (int c = wave; c < C; c += 4) {
-    float dot = 0.f;
-    for (int d = lane; d < D; d += 64) dot += e[d] * Wn[(size_t)c * D + d];
-    dot = wave_sum(dot);
-    if (lane == 0) {
-      if (linear) logits[(size_t)b * C + c] = dot + (hbias ? hbias[c] : 0.f);     // plain nn.Linear head (modified_VIT.py:34-36)
-      else { dot *= inv; logits[(size_t)b * C + c] = cs * ((c == lab) ? (dot - cm) : dot); }
+  // a wave owns classes wave, wave + 4, ...; five of them per round so that the loads of five W rows are in flight together (one
+  // class per round made the kernel a chain of 25 dependent global-load latencies: 60 us for 100 classes at any batch size)
+  constexpr int CB = 5;
+  for (int c0 = wave; c0 < C; c0 += 4 * CB) {
+    float dot[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) dot[k] = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float ev = e[d];
+#pragma unroll
+      for (int k = 0; k < CB; ++k) {
+        const int c = min(c0 + 4 * k, C - 1);
+        dot[k] += ev * Wn[(size_t)c * D + d];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+      const int c = c0 + 4 * k;
+      float dk = wave_sum(dot[k]);
+      if (lane == 0 && c < C) {
+        if (linear) logits[(size_t)b * C + c] = dk + (hbias ? hbias[c] : 0.f);     // plain nn.Linear head (modified_VIT.py:34-36)
+        else { dk *= inv; logits[(size_t)b * C + c] = cs * ((c == lab) ? (dk - cm) : dk); }
+      }
     }
   }
 }
