@@ -51,6 +51,32 @@ def proto_kl_sum(emb, labels, table):
     return _ProtoKLSum.apply(emb, labels, table)
 
 
+class _Combine(torch.autograd.Function):
+    """total loss of the step from the five batch sums; one kernel forward, one multiply backward (see gsl_loss_combine)."""
+
+    @staticmethod
+    def forward(ctx, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        total, meters, coefs = ops.loss_combine(f(ce_r_sum), f(ce_f_sum), f(kl_f_sum), f(kl_r_sum), f(structure), f(hit_r), f(hit_f),
+                                                n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro)
+        ctx.save_for_backward(coefs)
+        ctx.has = (kl_f_sum is not None, kl_r_sum is not None, structure is not None)
+        ctx.mark_non_differentiable(meters)
+        return total, meters
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        (coefs,) = ctx.saved_tensors
+        gc = coefs * g                      # one 5-element kernel; the entries below are views
+        has_f, has_r, has_s = ctx.has
+        return (gc[0], gc[1], gc[2] if has_f else None, gc[3] if has_r else None, gc[4] if has_s else None) + (None,) * 10
+
+
+def combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):
+    return _Combine.apply(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r,
+                          BND_pro)
+
+
 _table_cache = {}
 
 

@@ -186,6 +186,18 @@ def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
                               1 if accumulate else 0, _p(ws), _stream()), "gsl_lora_grad")
 
 
+def loss_combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):
+    """-> (total [0-dim], meters [8], coefs [5]) — see gsl_loss_combine."""
+    _need(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f)
+    dev = ce_r_sum.device
+    out = torch.empty(14, device=dev, dtype=torch.float32)
+    L.check(L.load().gsl_loss_combine(_p(ce_r_sum), _p(ce_f_sum), _p(kl_f_sum), _p(kl_r_sum), _p(structure), _p(hit_r), _p(hit_f),
+                                      float(n_r), float(n_f), float(beta), float(BND), float(alpha), float(w_f), float(w_r),
+                                      float(BND_pro), out.data_ptr(), out.data_ptr() + 4, out.data_ptr() + 36, _stream()),
+            "gsl_loss_combine")
+    return out[0], out[1:9], out[9:14]
+
+
 def cosface_prep(W):
     _need(W)
     Wn = torch.empty_like(W)

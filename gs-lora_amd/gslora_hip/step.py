@@ -93,6 +93,16 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         hit_r, hit_f, g_nr, g_nf = pack[2], pack[3], pack[4], pack[5]
         if use_prototype:
             kl_f_sum, kl_r_sum = _globalize(kl_f_sum, pack[6]), _globalize(kl_r_sum, pack[7])
+    if world == 1 and ce_r_sum.is_cuda:
+        # single process: the scalar tail (hinges, weighted sum, meters, the five upstream gradients) is ONE kernel forward and one
+        # 5-element multiply backward instead of ~35 one-element torch kernels (losses.combine / gsl_loss_combine)
+        structure = backend.structure_loss(net, group_type, grad_scale=1.0) if use_structure else None
+        total, meters = losses.combine(ce_r_sum, ce_f_sum, kl_f_sum if use_prototype else None, kl_r_sum if use_prototype else None,
+                                       structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro)
+        optimizer.zero_grad()
+        total.backward()
+        optimizer.step()
+        return meters
     loss_remain = ce_r_sum / g_nr
     loss_forget = torch.relu(BND - ce_f_sum / g_nf)
     structure = backend.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else zero

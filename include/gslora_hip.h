@@ -156,6 +156,16 @@ int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto
 int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef,
                      float scale, float* demb, int B, int D, int C, int accumulate, gsl_stream_t s);
 
+/* ---- scalar tail of the step (engine_cl.py:65-125, single process): from the batch SUMS of the kernels above
+ *   total = beta*relu(BND - ce_f_sum/n_f) + ce_r_sum/n_r + alpha*structure + w_f*relu(BND_pro - kl_f_sum/n_f) + w_r*kl_r_sum/n_r
+ * meters8 = [beta*loss_forget, loss_remain, total, alpha*structure, top1_forget %, top1_remain %, proto_f, proto_r],
+ * coefs5 = d total / d {ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure} (relu'(0) = 0). kl_* / structure nullable (term absent).
+ * All inputs and outputs are device scalars / small device arrays: no host sync. */
+int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* kl_f_sum, const float* kl_r_sum,
+                     const float* structure, const float* hit_r, const float* hit_f, float n_r, float n_f,
+                     float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
+                     float* total, float* meters8, float* coefs5, gsl_stream_t s);
+
 /* ---- K12 group-lasso norms over a flat LoRA buffer (engine_cl.py:349-432, util/cal_norm.py:4-146).
  * tensor t = flat[toff[t] .. +tnumel[t]) belongs to group tgroup[t] (tables on device, int64/int64/int32).
  * Outputs (f32 unless noted): tensor_sumsq[ntensors], group_norm[ngroups] = sqrt(sum sumsq),
