@@ -33,6 +33,69 @@ def ce_sum_top1(logits, labels):
     return _CESum.apply(logits, labels)
 
 
+class _CESumSplit(torch.autograd.Function):
+    """ce_sum_top1 of the remain rows [0, nr) and the forget rows [nr, N) of ONE logits tensor (the step runs both batches as one
+    forward). Backward writes the two row ranges of a single dlogits buffer — slicing the logits in Python instead would make
+    autograd build two zero-filled full-size gradients and add them (10 extra one-off kernels per step)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, nr):
+        logits = logits.contiguous().float()
+        labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        out_r, out_f = ops.ce_fwd(logits[:nr], labels[:nr]), ops.ce_fwd(logits[nr:], labels[nr:])
+        ctx.save_for_backward(logits, labels)
+        ctx.nr = nr
+        res = (out_r[0], out_r[1], out_f[0], out_f[1])
+        ctx.mark_non_differentiable(res[1], res[3])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_r, _c_r, g_f, _c_f):
+        logits, labels = ctx.saved_tensors
+        nr = ctx.nr
+        dl = torch.empty_like(logits)
+        for g, sl in ((g_r, slice(0, nr)), (g_f, slice(nr, None))):
+            if g is None:
+                dl[sl].zero_()
+            else:
+                ops.ce_bwd(logits[sl], labels[sl], g.reshape(1).float().contiguous(), 1.0, dlogits=dl[sl], accumulate=False)
+        return dl, None, None
+
+
+def ce_sum_top1_split(logits, labels, nr):
+    """-> (CE sum, top-1 hits) of rows [0, nr) and of rows [nr, N): four 0-dim f32 device tensors."""
+    return _CESumSplit.apply(logits, labels, int(nr))
+
+
+class _ProtoKLSumSplit(torch.autograd.Function):
+    """proto_kl_sum of rows [nr, N) (forget) and rows [0, nr) (remain) of one embedding tensor; one demb buffer in backward."""
+
+    @staticmethod
+    def forward(ctx, emb, labels, table, nr):
+        emb = emb.contiguous().float()
+        labels = labels.to(device=emb.device, dtype=torch.int64).contiguous()
+        ctx.save_for_backward(emb, labels, table)
+        ctx.nr = nr
+        return ops.proto_kl_fwd(emb[nr:], labels[nr:], table)[0], ops.proto_kl_fwd(emb[:nr], labels[:nr], table)[0]
+
+    @staticmethod
+    def backward(ctx, g_f, g_r):
+        emb, labels, table = ctx.saved_tensors
+        nr = ctx.nr
+        de = torch.empty_like(emb)
+        for g, sl in ((g_r, slice(0, nr)), (g_f, slice(nr, None))):
+            if g is None:
+                de[sl].zero_()
+            else:
+                ops.proto_kl_bwd(emb[sl], labels[sl], table, g.reshape(1).float().contiguous(), 1.0, demb=de[sl], accumulate=False)
+        return de, None, None, None
+
+
+def proto_kl_sum_split(emb, labels, table, nr):
+    """-> (KL sum of the forget rows [nr, N), KL sum of the remain rows [0, nr))."""
+    return _ProtoKLSumSplit.apply(emb, labels, table, int(nr))
+
+
 class _ProtoKLSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb, labels, table):

@@ -238,9 +238,9 @@ def ce_fwd(logits, labels):
     return out
 
 
-def ce_bwd(logits, labels, coef, scale, dlogits=None):
+def ce_bwd(logits, labels, coef, scale, dlogits=None, accumulate=None):
     _need(logits, labels, coef, dlogits)
-    acc = dlogits is not None
+    acc = (dlogits is not None) if accumulate is None else bool(accumulate)
     if dlogits is None:
         dlogits = torch.empty_like(logits)
     L.check(L.load().gsl_ce_bwd(_p(logits), _p(labels), _p(coef), float(scale), _p(dlogits), logits.shape[0], logits.shape[1],
@@ -257,9 +257,9 @@ def proto_kl_fwd(emb, labels, proto):
     return out
 
 
-def proto_kl_bwd(emb, labels, proto, coef, scale, demb=None):
+def proto_kl_bwd(emb, labels, proto, coef, scale, demb=None, accumulate=None):
     _need(emb, labels, proto, coef, demb)
-    acc = demb is not None
+    acc = (demb is not None) if accumulate is None else bool(accumulate)
     if demb is None:
         demb = torch.empty_like(emb)
     L.check(L.load().gsl_proto_kl_bwd(_p(emb), _p(labels), _p(proto), _p(coef), float(scale), _p(demb), emb.shape[0],

@@ -35,6 +35,8 @@ class HipBackend:
     arithmetic of gs_lora_step under gloo; nothing in the package ever selects another backend."""
     ce_sum_top1 = staticmethod(losses.ce_sum_top1)
     proto_kl_sum = staticmethod(losses.proto_kl_sum)
+    ce_sum_top1_split = staticmethod(losses.ce_sum_top1_split)
+    proto_kl_sum_split = staticmethod(losses.proto_kl_sum_split)
     structure_loss = staticmethod(losses.structure_loss)
 
     @staticmethod
@@ -54,12 +56,16 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     net = model.module if isinstance(model, nn.DataParallel) else model
     world = _world()
     dev = x_r.device
+    split = None
     if fuse_batches:
         # every operation of the network is per-sample (no BatchNorm), so one forward over the concatenated batch is
         # arithmetically identical to the reference's two forwards and halves the number of kernel launches / tile tails
         nr = x_r.size(0)
-        out, emb = model(torch.cat((x_r.float(), x_f.float()), 0), torch.cat((y_r, y_f), 0))
+        y_all = torch.cat((y_r, y_f), 0)
+        out, emb = model(torch.cat((x_r.float(), x_f.float()), 0), y_all)
         out_r, out_f, emb_r, emb_f = out[:nr], out[nr:], emb[:nr], emb[nr:]
+        if _plain_ce(criterion) and hasattr(backend, "ce_sum_top1_split"):
+            split = (out, emb, y_all, nr)       # losses on the two row ranges of the un-sliced tensors (one gradient buffer each)
     else:
         out_r, emb_r = model(x_r.float(), y_r)
         out_f, emb_f = model(x_f.float(), y_f)
@@ -68,7 +74,9 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         n_f = torch.full((), float(x_f.size(0)), device=dev)
     else:
         n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
-    if _plain_ce(criterion):
+    if split is not None:
+        ce_r_sum, hit_r, ce_f_sum, hit_f = backend.ce_sum_top1_split(split[0], split[2], split[3])
+    elif _plain_ce(criterion):
         ce_r_sum, hit_r = backend.ce_sum_top1(out_r, y_r)
         ce_f_sum, hit_f = backend.ce_sum_top1(out_f, y_f)
     else:   # exotic criterion: keep its semantics (mean over the local batch), top-1 from the HIP kernel
@@ -77,7 +85,9 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         hit_r = backend.ce_sum_top1(out_r.detach(), y_r)[1]
         hit_f = backend.ce_sum_top1(out_f.detach(), y_f)[1]
     zero = torch.zeros((), device=dev)
-    if use_prototype:
+    if use_prototype and split is not None:
+        kl_f_sum, kl_r_sum = backend.proto_kl_sum_split(split[1], split[2], proto_table, split[3])
+    elif use_prototype:
         kl_f_sum = backend.proto_kl_sum(emb_f, y_f, proto_table)
         kl_r_sum = backend.proto_kl_sum(emb_r, y_r, proto_table)
     else:
