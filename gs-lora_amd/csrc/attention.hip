@@ -13,9 +13,14 @@
 //     32*pair + 16*(idx/4) + 4*g + idx%4 — exactly what the C layout of two adjacent score tiles
 //     delivers — and the A operand (Vᵀ) is gathered from the row-major V panel with the same
 //     permutation by two LDS transpose reads (ds_read_b64_tr_b16), so the contraction is unchanged.
-//   * backward is two kernels with no atomics: dQ (waves own query tiles; K and V panels in LDS)
+//   * backward has two phases with no atomics: dQ (waves own query tiles; K and V panels in LDS)
 //     and dK/dV (waves own key tiles; Q and dO panels in LDS); probabilities are recomputed
-//     from the saved log-sum-exp (flash-style), delta = rowsum(dO∘O) is produced by the dQ kernel.
+//     from the saved log-sum-exp (flash-style), delta = rowsum(dO∘O) is produced by the dQ phase.
+//     T > 64 runs both phases in ONE launch (attn_bwd_fused_bf16_kernel); the two-kernel form stays for
+//     T <= 64 and as the bit-exact reference of the tests.
+//   * forward, T in (64, 208] and enough (image, head) items: a persistent wave-specialised kernel
+//     (attn_fwd_bf16_pers_kernel: 13 compute waves + 3 loader waves per CU) streams the next item's
+//     panels under the current item's softmax; bit-identical to the one-item-per-workgroup kernel.
 // f32 path (parity mode): thread-per-row VALU kernels with LDS-broadcast panels; exact f32.
 #include <stdlib.h>
 

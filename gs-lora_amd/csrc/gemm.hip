@@ -13,7 +13,8 @@
 //   applied on the DMA source address and again on the ds_read_b128 fragment read (0 bank conflicts measured). Block ids are
 //   remapped so the N-tiles of one A row-panel run on one XCD, and N-tile j starts its K loop at K tile j. Epilogue operands
 //   (outputs, residual, GELU') go through a wave-private LDS staging area and touch HBM as full rows; outputs use non-temporal
-//   stores. What was tried and measured is in profiles/r01_gemm_ab.md and DESIGN.md section 4.
+//   stores. gsl_gemm_nt_lora_mulgrad (end of file) is the FFN2-dX GEMM with the two LoRA-gradient reductions of its tiles fused
+//   into the epilogue. What was tried and measured is in profiles/r01_gemm_ab.md and DESIGN.md section 4.
 // f32 path (parity mode): 64x64x16 tile, 4x4 outputs per thread, sequential fmaf over k.
 #include <stdlib.h>
 
