@@ -398,7 +398,7 @@ def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
     assert relerr(outf.cpu(), out2.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("M,N,K,r", [(1000, 512, 256, 8), (2560, 768, 128, 16), (4099, 2048, 512, 8)])
+@pytest.mark.parametrize("M,N,K,r", [(1000, 512, 256, 8), (2560, 768, 128, 16), (4099, 2048, 512, 8), (1300, 640, 192, 5)])
 def test_gemm_nt_lora_mulgrad_fused_reductions(ops, M, N, K, r, monkeypatch):
     """FFN2-dX with both LoRA-gradient reductions of its tiles fused into the epilogue: `out` and `tout` are bit-identical to the
     unfused MUL GEMM (run without its K-tile rotation: the fused kernel keeps one K order for all N tiles so that the tile-local
