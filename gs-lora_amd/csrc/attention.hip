@@ -610,10 +610,44 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
     kf[0] = gl_frag(krow, 0, fc); kf[1] = gl_frag(krow, 1, fc);
     vf[0] = gl_frag(vrow, 0, fc); vf[1] = gl_frag(vrow, 1, fc);
   };
+  // The Q / dO panels of phase B: with nwaves < nqt < 2 nwaves (T = 197: 13 tiles, 8 waves) the last 2 nwaves - nqt waves have no
+  // second query tile in phase A — they fetch the panels into registers while the others finish (the rows >= T of both panels stay
+  // zero from the K / V staging), and put them into LDS after the barrier. Otherwise every thread stages after the barrier.
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int NPF = 18;
+  const int first_early = nqt - nwaves, tot = 2 * T * 8;
+  const int net = (nwaves - first_early) * 64;                               // threads of the early waves
+  const bool pre = first_early > 0 && first_early < nwaves && net * NPF >= tot;      // uniform
+  const bool early = pre && wave >= first_early;
+  u32x4_t pf[NPF];
+  if (early) {
+    const int et = (wave - first_early) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int c = min(et + k * net, tot - 1);
+      const int pnl = c >= T * 8, rc = c - pnl * (T * 8);
+      const bf16_t* src = pnl ? dob + (size_t)(rc >> 3) * ldo : qb + (size_t)(rc >> 3) * ld;
+      pf[k] = *reinterpret_cast<const u32x4_t*>(src + (rc & 7) * 8);
+    }
+  }
   load_keys(wave);
   __syncthreads();             // every wave is done with the K / V panels (and del_s is complete)
-  stage_rowmajor<TP>(P0, qb, ld, T);
-  stage_rowmajor<TP>(P1, dob, ldo, T);
+  if (pre) {
+    if (early) {
+      const int et = (wave - first_early) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        const int c = et + k * net;
+        if (c < tot) {
+          const int pnl = c >= T * 8, rc = c - pnl * (T * 8);
+          *reinterpret_cast<u32x4_t*>((pnl ? P1 : P0) + lds_off(rc >> 3, (rc & 7) * 8)) = pf[k];
+        }
+      }
+    }
+  } else {
+    stage_rowmajor<TP>(P0, qb, ld, T);
+    stage_rowmajor<TP>(P1, dob, ldo, T);
+  }
   __syncthreads();
   for (int kp = wave; kp < nqt; kp += nwaves) {
     if (kp != wave) load_keys(kp);
