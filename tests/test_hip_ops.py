@@ -328,7 +328,7 @@ def test_attention_fwd_persistent_bit_identical_to_per_item_kernel(ops, B, T, H,
     assert torch.equal(o1, o1b) and torch.equal(lse1, lse1b)
 
 
-@pytest.mark.parametrize("B,T,H", [(3, 197, 8), (2, 150, 4), (5, 224, 2)])
+@pytest.mark.parametrize("B,T,H", [(3, 197, 8), (2, 150, 4), (5, 224, 2), (150, 197, 8), (131, 150, 12), (300, 224, 2)])
 def test_attention_bwd_fused_bit_identical_to_two_kernel_form(ops, B, T, H, monkeypatch):
     """bf16, T > 64: the single-launch backward (dQ phase then dK/dV phase over the same LDS panels) == the dQ kernel + the dK/dV kernel."""
     dt = torch.bfloat16
