@@ -1,18 +1,23 @@
 #!/usr/bin/env python
 """bench.py — forgetting-step images/sec of the GS-LoRA step on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-Workload (config.workload): BASELINE.json configs[1] — ViT-P8S8 depth 6, 112 px, LoRA r=8 on both
-FFN linears, CosFace-100 head, per-GPU batch 512 remain + 512 forget images resident in HBM,
-bf16 speed mode, dropout 0.1 / emb-dropout 0.1 (the reference's training setting), prototype term on,
-FusedAdamW (lr 1e-2, wd 0.05). One "step" = the engine_cl.train_one_epoch loop body
-(2 forwards, 5 loss terms, backward, gradient all-reduce when N>1, AdamW). Weak scaling.
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU over RCCL. Either the driver launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when WORLD_SIZE is not set,
+bench.py launches them itself through torch.distributed.run on 127.0.0.1. The process group must have exactly N ranks, otherwise
+the run fails.
+
+Workload (config.workload): BASELINE.json configs[1] — ViT-P8S8 depth 6, 112 px, LoRA r=8 on both FFN linears, CosFace-100 head,
+per-GPU batch 512 remain + 512 forget images resident in HBM (weak scaling; `--scaling strong` keeps the GLOBAL batch at 512 + 512),
+bf16 speed mode, dropout 0.1 / emb-dropout 0.1 (the reference's training setting), prototype term on, FusedAdamW (lr 1e-2, wd 0.05).
+One "step" = the engine_cl.train_one_epoch loop body (2 forwards, 5 loss terms, backward, packed scalar all-reduce + gradient
+all-reduce when N > 1, AdamW). Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +33,12 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0       # HBM3E, same guide
 FULL = dict(image_size=112, patch_size=8, dim=512, depth=6, heads=8, mlp_dim=2048, num_class=100, lora_rank=8)
 HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-4, BND=105.0, BND_pro=18.0, pro_f=0.01, pro_r=0.01)
+# minimal necessary FLOPs per image (2 m n k, no recompute, no dW of frozen weights)
+FLOP_IMG_ALG = 15.646e9
+# what this path executes: the last block's backward runs on the B cls rows only (its stream gradient is exactly zero elsewhere), i.e.
+# one generic-layer backward (1.43065 GFLOP/img) shrinks to 1/197 of its rows
+FLOP_IMG_EXEC = FLOP_IMG_ALG - 1.43065e9 * (196.0 / 197.0)
+T_TOK = 197
 
 
 def build_model(dtype, dropout, device):
@@ -45,21 +56,50 @@ def build_model(dtype, dropout, device):
     return m.to(device).set_compute_dtype(dtype).train()
 
 
-def cpu_baseline(batch=16, steps=2):
-    """The CPU oracle (a port of the reference step; the reference's Python cannot travel to the GPU
-    box) timed on the host cores: fp32, B=16+16, full-size model, dropout omitted (the reference spends
-    ~26 % of its CPU time in bernoulli_, so this baseline is FASTER than the reference itself)."""
+def host_cpu():
+    """(physical cores visible to this process, CPU model string)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n_phys = len(cores) or (os.cpu_count() or 1)
+    try:
+        n_phys = min(n_phys, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, n_phys), model
+
+
+def cpu_baseline(batch=16, steps=3, dropout=0.1):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the build's CPU restatement of the reference step (oracle port; the reference's Python
+    cannot travel to the GPU box) timed on the host cores: fp32, B = 16 + 16, full-size model, dropout 0.1 ON (torch's own Bernoulli
+    dropout at the reference's 19 sites, as the reference trains), torch.set_num_threads(physical cores), 1 warm-up + `steps` timed."""
     from oracle import gslora_oracle as O
     from oracle import recipe
     cfg = recipe.cfg_full()
-    cores = min(32, os.cpu_count() or 1)     # more threads than this only adds fork/join overhead at B=16
+    cores, model = host_cpu()
     torch.set_num_threads(cores)
     st = recipe.make_state(cfg)
     xr = torch.tensor(recipe.make_images(cfg, batch, seed=1)); yr = torch.tensor(recipe.make_labels(cfg, batch, seed=1, hi=80))
     xf = torch.tensor(recipe.make_images(cfg, batch, seed=2)); yf = torch.tensor(recipe.make_labels(cfg, batch, seed=2, lo=80))
     proto = torch.tensor(recipe.make_prototypes(cfg))
     hy = dict(beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"], BND_pro=HYPER["BND_pro"], pro_f_weight=HYPER["pro_f"],
-              pro_r_weight=HYPER["pro_r"], wd=HYPER["wd"])
+              pro_r_weight=HYPER["pro_r"], wd=HYPER["wd"], dropout=dropout)
     opt = None
     times = []
     for s in range(steps + 1):
@@ -70,8 +110,83 @@ def cpu_baseline(batch=16, steps=2):
             times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
     return {"value": round(2 * batch / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle train_step (fp32 torch CPU, no dropout), ViT-P8S8 d6 r8, B={batch}+{batch}, median of {steps} steps "
-                      f"after 1 warm-up, {t:.2f} s/step"}
+            "sample": f"oracle train_step (fp32 torch CPU, dropout {dropout}), ViT-P8S8 d6 r8, B={batch}+{batch}, median of {steps} timed steps "
+                      f"after 1 warm-up, {t:.2f} s/step, {cores} threads = physical cores visible, CPU: {model}"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class StubWorkload:
+    """GSL_BENCH_STUB=1 (tests/test_bench_launch.py): a CPU stand-in step under gloo, so that the launch / process-group / barrier /
+    max-over-ranks / JSON plumbing of this file is exercised where no GPU exists. Never measured, never used by the driver."""
+    device_type = "cpu"
+
+    def __init__(self, args, rank, world, dev):
+        self.B = args.batch
+        self.w = torch.ones(64, 64)
+
+    def step(self):
+        self.w = torch.tanh(self.w @ self.w * 1e-3)
+        if dist.is_initialized():
+            dist.all_reduce(self.w)
+        return self.w.reshape(-1)[:8].clone()
+
+    def profile(self):
+        return {}
+
+
+class GsLoraWorkload:
+    device_type = "cuda"
+
+    def __init__(self, args, rank, world, dev):
+        from gslora_hip.optim import FusedAdamW
+        from gslora_hip.step import GraphedStep, gs_lora_step
+        self.args, self.B = args, args.batch
+        B = self.B
+        self.model = build_model(args.dtype, args.dropout, dev)
+        self.opt = FusedAdamW([p for p in self.model.parameters() if p.requires_grad], lr=HYPER["lr"], weight_decay=HYPER["wd"], eps=1e-8)
+        crit = torch.nn.CrossEntropyLoss()
+        g = torch.Generator(device="cpu").manual_seed(1337 + rank)
+        import random
+        order = list(range(100)); random.seed(1337); random.shuffle(order)
+        mk_img = lambda: (torch.randint(0, 256, (B, 3, 112, 112), generator=g, dtype=torch.uint8).float() / 255.0).to(dev)
+        self.x_r, self.x_f = mk_img(), mk_img()
+        self.y_r = torch.tensor(order[:80])[torch.randint(0, 80, (B,), generator=g)].to(dev)
+        self.y_f = torch.tensor(order[80:])[torch.randint(0, 20, (B,), generator=g)].to(dev)
+        self.proto = torch.randn(100, FULL["dim"], generator=g).to(dev)
+        self.graph = bool(args.graph)
+        self.stepper = GraphedStep(self.model, self.opt, crit) if args.graph else (lambda *a, **k: gs_lora_step(self.model, self.opt, crit, *a, **k))
+
+    def step(self):
+        return self.stepper(self.x_r, self.y_r, self.x_f, self.y_f, beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"],
+                            use_structure=True, group_type="block", use_prototype=True, proto_table=self.proto, w_f=HYPER["pro_f"],
+                            w_r=HYPER["pro_r"], BND_pro=HYPER["BND_pro"])
+
+
+def kernel_roofline(name, what, recs, flops_of, bytes_of):
+    """Live numbers of one GEMM family: HIP-event duration of every launch in the timed region (events recorded on the stream the
+    kernel is launched on), algorithmic FLOPs / bytes per launch from the launch's own shape."""
+    durs = [a.elapsed_time(b) for a, b, *_ in recs]
+    dense = [(d, r) for d, r in zip(durs, recs) if r[2] >= 4096]           # the cls-row launches of the last block are a different shape
+    if not dense:
+        return None
+    avg_ms = sum(d for d, _ in dense) / len(dense)
+    _, _, M, N, K, K2 = dense[0][1]
+    fl, by = flops_of(M, N, K, K2), bytes_of(M, N, K, K2)
+    tf = fl / (avg_ms * 1e-3) / 1e12
+    gbs = by / (avg_ms * 1e-3) / 1e9
+    return {"kernel": name, "what": what, "launches_timed": len(dense), "rows_per_launch": M, "avg_ms": round(avg_ms, 4),
+            "algorithmic_flops": fl, "algorithmic_bytes": by, "mfma_tflops": round(tf, 2), "mfma_frac_of_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+            "hbm_gbs": round(gbs, 1), "hbm_frac_of_peak": round(gbs / PEAK_HBM_GBS, 4), "arithmetic_intensity_flop_per_byte": round(fl / by, 1)}
 
 
 def main():
@@ -79,77 +194,79 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU images per forward (remain and forget each)")
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU images per forward (remain and forget each); with --scaling strong: the GLOBAL batch")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (the engines' default for launch-bound batches)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as captured HIP graph segments (the engines' default for launch-bound batches)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    stub = os.environ.get("GSL_BENCH_STUB") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the GS-LoRA step has no CPU fallback)")
     # development knobs for exercising the world > 1 code path on a 1-GPU box: GSL_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # GSL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device). Never set by the driver.
     if os.environ.get("GSL_BENCH_ONE_DEVICE") == "1":
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if env_world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GSL_BENCH_BACKEND", "nccl")
+        backend = "gloo" if stub else os.environ.get("GSL_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')}); "
+                         "launch one rank per GPU with torch.distributed.run, or call bench.py without a launcher")
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {args.batch} is not divisible by {world} ranks")
+        args.batch //= world
 
-    from gslora_hip import ops
-    from gslora_hip.optim import FusedAdamW
-    from gslora_hip.step import gs_lora_step
-    model = build_model(args.dtype, args.dropout, dev)
-    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=HYPER["lr"], weight_decay=HYPER["wd"], eps=1e-8)
-    crit = torch.nn.CrossEntropyLoss()
+    if not stub:
+        from gslora_hip import ops
+    wl = (StubWorkload if stub else GsLoraWorkload)(args, rank, world, dev)
     B = args.batch
-    g = torch.Generator(device="cpu").manual_seed(1337 + rank)
-    import random
-    order = list(range(100)); random.seed(1337); random.shuffle(order)
-    mk_img = lambda: (torch.randint(0, 256, (B, 3, 112, 112), generator=g, dtype=torch.uint8).float() / 255.0).to(dev)
-    x_r, x_f = mk_img(), mk_img()
-    y_r = torch.tensor(order[:80])[torch.randint(0, 80, (B,), generator=g)].to(dev)
-    y_f = torch.tensor(order[80:])[torch.randint(0, 20, (B,), generator=g)].to(dev)
-    proto = torch.randn(100, FULL["dim"], generator=g).to(dev)
-
-    from gslora_hip.step import GraphedStep
-    stepper = GraphedStep(model, opt, crit) if (args.graph and world == 1) else (lambda *a, **k: gs_lora_step(model, opt, crit, *a, **k))
-
-    def step():
-        return stepper(x_r, y_r, x_f, y_f, beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"],
-                            use_structure=True, group_type="block", use_prototype=True, proto_table=proto, w_f=HYPER["pro_f"],
-                            w_r=HYPER["pro_r"], BND_pro=HYPER["BND_pro"])
 
     def fence():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not stub:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     fence()
-    ops.PROFILE = {"ffn1": []}
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step HIP events (no sync inside the timed region)
+    if not stub:
+        ops.PROFILE = {"ffn1": [], "ffn2dx": []}
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step HIP events (no sync inside the timed region)
+        marks[0].record()
     t0 = time.perf_counter()
-    marks[0].record()
     for i in range(args.steps):
-        pack = step()
-        marks[i + 1].record()
+        pack = wl.step()
+        if not stub:
+            marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof = {}
+    per_step = [0.0]
+    if not stub:
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,44 +275,59 @@ def main():
 
     if rank == 0:
         r = FULL["lora_rank"]
-        durs = [a.elapsed_time(b) for a, b, *_ in prof["ffn1"]]       # ms per launch of the fused FFN1+LoRA+GELU GEMM
-        avg_ms = sum(durs) / max(1, len(durs))
-        # algorithmic flops of one launch: 2*M*N*K for the dense part + 2*M*N*r for the LoRA up-projection K segment
-        fl = [2.0 * m_ * n_ * k1 + 2.0 * m_ * n_ * r for _, _, m_, n_, k1, _ in prof["ffn1"]]
-        flops = sum(fl) / max(1, len(fl))
-        M = prof["ffn1"][0][2] if prof["ffn1"] else 2 * B * 197
-        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        alg_bytes = int(M * (FULL["dim"] + 64) * 2 + 2 * M * FULL["mlp_dim"] * 2)     # A + LoRA segment read, h + GELU' written (bf16)
-        traffic = None
-        try:   # HBM bytes per launch of the roofline kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
+        D, MLP = FULL["dim"], FULL["mlp_dim"]
+        kernels = []
+        if prof.get("ffn1"):
+            # fused FFN1: [x | s x A1^T] [W1 | B1]^T, bias + GELU + GELU' + dropout, TWO bf16 [M, mlp] outputs.
+            # FLOPs = 2 M N (K + r); bytes = A + LoRA segment read, h + GELU' written
+            kernels.append(kernel_roofline(
+                "gsl_gemm_nt<BIAS_GELU>", "fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout (forward)", prof["ffn1"],
+                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * N * r, lambda M, N, K, K2: int(M * (K + K2) * 2 + 2 * M * N * 2)))
+        if prof.get("ffn2dx"):
+            # FFN2-dX: dZ = (dY W2 + t A2) * GELU' with t = s dY B2 in the kernel, + the two LoRA-gradient reductions of its tiles.
+            # FLOPs = 2 M N K + LoRA (down 2 M K r, up 2 M N r, two reductions 2 * 2 M N r); bytes = dY + GELU' + h read, dZ written
+            kernels.append(kernel_roofline(
+                "gsl_gemm_nt_lora_mulgrad", "FFN2-dX x GELU' + in-kernel LoRA + dB1 / dA2 reductions (backward)", prof["ffn2dx"],
+                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * K * r + 6.0 * M * N * r, lambda M, N, K, K2: int(M * K * 2 + 3 * M * N * 2)))
+        kernels = [k for k in kernels if k]
+        traffic, traffic_source = None, None
+        try:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("rows_per_launch") == M:
-                traffic = pj["hbm_bytes_per_launch"]
+            if kernels and pj.get("rows_per_launch") == kernels[0]["rows_per_launch"]:
+                traffic, traffic_source = pj["hbm_bytes_per_launch"], pj.get("source")
         except Exception:
             pass
+        k0 = kernels[0] if kernels else None
         ips = world * 2 * B * args.steps / elapsed
         out = {
             "metric": "forgetting-step images/sec, ViT-P8S8 d6 112px r=8", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8, per-GPU batch {B} remain + "
-                                   f"{B} forget (112x112 synthetic), dropout {args.dropout}, prototype term on, FusedAdamW",
-                       "global_batch": world * 2 * B, "tokens_per_image": 197, "parallelism": f"dp{world}"},
-            # The fused FFN1 GEMM writes TWO [M, 2048] bf16 outputs (h and GELU'): 430 GFLOP over 1.885 GB of algorithmic bytes is
-            # 228 FLOP/B, below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B) -> HBM is the roof that bounds it.
-            "roofline": {"bound": "hbm", "kernel": "gsl_gemm_nt<BIAS_GELU> (fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout, fwd)",
-                         "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if avg_ms > 0 else 0.0,
-                         "launches_timed": len(durs), "rows_per_launch": M, "avg_ms": round(avg_ms, 4), "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes, "arithmetic_intensity_flop_per_byte": round(flops / alg_bytes, 1),
-                         "mfma_tflops": round(ach, 2), "mfma_frac_of_peak": round(ach / PEAK_BF16_TFLOPS, 4)},
-            "step_flops_frac_of_peak": round((15.646e9 * 2 * B * args.steps / elapsed) / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("STUB (CPU plumbing test, not a measurement)" if stub else
+                                    f"ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8, per-GPU batch {B} remain + "
+                                    f"{B} forget (112x112 synthetic), dropout {args.dropout}, prototype term on, FusedAdamW"),
+                       "global_batch": world * 2 * B, "tokens_per_image": T_TOK, "parallelism": f"dp{world}"},
+        }
+        if k0:
+            # the step's roof is the bf16 MFMA peak; the dominant kernel is priced against it with 8(d)'s FLOPs
+            # (2 M N (K + r)). Its HBM view (it writes two [M, mlp] outputs: 228 FLOP/B, below the 312 FLOP/B ridge) is carried beside it.
+            out["roofline"] = {"bound": "mfma", "kernel": k0["kernel"] + " — " + k0["what"], "achieved": k0["mfma_tflops"],
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k0["mfma_frac_of_peak"], "traffic": traffic,
+                               "traffic_source": traffic_source, "launches_timed": k0["launches_timed"],
+                               "rows_per_launch": k0["rows_per_launch"], "avg_ms": k0["avg_ms"],
+                               "algorithmic_flops": k0["algorithmic_flops"], "algorithmic_bytes": k0["algorithmic_bytes"],
+                               "hbm_view": {"achieved": k0["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k0["hbm_frac_of_peak"]},
+                               "kernels": kernels}
+        out.update({
+            "step_flops_frac_of_peak": round((FLOP_IMG_ALG * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "step_flops_frac_of_peak_executed": round((FLOP_IMG_EXEC * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "flops_per_image": {"algorithmic_8d": FLOP_IMG_ALG, "executed": round(FLOP_IMG_EXEC)},
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
-            "hip_graph": bool(args.graph and world == 1),
+            "hip_graph": bool(args.graph),
             "ms_per_step_events": {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
                                    "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
+        })
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -351,12 +351,47 @@ __global__ void loss_combine_kernel(const float* ce_r_sum, const float* ce_f_sum
   const float tot = loss_forget * beta + loss_remain + st * alpha + (pro_f + pro_r);
   total[0] = tot;
   meters[0] = beta * loss_forget; meters[1] = loss_remain; meters[2] = tot; meters[3] = alpha * st;
-  meters[4] = hit_f[0] * (100.0f / n_f); meters[5] = hit_r[0] * (100.0f / n_r); meters[6] = pro_f; meters[7] = pro_r;
+  meters[4] = hit_f[0] * (100.0f / n_f); meters[5] = hit_r[0] * (100.0f / n_r); meters[7] = pro_r;
+  // without the prototype term the reference still LOGS w_f * relu(BND_pro - 0) in losses_prototype_forget (engine_cl.py:103-110,
+  // engine.py:118-125: prototype_loss_forget is the constant 0 there); the total does not contain it
+  meters[6] = kl_f_sum ? pro_f : w_f * fmaxf(BND_pro, 0.f);
   coefs[0] = 1.0f / n_r;                                     // d total / d ce_r_sum
   coefs[1] = hinge_f > 0.f ? -beta / n_f : 0.f;              // d total / d ce_f_sum   (relu'(0) = 0 as in torch)
   coefs[2] = (kl_f_sum && hinge_p > 0.f) ? -w_f / n_f : 0.f; // d total / d kl_f_sum
   coefs[3] = kl_r_sum ? w_r / n_r : 0.f;                     // d total / d kl_r_sum
   coefs[4] = alpha;                                          // d total / d structure
+}
+// Data-parallel form: the eight batch sums arrive as ONE all-reduced device array (gslora_hip/step.py packs and sum-all-reduces them
+// before the hinges so that relu(BND - mean CE_f) / relu(BND_pro - mean KL_f) see the GLOBAL batch means, the reference's single-GPU /
+// nn.DataParallel semantics, train_own_forget_cl.py:494-497): pack8 = [ce_r, ce_f, hit_r, hit_f, n_r, n_f, kl_f, kl_r]. The batch sizes
+// are read from the pack, so no host value depends on the other ranks.
+__global__ void loss_combine_pack_kernel(const float* pack, const float* structure, int has_proto, float beta, float BND, float alpha,
+                                         float w_f, float w_r, float BND_pro, float* total, float* meters, float* coefs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float n_r = pack[4], n_f = pack[5];
+  const float loss_remain = pack[0] / n_r;
+  const float hinge_f = BND - pack[1] / n_f;
+  const float loss_forget = fmaxf(hinge_f, 0.f);
+  const float st = structure ? structure[0] : 0.f;
+  float pro_f = 0.f, pro_r = 0.f, hinge_p = 0.f;
+  if (has_proto) { hinge_p = BND_pro - pack[6] / n_f; pro_f = w_f * fmaxf(hinge_p, 0.f); pro_r = w_r * (pack[7] / n_r); }
+  const float tot = loss_forget * beta + loss_remain + st * alpha + (pro_f + pro_r);
+  total[0] = tot;
+  meters[0] = beta * loss_forget; meters[1] = loss_remain; meters[2] = tot; meters[3] = alpha * st;
+  meters[4] = pack[3] * (100.0f / n_f); meters[5] = pack[2] * (100.0f / n_r); meters[7] = pro_r;
+  meters[6] = has_proto ? pro_f : w_f * fmaxf(BND_pro, 0.f);
+  coefs[0] = 1.0f / n_r;
+  coefs[1] = hinge_f > 0.f ? -beta / n_f : 0.f;
+  coefs[2] = (has_proto && hinge_p > 0.f) ? -w_f / n_f : 0.f;
+  coefs[3] = has_proto ? w_r / n_r : 0.f;
+  coefs[4] = alpha;
+}
+extern "C" int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_proto, float beta, float BND, float alpha,
+                                     float w_f, float w_r, float BND_pro, float* total, float* meters8, float* coefs5, gsl_stream_t s) {
+  GSL_CHECK_ARG(pack8 && total && meters8 && coefs5, "null");
+  hipLaunchKernelGGL(loss_combine_pack_kernel, dim3(1), dim3(64), 0, as_stream(s), pack8, structure, has_proto, beta, BND, alpha, w_f, w_r,
+                     BND_pro, total, meters8, coefs5);
+  return check_launch("gsl_loss_combine_pack");
 }
 extern "C" int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* kl_f_sum, const float* kl_r_sum,
                                 const float* structure, const float* hit_r, const float* hit_f, float n_r, float n_f, float beta,

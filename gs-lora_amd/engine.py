@@ -4,12 +4,17 @@ Differences from engine_cl that the reference has and that are kept: the structu
 by `epoch < cfg["ALPHA_EPOCH"]` (:82-90), the prototype bound is the literal 18 (:105), grouping
 comes from cfg["GROUP_TYPE"] in {block, lora, matrix} (:585-650), and with cfg["few_shot"] and a
 longer forget loader the roles of the two loaders are swapped (:53-236)."""
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
+import loralib as _lora
 import util.utils as util
-from engine_cl import DISP_FREQ, VER_FREQ, _log, _unwrap, eval_data  # noqa: F401
-from engine_cl import evaluate as _evaluate_cl
+from engine_cl import DISP_FREQ, VER_FREQ, _log, _unwrap  # noqa: F401
+from engine_cl import eval_data as _eval_data_cl
+from util.utils import get_time
 from gslora_hip import losses as _losses
 from gslora_hip.step import MeterQueue, gs_lora_step, pick_stepper  # noqa: F401
 from util.data_prefetcher import data_prefetcher
@@ -80,17 +85,57 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
             meters["losses_prototype_remain"])
 
 
+@contextlib.contextmanager
+def _evaluation_copy(model):
+    """What the reference gets from `copy.deepcopy(model).eval()` (engine.py:449, :514), without copying 77 MB of frozen weights per
+    call: the un-merged weights of the adapter layers are stashed, the model is evaluated in eval() (merged) mode, and on exit the stashed
+    tensors are copied back and every module's `training` flag restored — the training weights come back BIT FOR BIT (an arithmetic
+    un-merge would leave one f32 rounding per evaluation, which the reference's training weights never see)."""
+    layers = [m for m in model.modules() if isinstance(m, (_lora.Linear, _lora.MergedLinear)) and m.r > 0 and m.merge_weights]
+    modes = [(m, m.training) for m in model.modules()]
+    stash = [(l, l.weight.detach().clone()) for l in layers if not l.merged]
+    try:
+        model.eval()
+        yield model
+    finally:
+        with torch.no_grad():
+            for l, w in stash:
+                l.weight.copy_(w)      # in place: bumps _version, the operand caches of the HIP path refresh
+                l.merged = False
+        for m, t in modes:
+            m.training = t
+
+
 def evaluate(model, testloader_forget, testloader_remain, device, batch, epoch, forget_acc_before, highest_H_mean, cfg,
              optimizer, testloader_open=None):
-    """The reference deep-copies the model before eval() (:449) so the training weights never see the
-    merge/un-merge round trip; the HIP path gets the same guarantee by restoring train() afterwards
-    from the SAME parameters (merge and un-merge are exact inverses up to one f32 rounding)."""
-    was_training = model.training
-    out = _evaluate_cl(model, testloader_forget, testloader_remain, device, batch, epoch, forget_acc_before,
-                       highest_H_mean, cfg, optimizer, task_i="0", testloader_open=testloader_open)
-    if was_training:
-        model.train()
-    return out
+    """Reference engine.py:436-498: accuracies of a COPY of the model in eval mode, H-mean (no epsilon in this engine), save of the best
+    checkpoint (merged weights, as the copy is in eval mode) and pruning to two checkpoints once the work directory holds >= 3 entries."""
+    lr = optimizer.param_groups[0]["lr"]
+    print("current learning rate:{:.7f}".format(lr))
+    print("Perfom evaluation on test set and save checkpoints...")
+    with _evaluation_copy(model) as m:
+        forget_acc = _eval_data_cl(m, testloader_forget, device, "forget", batch)
+        remain_acc = _eval_data_cl(m, testloader_remain, device, "remain", batch)
+        if testloader_open is not None:
+            _eval_data_cl(m, testloader_open, device, "open", batch)
+        forget_drop = forget_acc_before - forget_acc
+        Hmean = 2 * forget_drop * remain_acc / (forget_drop + remain_acc)
+        if Hmean > highest_H_mean:
+            highest_H_mean = Hmean
+            net = m.module if cfg["MULTI_GPU"] else m
+            torch.save(net.state_dict(), os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
+                cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time())))
+            if len(os.listdir(cfg["WORK_PATH"])) >= 3:
+                ckpts = sorted((f for f in os.listdir(cfg["WORK_PATH"]) if f.endswith(".pth")),
+                               key=lambda f: os.path.getmtime(os.path.join(cfg["WORK_PATH"], f)))
+                os.remove(os.path.join(cfg["WORK_PATH"], ckpts[0]))
+    return highest_H_mean
+
+
+def eval_data(model, dataloader, device, mode: str, batch: int = 0):
+    """Reference engine.py:501-529: accuracy (0-100) of a copy of the model in eval mode; the caller's model keeps its mode and weights."""
+    with _evaluation_copy(model) as m:
+        return _eval_data_cl(m, dataloader, device, mode, batch)
 
 
 def _check_group_pos(model, group_pos):

@@ -140,6 +140,33 @@ def combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r
                           BND_pro)
 
 
+class _CombinePack(torch.autograd.Function):
+    """Data-parallel scalar tail: value from the all-reduced pack (global batch sums and sizes), gradient with respect to this rank's
+    local sums (d global sum / d local sum = 1): one kernel forward, one 5-element multiply backward (gsl_loss_combine_pack)."""
+
+    @staticmethod
+    def forward(ctx, pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro):
+        has_proto = kl_f_sum is not None
+        total, meters, coefs = ops.loss_combine_pack(pack.detach().float().contiguous(),
+                                                     None if structure is None else structure.detach().float().contiguous(),
+                                                     has_proto, beta, BND, alpha, w_f, w_r, BND_pro)
+        ctx.save_for_backward(coefs)
+        ctx.has = (has_proto, structure is not None)
+        ctx.mark_non_differentiable(meters)
+        return total, meters
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        (coefs,) = ctx.saved_tensors
+        gc = coefs * g
+        has_p, has_s = ctx.has
+        return (None, gc[0], gc[1], gc[2] if has_p else None, gc[3] if has_p else None, gc[4] if has_s else None) + (None,) * 6
+
+
+def combine_pack(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro):
+    return _CombinePack.apply(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro)
+
+
 _table_cache = {}
 
 

@@ -88,12 +88,19 @@ def gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, *, epilogue=L.EPI_STORE, bia
     return out
 
 
-def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True):
+def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True, tag=None):
     """out = (A W^T + t Q^T) * aux with t = lora_scale * A P^T (as gemm_nt_lora, epilogue MUL) and, from the same tiles,
     G1[n*g1s[0] + j*g1s[1]] (+)= sum_m out[m,n] U1[m,j] and G2[n*g2s[0] + j*g2s[1]] (+)= sum_m Y2[m,n] t[m,j]."""
     _need(A, W, P, Q, tout, out, aux, U1, Y2)
     M, K = A.shape
     N = W.shape[0]
+    if PROFILE is not None and tag in PROFILE:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate)
+        ev[1].record()
+        PROFILE[tag].append((ev[0], ev[1], M, N, K, 0))
+        return out
     if not (out.stride(0) == aux.stride(0) == Y2.stride(0) and U1.stride(1) == 1):
         raise RuntimeError("gemm_nt_lora_mulgrad: out / aux / Y2 must share one row stride")
     lib = L.load()
@@ -195,6 +202,16 @@ def loss_combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f
                                       float(n_r), float(n_f), float(beta), float(BND), float(alpha), float(w_f), float(w_r),
                                       float(BND_pro), out.data_ptr(), out.data_ptr() + 4, out.data_ptr() + 36, _stream()),
             "gsl_loss_combine")
+    return out[0], out[1:9], out[9:14]
+
+
+def loss_combine_pack(pack8, structure, has_proto, beta, BND, alpha, w_f, w_r, BND_pro):
+    """Data-parallel scalar tail from the all-reduced 8-float pack -> (total [0-dim], meters [8], coefs [5]) — see gsl_loss_combine_pack."""
+    _need(pack8, structure)
+    out = torch.empty(14, device=pack8.device, dtype=torch.float32)
+    L.check(L.load().gsl_loss_combine_pack(_p(pack8), _p(structure), 1 if has_proto else 0, float(beta), float(BND), float(alpha),
+                                           float(w_f), float(w_r), float(BND_pro), out.data_ptr(), out.data_ptr() + 4,
+                                           out.data_ptr() + 36, _stream()), "gsl_loss_combine_pack")
     return out[0], out[1:9], out[9:14]
 
 

@@ -31,19 +31,89 @@ def _globalize(local_sum, global_sum_detached):
 
 class HipBackend:
     """The loss / gradient-bucket operations of the step on the HIP kernels (the only product backend).
-    tests/test_ddp_gloo.py injects a CPU stand-in with the same four methods to exercise the data-parallel
+    tests/test_ddp_gloo.py injects a CPU stand-in with the same methods to exercise the data-parallel
     arithmetic of gs_lora_step under gloo; nothing in the package ever selects another backend."""
     ce_sum_top1 = staticmethod(losses.ce_sum_top1)
     proto_kl_sum = staticmethod(losses.proto_kl_sum)
     ce_sum_top1_split = staticmethod(losses.ce_sum_top1_split)
     proto_kl_sum_split = staticmethod(losses.proto_kl_sum_split)
     structure_loss = staticmethod(losses.structure_loss)
+    combine = staticmethod(losses.combine)
+    combine_pack = staticmethod(losses.combine_pack)
 
     @staticmethod
     def grad_bucket(net):
         bucket = net.lora_bucket()
         bucket.attach_grads()
         return bucket.grad
+
+    @staticmethod
+    def early_grad_slice(net):
+        """(flat gradient bucket, first element of block 1): the LoRA gradients of blocks 1 .. L-1 are final once the backward chain
+        reaches block 0, so their slice of the bucket can be all-reduced while block 0's backward still runs."""
+        b = net.lora_bucket()
+        if b is None or b.ngroups_block < 2:
+            return None
+        return b.grad, b.offsets[b.per_layer]
+
+
+class _OverlappedBucketReduce:
+    """Gradient all-reduce in two messages: blocks 1..L-1 on a side stream as soon as block 1's gradients are written (it runs
+    under block 0's FFN backward), block 0 afterwards. The structure-loss gradient is parameter-only and pre-scaled by 1/world; its
+    autograd node is created after the network's, so it has been added to the bucket before the network backward starts."""
+
+    def __init__(self, net, backend):
+        self.net, self.backend, self.work, self.split, self.side = net, backend, None, None, None
+        sl = backend.early_grad_slice(net) if hasattr(backend, "early_grad_slice") else None
+        runner = net.runner() if hasattr(net, "runner") else None
+        if sl is not None and runner is not None:
+            self.flat, self.split, self.runner = sl[0], sl[1], runner
+            runner.grad_hook = self._hook
+
+    def _hook(self, layer):
+        if layer != 1 or self.work is not None:
+            return
+        if self.flat.is_cuda:
+            if self.side is None:
+                self.side = _side_stream(self.flat.device)
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.work = dist.all_reduce(self.flat[self.split:], async_op=True)
+        else:
+            self.work = dist.all_reduce(self.flat[self.split:], async_op=True)
+
+    def finish(self):
+        if self.split is None:
+            dist.all_reduce(self.backend.grad_bucket(self.net))      # one flat message: 0.94 MiB for ViT-P8S8 r=8
+            return
+        self.runner.grad_hook = None
+        if self.work is None:        # the hook never fired (single block, or a backward that stopped early)
+            dist.all_reduce(self.flat)
+            return
+        dist.all_reduce(self.flat[:self.split])
+        self.work.wait()
+        if self.flat.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _check_not_replicated(model):
+    """nn.DataParallel over several devices replicates the module per forward; the replicas' hand-written backward would write into
+    throw-away gradient buckets and the real LoRA parameters would only ever see the structure-loss gradient. The multi-GPU mode of
+    this build is one process per GPU under torch.distributed."""
+    if isinstance(model, nn.DataParallel) and len(model.device_ids or []) > 1:
+        raise RuntimeError("gs-lora_amd: nn.DataParallel over several devices is not supported by the HIP path (replicas cannot "
+                           "back-propagate into the flat LoRA gradient bucket). Launch one process per GPU with torch.distributed "
+                           "(python -m torch.distributed.run --nproc-per-node N ...): gs_lora_step is data-parallel there.")
 
 
 def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
@@ -53,6 +123,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     Returns a packed DEVICE tensor of the 8 meter values (no host sync here):
       [beta*loss_forget, loss_remain, total, alpha*structure, top1_forget%, top1_remain%,
        w_f*relu(BND_pro-KL_f), w_r*KL_r]"""
+    _check_not_replicated(model)
     net = model.module if isinstance(model, nn.DataParallel) else model
     world = _world()
     dev = x_r.device
@@ -69,11 +140,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     else:
         out_r, emb_r = model(x_r.float(), y_r)
         out_f, emb_f = model(x_f.float(), y_f)
-    if world > 1:      # device scalars: they travel in the packed all-reduce below (fill kernels, no pageable H2D copy)
-        n_r = torch.full((), float(x_r.size(0)), device=dev)
-        n_f = torch.full((), float(x_f.size(0)), device=dev)
-    else:
-        n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
+    n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
     if split is not None:
         ce_r_sum, hit_r, ce_f_sum, hit_f = backend.ce_sum_top1_split(split[0], split[2], split[3])
     elif _plain_ce(criterion):
@@ -84,52 +151,38 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         ce_f_sum = criterion(out_f, y_f) * n_f
         hit_r = backend.ce_sum_top1(out_r.detach(), y_r)[1]
         hit_f = backend.ce_sum_top1(out_f.detach(), y_f)[1]
-    zero = torch.zeros((), device=dev)
     if use_prototype and split is not None:
         kl_f_sum, kl_r_sum = backend.proto_kl_sum_split(split[1], split[2], proto_table, split[3])
     elif use_prototype:
         kl_f_sum = backend.proto_kl_sum(emb_f, y_f, proto_table)
         kl_r_sum = backend.proto_kl_sum(emb_r, y_r, proto_table)
     else:
-        kl_f_sum = kl_r_sum = zero
-    g_nr, g_nf = n_r, n_f
-    if world > 1:
-        # every entry detached: the collective must not become a node of the autograd graph (the top-1 counters come out of an
-        # autograd Function and would otherwise drag the whole pack, and with it the divisors g_nr / g_nf, into it)
-        pack = torch.stack([ce_r_sum.detach(), ce_f_sum.detach(), hit_r.detach(), hit_f.detach(), n_r, n_f, kl_f_sum.detach(),
-                            kl_r_sum.detach()])
-        dist.all_reduce(pack)
-        ce_r_sum, ce_f_sum = _globalize(ce_r_sum, pack[0]), _globalize(ce_f_sum, pack[1])
-        hit_r, hit_f, g_nr, g_nf = pack[2], pack[3], pack[4], pack[5]
-        if use_prototype:
-            kl_f_sum, kl_r_sum = _globalize(kl_f_sum, pack[6]), _globalize(kl_r_sum, pack[7])
-    if world == 1 and ce_r_sum.is_cuda:
-        # single process: the scalar tail (hinges, weighted sum, meters, the five upstream gradients) is ONE kernel forward and one
-        # 5-element multiply backward instead of ~35 one-element torch kernels (losses.combine / gsl_loss_combine)
+        kl_f_sum = kl_r_sum = None
+    # the scalar tail (hinges, weighted sum, meters, the five upstream gradients) is ONE kernel forward and one 5-element multiply
+    # backward instead of ~35 one-element torch kernels (losses.combine / gsl_loss_combine[_pack])
+    if world == 1:
         structure = backend.structure_loss(net, group_type, grad_scale=1.0) if use_structure else None
-        total, meters = losses.combine(ce_r_sum, ce_f_sum, kl_f_sum if use_prototype else None, kl_r_sum if use_prototype else None,
-                                       structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro)
+        total, meters = backend.combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha,
+                                        w_f, w_r, BND_pro)
         optimizer.zero_grad()
         total.backward()
         optimizer.step()
         return meters
-    loss_remain = ce_r_sum / g_nr
-    loss_forget = torch.relu(BND - ce_f_sum / g_nf)
-    structure = backend.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else zero
-    if use_prototype:
-        pro_f = w_f * torch.relu(BND_pro - kl_f_sum / g_nf)
-        pro_r = w_r * (kl_r_sum / g_nr)
-    else:
-        pro_f = pro_r = zero
-    total = loss_forget * beta + loss_remain + structure * alpha + (pro_f + pro_r)
+    # data parallel: the eight batch sums travel in ONE packed all-reduce, so the hinges see the GLOBAL batch means. Every entry is
+    # detached: the collective must not become a node of the autograd graph. The two batch sizes ride along as device scalars.
+    f = lambda t: t.detach().float()
+    kz = torch.zeros((), device=dev) if not use_prototype else None
+    pack = torch.stack([f(ce_r_sum), f(ce_f_sum), f(hit_r), f(hit_f), torch.full((), n_r, device=dev), torch.full((), n_f, device=dev),
+                        f(kl_f_sum) if use_prototype else kz, f(kl_r_sum) if use_prototype else kz])
+    dist.all_reduce(pack)
+    structure = backend.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else None
+    total, meters = backend.combine_pack(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro)
     optimizer.zero_grad()
+    reducer = _OverlappedBucketReduce(net, backend)
     total.backward()
-    if world > 1:
-        dist.all_reduce(backend.grad_bucket(net))    # one flat message: 0.94 MiB for ViT-P8S8 r=8
+    reducer.finish()
     optimizer.step()
-    return torch.stack([(beta * loss_forget).detach(), loss_remain.detach(), total.detach(), (alpha * structure).detach(),
-                        hit_f * (100.0 / g_nf), hit_r * (100.0 / g_nr), pro_f.detach() if use_prototype else zero,
-                        pro_r.detach() if use_prototype else zero])
+    return meters
 
 
 class GraphedStep:

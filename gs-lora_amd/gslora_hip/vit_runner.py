@@ -129,6 +129,7 @@ class ViTRunner:
         self.seed_dev = None      # int64 [1] device tensor: dropout seed of a step that is being captured / replayed as a HIP graph
         self.drop_seed = 0x5EED
         self.drop_calls = 0
+        self.grad_hook = None     # callable(layer) invoked when the LoRA gradients of `layer` are complete (data-parallel overlap, step.py)
 
     def __deepcopy__(self, memo):   # copies of the model build their own runner lazily
         return None
@@ -433,7 +434,7 @@ class ViTRunner:
                 # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
                 ops.gemm_nt_lora_mulgrad(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                          self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, gp,
-                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r)
+                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx")
             elif ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
                 ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                  self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=L.EPI_MUL, aux=gp)
@@ -455,6 +456,8 @@ class ViTRunner:
             if not fused_grads:
                 ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)             # dB1[hid, j]
             ops.lora_grad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                # dA1[j, c]
+            if self.grad_hook is not None:
+                self.grad_hook(i)
             if i == 0:
                 break   # nothing below the layer-0 FFN input is trainable
             if dxn2 is None:
@@ -557,6 +560,8 @@ class ViTRunner:
             for g in range(ng):
                 ops.lora_grad(st["xn"], v[:, g * r:], gA[g * r:(g + 1) * r], 1, D, r)                       # dA_g[j, c]
                 ops.lora_grad(dqkv[:, g * inner:(g + 1) * inner], st["uq"][:, g * r:], gB[g * inner:(g + 1) * inner], r, 1, r)   # dB_g[n, j]
+            if self.grad_hook is not None:
+                self.grad_hook(i)
             if i == 0:
                 break      # nothing below the block-0 QKV projection is trainable
             dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)

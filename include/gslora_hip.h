@@ -166,6 +166,13 @@ int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* 
                      float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
                      float* total, float* meters8, float* coefs5, gsl_stream_t s);
 
+/* Data-parallel form of the scalar tail (SURVEY 8(e) collective C2; reference semantics train_own_forget_cl.py:494-497, engine_cl.py:78,99):
+ * pack8 = the sum-all-reduced [ce_r_sum, ce_f_sum, hit_r, hit_f, n_r, n_f, kl_f_sum, kl_r_sum] — global batch sums and sizes, all on the
+ * device. Same outputs as gsl_loss_combine; coefs5 are the derivatives with respect to THIS rank's local sums (= those of the global sums). */
+int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_proto, float beta, float BND, float alpha, float w_f,
+                          float w_r, float BND_pro, float* total, float* meters8, float* coefs5, gsl_stream_t s);
+
+
 /* ---- K12 group-lasso norms over a flat LoRA buffer (engine_cl.py:349-432, util/cal_norm.py:4-146).
  * tensor t = flat[toff[t] .. +tnumel[t]) belongs to group tgroup[t] (tables on device, int64/int64/int32).
  * Outputs (f32 unless noted): tensor_sumsq[ntensors], group_norm[ngroups] = sqrt(sum sumsq),

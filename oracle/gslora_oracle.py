@@ -63,18 +63,21 @@ def merged_delta(A, B, r):
     return torch.bmm(B.view(ng, -1, r), A.view(ng, r, -1)).reshape(B.shape[0], A.shape[1])
 
 
-def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None):
+def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None, dropout_p=0.0):
     """ViT_face.forward (vit_face.py:523-548) with Transformer (:442-446), Attention
     (:358-379, scale = dim**-0.5 :346), FeedForward (:329-335, exact-erf GELU) and
-    CosFace (:171-208). Dropout is the identity here (parity runs use p=0; eval mode).
+    CosFace (:171-208). Dropout is the identity for parity runs (p = 0 / eval mode); dropout_p > 0 applies torch's own Bernoulli
+    dropout at the reference's 19 sites (emb_dropout :537, to_out :353-356, FeedForward :329-335) — used only by bench.py's CPU
+    baseline, which times the step "as the reference trains" (dropout 0.1).
     Returns (logits|None, emb)."""
+    dp = (lambda t: F.dropout(t, dropout_p, True)) if dropout_p > 0 else (lambda t: t)
     p, d, hds, r = cfg["patch_size"], cfg["dim"], cfg["heads"], cfg["lora_rank"]
     attn_lora = cfg.get("lora_pos", "FFN") == "Attention"
     x = patchify(img.float(), p)
     x = F.linear(x, st["patch_to_embedding.weight"], st["patch_to_embedding.bias"])
     b, n, _ = x.shape
     x = torch.cat((st["cls_token"].expand(b, -1, -1), x), dim=1)
-    x = x + st["pos_embedding"][:, : n + 1]
+    x = dp(x + st["pos_embedding"][:, : n + 1])
     scale = d ** -0.5
     for i in range(cfg["depth"]):
         a = f"transformer.layers.{i}.0.fn"
@@ -89,15 +92,15 @@ def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None):
         dots = torch.einsum("bhid,bhjd->bhij", q, k) * scale
         attn = dots.softmax(dim=-1)
         o = torch.einsum("bhij,bhjd->bhid", attn, v).permute(0, 2, 1, 3).reshape(b, n + 1, -1)
-        x = F.linear(o, st[f"{a}.fn.to_out.0.weight"], st[f"{a}.fn.to_out.0.bias"]) + x
+        x = dp(F.linear(o, st[f"{a}.fn.to_out.0.weight"], st[f"{a}.fn.to_out.0.bias"])) + x
         xn = F.layer_norm(x, (d,), st[f"{f}.norm.weight"], st[f"{f}.norm.bias"], LN_EPS)
         rf = 0 if attn_lora else r
         h = lora_linear(xn, st[f"{f}.fn.net.0.weight"], st[f"{f}.fn.net.0.bias"],
                         st.get(f"{f}.fn.net.0.lora_A"), st.get(f"{f}.fn.net.0.lora_B"), rf, merged)
-        h = F.gelu(h)
+        h = dp(F.gelu(h))
         y = lora_linear(h, st[f"{f}.fn.net.3.weight"], st[f"{f}.fn.net.3.bias"],
                         st.get(f"{f}.fn.net.3.lora_A"), st.get(f"{f}.fn.net.3.lora_B"), rf, merged)
-        x = y + x
+        x = dp(y) + x
     x = x[:, 0]  # pool='cls' (vit_face.py:540)
     emb = F.layer_norm(x, (d,), st["mlp_head.0.weight"], st["mlp_head.0.bias"], LN_EPS)
     if label is None:
@@ -185,8 +188,8 @@ def top1_percent(logits, labels):
 
 def step_losses(st, cfg, x_r, y_r, x_f, y_f, hyper, proto=None):
     """Loss side of the engine_cl.train_one_epoch loop body (engine_cl.py:59-120)."""
-    lr_logits, lr_emb = vit_forward(st, x_r, y_r, cfg)
-    lf_logits, lf_emb = vit_forward(st, x_f, y_f, cfg)
+    lr_logits, lr_emb = vit_forward(st, x_r, y_r, cfg, dropout_p=hyper.get("dropout", 0.0))
+    lf_logits, lf_emb = vit_forward(st, x_f, y_f, cfg, dropout_p=hyper.get("dropout", 0.0))
     ce_r = F.cross_entropy(lr_logits, y_r)
     ce_f = F.cross_entropy(lf_logits, y_f)
     loss_forget = F.relu(hyper["BND"] - ce_f)

@@ -1,0 +1,286 @@
+"""Engine-level goldens from the REAL reference (imported unmodified from /root/reference; build container only):
+
+  tests/golden/engine_cl_traj.npz   24 steps of engine_cl.train_one_epoch on the full ViT-P8S8 (4 epochs x 6 remain batches, forget
+                                    loader cycled, cosine lr per epoch), per-step meter values, eval accuracies / H-mean before and
+                                    after, final eval logits; then one more epoch in which engine_cl.evaluate runs inside the engine
+                                    (batch counter 99): H-mean, best-checkpoint save + prune to two, training resumed after the merge
+                                    round trip.
+  tests/golden/engine_single.npz    engine.train_one_epoch: normal branch, few-shot loop inversion, epoch < ALPHA_EPOCH, the literal
+                                    prototype bound 18, the three groupings; engine.evaluate / eval_data (deep-copied model).
+  tests/golden/chain2.npz           two tasks chained the way train_own_forget_cl.py does it: train -> eval() -> save merged state ->
+                                    load_state_dict -> reinitialize_lora_parameters -> train.
+
+Inputs come from oracle/scenarios.py (shared with tests/test_hip_engines.py); fixtures hold OUTPUTS only.
+Usage: python oracle/make_golden_engines.py [traj] [single] [chain]
+"""
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import recipe, scenarios as S  # noqa: E402
+from oracle.make_golden import build_reference_model, install_shims  # noqa: E402
+
+NAMES = ["losses_forget", "losses_remain", "losses_total", "losses_structure", "top1_forget", "top1_remain",
+         "losses_prototype_forget", "losses_prototype_remain"]
+
+
+class UpdateLog:
+    """Records every AverageMeter.update(val, n) of the reference (the engine re-binds fresh meters after each display)."""
+
+    def __init__(self, rutil):
+        self.vals, self.rutil, self.orig = [], rutil, rutil.AverageMeter.update
+
+    def __enter__(self):
+        log, orig = self.vals, self.orig
+
+        def update(meter, val, n=1):
+            log.append(float(val))
+            return orig(meter, val, n)
+        self.rutil.AverageMeter.update = update
+        return self
+
+    def __exit__(self, *a):
+        self.rutil.AverageMeter.update = self.orig
+
+    def steps(self):
+        return np.array(self.vals, dtype=np.float64).reshape(-1, 8)
+
+
+def fresh_meters(rutil):
+    return {k: rutil.AverageMeter() for k in NAMES}
+
+
+def lora_state(model):
+    return {n: p.detach().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}
+
+
+def gen_traj(out):
+    import engine_cl
+    from util import utils as rutil
+    cfg, T = recipe.cfg_full(), S.TRAJ
+    rem, forg, test_rem, test_forg = S.class_loaders(cfg, T["n_remain"], T["n_forget"], T["batch"])
+    state = recipe.make_state(cfg)
+
+    def emb_fn(st, x):
+        m = build_reference_model(cfg, st).train()
+        with torch.no_grad():
+            return torch.cat([m(x[i:i + 12]) for i in range(0, x.shape[0], 12)])
+    res = {}
+    res["head_bias"], res["loss_weight"] = S.discriminative_head(emb_fn, state, cfg, (rem, forg))
+    state["mlp_head.0.bias"], state["loss.weight"] = res["head_bias"], res["loss_weight"]
+    model = build_reference_model(cfg, state)
+    proto = S.prototypes(cfg)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=T["lr"], weight_decay=T["wd"], eps=1e-8)
+    crit = torch.nn.CrossEntropyLoss()
+    dev = torch.device("cpu")
+    x_ev = torch.cat([test_rem.batches[0][0], test_forg.batches[0][0]])
+    y_ev = torch.cat([test_rem.batches[0][1], test_forg.batches[0][1]])
+
+    def snapshot(tag):
+        with torch.no_grad():
+            res[f"acc_forget_{tag}"] = np.float64(engine_cl.eval_data(model, test_forg, dev, "forget", 0))
+            res[f"acc_remain_{tag}"] = np.float64(engine_cl.eval_data(model, test_rem, dev, "remain", 0))
+            model.eval()
+            lo, _ = model(x_ev, y_ev)
+            res[f"eval_logits_{tag}"] = lo.numpy().copy()
+            lo_nl = model(x_ev)           # embedding without label
+            res[f"eval_emb_{tag}"] = lo_nl.numpy().copy()
+        model.train()
+
+    snapshot("before")
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": T["BND_pro"], "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+    meters = fresh_meters(rutil)
+    batch_ctr, hmean = 0, 0.0
+    epoch_avgs = []
+    with UpdateLog(rutil) as log:
+        for epoch in range(T["epochs"]):
+            for g in opt.param_groups:
+                g["lr"] = S.cosine_lr(epoch, T["epochs"], T["lr"], T["lr_min"])
+            ret = engine_cl.train_one_epoch(
+                model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=epoch,
+                beta=T["beta"], alpha=T["alpha"], BND=T["BND"], batch=batch_ctr, testloader_forget=None, testloader_remain=None,
+                forget_acc_before=T["forget_acc_before"], highest_H_mean=hmean, cfg=cfgd, task_i="0", use_prototype=True,
+                prototype_dict=proto, prototype_weight_forget=T["pro_f_weight"], prototype_weight_remain=T["pro_r_weight"], **meters)
+            batch_ctr, hmean = ret[0], ret[1]
+            meters = dict(losses_forget=ret[2], losses_remain=ret[3], top1_forget=ret[4], top1_remain=ret[5], losses_total=ret[6],
+                          losses_structure=ret[7], losses_prototype_forget=ret[8], losses_prototype_remain=ret[9])
+            epoch_avgs.append([meters[k].avg for k in NAMES])
+    res["step_updates"] = log.steps()                  # [24, 8] in scenarios.REF_UPDATE_ORDER
+    res["epoch_avgs"] = np.array(epoch_avgs, dtype=np.float64)
+    res["batch_ctr"] = np.int64(batch_ctr)
+    snapshot("after")
+    st = lora_state(model)
+    res["lora_norms_after"] = np.array([np.linalg.norm(v) for v in st.values()], dtype=np.float64)
+    for k in ("transformer.layers.0.1.fn.fn.net.0.lora_A", "transformer.layers.5.1.fn.fn.net.3.lora_B",
+              "transformer.layers.2.1.fn.fn.net.0.lora_B"):
+        res[f"param_after::{k}"] = st[k]
+
+    # ---- part 2: evaluate() inside the engine (batch counter 97 -> evaluation after the third step), save + prune -------------------
+    work = tempfile.mkdtemp(prefix="gsl_golden_")
+    open(os.path.join(work, "config.txt"), "w").write("cfg\n")
+    for i, name in enumerate(["Backbone_VIT_Epoch_1_Batch_10_Time_old_checkpoint.pth", "Backbone_VIT_Epoch_1_Batch_20_Time_old_checkpoint.pth"]):
+        p = os.path.join(work, name)
+        torch.save({"dummy": torch.zeros(1)}, p)
+        os.utime(p, (time.time() - 1000 + 10 * i, time.time() - 1000 + 10 * i))
+    cfgd2 = dict(cfgd, WORK_PATH=work)
+    meters = fresh_meters(rutil)
+    with UpdateLog(rutil) as log:
+        ret = engine_cl.train_one_epoch(
+            model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=4,
+            beta=T["beta"], alpha=T["alpha"], BND=T["BND"], batch=S.EVAL["batch0"], testloader_forget=test_forg, testloader_remain=test_rem,
+            forget_acc_before=S.EVAL["forget_acc_before"], highest_H_mean=0.0, cfg=cfgd2, task_i="0", use_prototype=True,
+            prototype_dict=proto, prototype_weight_forget=T["pro_f_weight"], prototype_weight_remain=T["pro_r_weight"], **meters)
+    res["eval_step_updates"] = log.steps()
+    res["eval_hmean"] = np.float64(ret[1])
+    res["eval_batch_ctr"] = np.int64(ret[0])
+    files = sorted(os.listdir(work))
+    res["eval_n_files"] = np.int64(len(files))
+    res["eval_kept_old"] = np.array([int("Batch_10_" in " ".join(files)), int("Batch_20_" in " ".join(files))])
+    new = [f for f in files if f.endswith(".pth") and "_old_" not in f]
+    res["eval_new_is_batch100"] = np.int64(len(new) == 1 and "_Epoch_5_Batch_100_" in new[0])
+    print("[golden] traj accuracies:", {k: float(v) for k, v in res.items() if k.startswith("acc_")}, "hmean", float(ret[1]), files)
+    ck = torch.load(os.path.join(work, new[0]))
+    res["ckpt_merged_w_l0_net0_sum"] = np.float64(ck["transformer.layers.0.1.fn.fn.net.0.weight"].double().sum().item())
+    res["ckpt_merged_w_l0_net0_row7"] = ck["transformer.layers.0.1.fn.fn.net.0.weight"][7].numpy().copy()
+    res["ckpt_n_keys"] = np.int64(len(ck))
+    shutil.rmtree(work)
+    # a second evaluate() with a LOWER H-mean must not save (forget_acc_before lowered)
+    work2 = tempfile.mkdtemp(prefix="gsl_golden_")
+    with torch.no_grad():
+        h2 = engine_cl.evaluate(model, test_forg, test_rem, dev, batch=199, epoch=5, forget_acc_before=S.EVAL["forget_acc_before"] - 30.0,
+                                highest_H_mean=float(ret[1]), cfg=dict(cfgd, WORK_PATH=work2), optimizer=opt, task_i="0")
+    res["eval2_hmean_returned"] = np.float64(h2)
+    res["eval2_n_files"] = np.int64(len(os.listdir(work2)))
+    shutil.rmtree(work2)
+    model.train()
+    snapshot("final")
+    np.savez_compressed(os.path.join(out, "engine_cl_traj.npz"), **res)
+    print("[golden] engine_cl_traj:", {k: (v.shape if hasattr(v, "shape") and v.ndim else float(v)) for k, v in res.items()
+                                       if not k.startswith("eval_logits") and not k.startswith("eval_emb") and "::" not in k and "row7" not in k})
+
+
+def gen_single(out):
+    import engine as eng
+    from util import utils as rutil
+    cfg = recipe.cfg_small2()
+    H = S.SINGLE_HYPER
+    res = {}
+    dev = torch.device("cpu")
+    for name, sc in S.SINGLE.items():
+        model = build_reference_model(cfg, recipe.make_state(cfg))
+        rem, forg = S.loaders(cfg, sc["n_remain"], sc["n_forget"], sc["batch"], seed=sc["seed"])
+        proto = S.prototypes(cfg, sc["proto_scale"])
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=H["lr"], weight_decay=H["wd"], eps=1e-8)
+        crit = torch.nn.CrossEntropyLoss()
+        cfgd = {"few_shot": sc["few_shot"], "ALPHA_EPOCH": sc["ALPHA_EPOCH"], "NUM_LAYERS": cfg["depth"], "GROUP_TYPE": sc["GROUP_TYPE"],
+                "GROUP_POS": "FFN", "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+        meters = fresh_meters(rutil)
+        with UpdateLog(rutil) as log:
+            ret = eng.train_one_epoch(
+                model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=sc["epoch"],
+                beta=H["beta"], alpha=H["alpha"], BND=H["BND"], batch=0, testloader_forget=None, testloader_remain=None,
+                forget_acc_before=0.0, highest_H_mean=0.0, cfg=cfgd, prototype_weight_forget=H["pro_f_weight"],
+                prototype_weight_remain=H["pro_r_weight"], use_prototype=sc["use_prototype"], prototype_dict=proto, **meters)
+        res[f"{name}::step_updates"] = log.steps()
+        res[f"{name}::batch_ctr"] = np.int64(ret[0])
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                res[f"{name}::grad_last::{n}"] = p.grad.numpy().copy()
+                res[f"{name}::param::{n}"] = p.detach().numpy().copy()
+        if name == "normal":      # engine.evaluate / eval_data work on deep copies: the training weights are untouched (:449, :514)
+            before = {n: p.detach().clone() for n, p in model.named_parameters()}
+            work = tempfile.mkdtemp(prefix="gsl_golden_")
+            with torch.no_grad():
+                res["normal::acc_forget"] = np.float64(eng.eval_data(model, forg, dev, "forget", 0))
+                res["normal::acc_remain"] = np.float64(eng.eval_data(model, rem, dev, "remain", 0))
+                res["normal::hmean"] = np.float64(eng.evaluate(model, forg, rem, dev, batch=9, epoch=0, forget_acc_before=100.0,
+                                                               highest_H_mean=0.0, cfg=dict(cfgd, WORK_PATH=work), optimizer=opt))
+            res["normal::n_files"] = np.int64(len(os.listdir(work)))
+            shutil.rmtree(work)
+            assert model.training and all(torch.equal(before[n], p) for n, p in model.named_parameters())
+    np.savez_compressed(os.path.join(out, "engine_single.npz"), **res)
+    for name in S.SINGLE:
+        print(f"[golden] engine_single/{name}: steps {res[f'{name}::step_updates'].shape[0]}, first step", np.round(res[f"{name}::step_updates"][0], 4))
+    print("[golden] engine_single eval:", res["normal::acc_forget"], res["normal::acc_remain"], res["normal::hmean"])
+
+
+def gen_chain(out):
+    import engine_cl
+    from util import utils as rutil
+    from util.cal_norm import get_norm_of_lora
+    cfg, C = recipe.cfg_full(), S.CHAIN
+    model = build_reference_model(cfg, recipe.make_state(cfg))
+    dev = torch.device("cpu")
+    crit = torch.nn.CrossEntropyLoss()
+    proto = S.prototypes(cfg)
+    res = {}
+    work = tempfile.mkdtemp(prefix="gsl_golden_")
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": C["BND_pro"], "MULTI_GPU": False, "WORK_PATH": work, "BACKBONE_NAME": "VIT"}
+    model.train()
+    x_ev = torch.tensor(recipe.make_images(cfg, 3, seed=901, tag="xev"))
+    y_ev = torch.tensor(recipe.make_labels(cfg, 3, seed=901, tag="yev"))
+    for task in range(2):
+        if task > 0:
+            model.load_state_dict(torch.load(os.path.join(work, "task-level", f"Backbone_task_{task - 1}.pth")))
+            rutil.reinitialize_lora_parameters(model)
+            st = lora_state(model)
+            assert all(np.all(v == 0) for k, v in st.items() if k.endswith("lora_B"))
+            bound = {k: np.sqrt(6.0 / (51.0 * v.shape[1])) for k, v in st.items() if k.endswith("lora_A")}
+            assert all(np.abs(st[k]).max() <= b and np.abs(st[k]).max() > 0.8 * b for k, b in bound.items())
+            with torch.no_grad():
+                for k, v in S.chain_lora_A(cfg, task).items():
+                    model.get_parameter(k).copy_(v)
+                lo, _ = model(x_ev, y_ev)
+                res["logits_after_reload_reinit"] = lo.numpy().copy()
+        rem, forg = S.loaders(cfg, C["n_remain"], C["n_forget"], C["batch"], seed=10 + task)
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=C["lr"], weight_decay=C["wd"], eps=1e-8)
+        meters = fresh_meters(rutil)
+        with UpdateLog(rutil) as log:
+            engine_cl.train_one_epoch(
+                model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=0,
+                beta=C["betas"][task], alpha=C["alpha"], BND=C["BND"], batch=0, testloader_forget=None, testloader_remain=None,
+                forget_acc_before=0.0, highest_H_mean=0.0, cfg=cfgd, task_i=task, use_prototype=True, prototype_dict=proto,
+                prototype_weight_forget=C["pro_f_weight"], prototype_weight_remain=C["pro_r_weight"], **meters)
+        res[f"task{task}::step_updates"] = log.steps()
+        res[f"task{task}::norm_list"] = np.array([float(v) for v in get_norm_of_lora(model, type="L2", group_num=cfg["depth"])])
+        model.eval()
+        os.makedirs(os.path.join(work, "task-level"), exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(work, "task-level", f"Backbone_task_{task}.pth"))
+        with torch.no_grad():
+            lo, _ = model(x_ev, y_ev)
+            res[f"task{task}::eval_logits"] = lo.numpy().copy()
+        sd = model.state_dict()
+        res[f"task{task}::saved_w_l3_net3_row5"] = sd["transformer.layers.3.1.fn.fn.net.3.weight"][5].numpy().copy()
+        res[f"task{task}::saved_lora_B_l3_net3"] = sd["transformer.layers.3.1.fn.fn.net.3.lora_B"].numpy().copy()
+        model.train()
+    shutil.rmtree(work)
+    np.savez_compressed(os.path.join(out, "chain2.npz"), **res)
+    print("[golden] chain2: |logits(after reload+reinit) - eval logits(task0)| =",
+          float(np.abs(res["logits_after_reload_reinit"] - res["task0::eval_logits"]).max()))
+
+
+def main():
+    install_shims()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out = os.path.join(ROOT, "tests", "golden")
+    only = sys.argv[1:]
+    if not only or "single" in only:
+        gen_single(out)
+    if not only or "chain" in only:
+        gen_chain(out)
+    if not only or "traj" in only:
+        gen_traj(out)
+
+
+if __name__ == "__main__":
+    main()

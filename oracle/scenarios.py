@@ -1,0 +1,151 @@
+"""Seeded engine-level scenarios shared by the golden generator (oracle/make_golden_engines.py, runs the REAL reference in the
+build container) and the parity tests (tests/test_hip_engines.py, run the HIP path on the GPU box).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): nothing in the product package imports this.
+
+A scenario is data only: lists of (images, labels) CPU batches built from oracle/recipe.py plus the hyper-parameters of the
+engine call. Both sides feed exactly these objects to `train_one_epoch` / `eval_data` / `evaluate`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import recipe
+
+
+class ListLoader:
+    """Minimal DataLoader stand-in (the engines iterate, call len(), and the data_prefetcher wraps iter())."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _batches(cfg, n, batch, seed0, kind):
+    nf = max(2, cfg["num_class"] // 5)
+    lo, hi = (0, cfg["num_class"] - nf) if kind == "r" else (cfg["num_class"] - nf, cfg["num_class"])
+    out = []
+    for i in range(n):
+        x = torch.tensor(recipe.make_images(cfg, batch, seed=seed0 + i, tag="x" + kind))
+        y = torch.tensor(recipe.make_labels(cfg, batch, seed=seed0 + i, tag="y" + kind, lo=lo, hi=hi))
+        out.append((x, y))
+    return out
+
+
+def loaders(cfg, n_remain, n_forget, batch, seed=0, batch_forget=None):
+    """(remain ListLoader, forget ListLoader); remain labels in the first 80 % of the classes, forget labels in the last 20 %."""
+    return (ListLoader(_batches(cfg, n_remain, batch, 300 + 1000 * seed, "r")),
+            ListLoader(_batches(cfg, n_forget, batch_forget or batch, 400 + 1000 * seed, "f")))
+
+
+def class_images(cfg, labels, seed, noise=0.08):
+    """Images with class structure: a per-class patch-sized texture tiled over the image + uniform pixel noise, quantised to k/255 like
+    ToTensor(). (A randomly initialised ViT averages its patch tokens almost uniformly, so only the MEAN patch vector of an image
+    reaches the embedding: a tiled texture is the class signal such a backbone can see.) Different `seed` = different samples of
+    the same classes (train / test split)."""
+    g = cfg["image_size"] // cfg["patch_size"]
+    out = []
+    for i, c in enumerate(labels.tolist()):
+        tile = recipe.uniform(f"classtile{int(c)}", (cfg["channels"], cfg["patch_size"], cfg["patch_size"]), 5, 0.0, 1.0)
+        img = np.tile(tile, (1, g, g))
+        nz = recipe.uniform(f"classnoise{seed}_{i}", img.shape, 9, -noise, noise)
+        out.append(np.floor(np.clip(img + nz, 0.0, 1.0) * 255.0) / 255.0)
+    return torch.tensor(np.stack(out).astype(np.float32))
+
+
+def class_loaders(cfg, n_remain, n_forget, batch, seed=0):
+    """Like loaders(), with class-structured images; returns (remain, forget, test_remain, test_forget): the test loaders hold
+    other samples (different noise) of the same label sequences."""
+    def mk(n, seed0, kind, img_seed):
+        nf = max(2, cfg["num_class"] // 5)
+        lo, hi = (0, cfg["num_class"] - nf) if kind == "r" else (cfg["num_class"] - nf, cfg["num_class"])
+        b = []
+        for i in range(n):
+            y = torch.tensor(recipe.make_labels(cfg, batch, seed=seed0 + i, tag="y" + kind, lo=lo, hi=hi))
+            b.append((class_images(cfg, y, img_seed * 100 + i), y))
+        return ListLoader(b)
+    return (mk(n_remain, 300 + 1000 * seed, "r", 1), mk(n_forget, 400 + 1000 * seed, "f", 2),
+            mk(n_remain, 300 + 1000 * seed, "r", 3), mk(n_forget, 400 + 1000 * seed, "f", 4))
+
+
+def discriminative_head(emb_fn, state, cfg, loaders_, common=1.17):
+    """Frozen head that makes the randomly initialised backbone discriminative on the scenario's classes (a stand-in for a pre-trained
+    checkpoint, which cannot be shipped): the final LayerNorm's bias cancels the data-set mean of its output, so the embedding is the
+    (small) class-specific part of the feature, and the CosFace class centres are the class means of that embedding. `emb_fn(state, x)`
+    returns the model's embedding [B, dim] for images x under `state` (the generator passes the reference model). Returns the two
+    overridden tensors; they are stored in the golden file as DATA and loaded by the tests.
+    `common` re-adds a shared component of that many class-signal norms, so that different classes sit at cosine ~common^2/(1+common^2)
+    (0.58 at 1.17) of each other: just inside the CosFace margin 0.35 — accuracies below 100 %, un-saturated cross-entropies."""
+    st = dict(state)
+    st["mlp_head.0.bias"] = np.zeros_like(state["mlp_head.0.bias"])
+    xs = torch.cat([x for ld in loaders_ for x, _ in ld.batches])
+    ys = torch.cat([y for ld in loaders_ for _, y in ld.batches])
+    e = emb_fn(st, xs).double()
+    mu = e.mean(0)
+    sig = (e - mu).norm(dim=1).mean()
+    shift = common * sig * mu / mu.norm()
+    bias = (shift - mu).float().numpy()
+    ec = (e - mu + shift).float()
+    w = np.array(state["loss.weight"], copy=True)
+    for c in sorted(set(ys.tolist())):
+        w[c] = torch.nn.functional.normalize(ec[ys == c].mean(0), dim=0).numpy()
+    return bias.astype(np.float32), w.astype(np.float32)
+
+
+def prototypes(cfg, scale=1.0):
+    p = recipe.make_prototypes(cfg) * scale
+    return {c: torch.tensor(p[c]) for c in range(cfg["num_class"])}
+
+
+def cosine_lr(epoch, n_epochs, lr0, lr_min):
+    """timm CosineLRScheduler(t_initial=n_epochs, lr_min, warmup 0, t_in_epochs) stepped with the epoch index."""
+    return lr_min + 0.5 * (lr0 - lr_min) * (1.0 + math.cos(math.pi * epoch / n_epochs))
+
+
+# ---- continual engine (engine_cl.train_one_epoch, reference engine_cl.py:12-244): a 24-step trajectory on the FULL ViT-P8S8 ----------
+TRAJ = dict(batch=4, n_remain=6, n_forget=3, epochs=4, lr=1e-2, lr_min=1e-5, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, BND_pro=2.0,
+            pro_f_weight=0.05, pro_r_weight=0.1, forget_acc_before=100.0)
+# second part, continued from the trajectory's end state: one more epoch starting at batch counter 97, so that engine_cl.evaluate runs
+# inside train_one_epoch at batch 99 (VER_FREQ 100): eval accuracies, H-mean, checkpoint save + prune (engine_cl.py:247-315)
+EVAL = dict(batch0=97, forget_acc_before=100.0)
+
+# ---- single-task engine (engine.train_one_epoch, reference engine.py:13-433) on the 3-layer test model --------------------------------
+SINGLE = {
+    # normal branch (remain loader drives, forget loader cycled), structure term on, prototype term with the literal bound 18 (:105);
+    # prototypes scaled so that KL_forget straddles 18 on this model
+    "normal": dict(n_remain=3, n_forget=2, batch=3, epoch=1, ALPHA_EPOCH=0, few_shot=False, GROUP_TYPE="block", use_prototype=True,
+                   proto_scale=4.0, seed=1),
+    # few-shot inversion (:53-236): the LONGER forget loader drives, the remain loader is cycled
+    "fewshot": dict(n_remain=2, n_forget=5, batch=2, epoch=1, ALPHA_EPOCH=0, few_shot=True, GROUP_TYPE="lora", use_prototype=True,
+                    proto_scale=12.0, seed=2),
+    # epoch < ALPHA_EPOCH (:82-90): no structure term; prototype term off -> the reference still logs w_f * relu(18 - 0) (:118-125)
+    "warm": dict(n_remain=3, n_forget=4, batch=3, epoch=0, ALPHA_EPOCH=2, few_shot=False, GROUP_TYPE="matrix", use_prototype=False,
+                 proto_scale=1.0, seed=3),
+}
+SINGLE_HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, pro_f_weight=0.05, pro_r_weight=0.1)
+
+# ---- two-task chain (train -> eval() -> save merged -> reload -> reinitialize -> train; train_own_forget_cl.py:515-536,1696-1705) -------
+CHAIN = dict(batch=2, n_remain=3, n_forget=2, lr=1e-2, wd=0.05, betas=(0.15, 0.2), alpha=1e-2, BND=105.0, BND_pro=2.0, pro_f_weight=0.05,
+             pro_r_weight=0.1)
+
+
+def chain_lora_A(cfg, task):
+    """Adapter A matrices installed after reinitialize_lora_parameters() in both flows (its kaiming_uniform draws come from the
+    device RNG, which differs between the CPU reference and the GPU path): U(+-sqrt(6 / (51 fan_in))), the same law."""
+    out = {}
+    for name, shape in recipe.param_shapes(cfg).items():
+        if name.endswith("lora_A"):
+            bound = float(np.sqrt(6.0 / (51.0 * shape[1])))
+            out[name] = torch.tensor(recipe.uniform(f"chain{task}:{name}", shape, 77, -bound, bound))
+    return out
+
+
+# reference order of the 8 AverageMeter.update calls of one step (engine_cl.py:68-117 == engine.py:66-133)
+REF_UPDATE_ORDER = ("losses_remain", "top1_remain", "losses_forget", "top1_forget", "losses_structure", "losses_prototype_forget",
+                    "losses_prototype_remain", "losses_total")

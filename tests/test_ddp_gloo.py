@@ -56,6 +56,30 @@ class OracleBackend:
         return s.detach() + grad_scale * (s - s.detach())       # value unscaled, gradient pre-divided by world
 
     @staticmethod
+    def combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):
+        """torch restatement of gsl_loss_combine (engine_cl.py:65-125)"""
+        loss_remain = ce_r_sum / n_r
+        loss_forget = torch.relu(BND - ce_f_sum / n_f)
+        zero = torch.zeros(())
+        st = structure if structure is not None else zero
+        pro_f = w_f * torch.relu(BND_pro - kl_f_sum / n_f) if kl_f_sum is not None else zero
+        pro_r = w_r * (kl_r_sum / n_r) if kl_r_sum is not None else zero
+        total = loss_forget * beta + loss_remain + st * alpha + (pro_f + pro_r)
+        meters = torch.stack([(beta * loss_forget).detach(), loss_remain.detach(), total.detach(), (alpha * st).detach(),
+                              hit_f * (100.0 / n_f), hit_r * (100.0 / n_r),
+                              pro_f.detach() if kl_f_sum is not None else torch.tensor(w_f * max(BND_pro, 0.0)), pro_r.detach()])
+        return total, meters
+
+    @staticmethod
+    def combine_pack(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro):
+        """value from the all-reduced pack, gradient through this rank's local sums (straight-through)"""
+        g = lambda local, tot: local + (tot - local.detach())
+        has = kl_f_sum is not None
+        return OracleBackend.combine(g(ce_r_sum, pack[0]), g(ce_f_sum, pack[1]), g(kl_f_sum, pack[6]) if has else None,
+                                     g(kl_r_sum, pack[7]) if has else None, structure, pack[2], pack[3], pack[4], pack[5], beta, BND,
+                                     alpha, w_f, w_r, BND_pro)
+
+    @staticmethod
     def grad_bucket(net):
         ps = list(net.lora.values())
         flat = torch.cat([p.grad.reshape(-1) for p in ps])

@@ -1,0 +1,348 @@
+"""Engine-level parity of the HIP path against goldens of the REAL reference engines (oracle/make_golden_engines.py):
+
+  * engine_cl.train_one_epoch: a 24-step trajectory on the full ViT-P8S8 (per-step meters, accuracies, eval logits), then evaluate()
+    inside the engine: H-mean, best-checkpoint save, prune-to-two, training resumed (reference engine_cl.py:12-346);
+  * engine.train_one_epoch: normal branch, few-shot loop inversion, epoch < ALPHA_EPOCH, literal prototype bound 18, the three
+    groupings; engine.evaluate / eval_data on a model that must stay untouched (reference engine.py:13-529);
+  * the two-task chain of train/train_own_forget_cl.py:515-536,1696-1705 through the build's own driver pieces.
+
+f32 mode is held to the reference within the tolerances stated at each assertion; bf16 (the benchmarked mode) within a declared band.
+"""
+import os
+import shutil
+import tempfile
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe
+from oracle import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["losses_forget", "losses_remain", "losses_total", "losses_structure", "top1_forget", "top1_remain",
+         "losses_prototype_forget", "losses_prototype_remain"]
+
+
+class UpdateLog:
+    """Per-step meter values of the build's engines: every AverageMeter.update, in MeterQueue.ORDER per step."""
+
+    def __init__(self):
+        import util.utils as U
+        self.U, self.vals, self.orig = U, [], U.AverageMeter.update
+
+    def __enter__(self):
+        log, orig = self.vals, self.orig
+
+        def update(meter, val, n=1):
+            log.append(float(val))
+            return orig(meter, val, n)
+        self.U.AverageMeter.update = update
+        return self
+
+    def __exit__(self, *a):
+        self.U.AverageMeter.update = self.orig
+
+    def steps_in_reference_order(self):
+        from gslora_hip.step import MeterQueue
+        a = np.array(self.vals, dtype=np.float64).reshape(-1, 8)
+        col = {n: i for i, n in enumerate(MeterQueue.ORDER)}
+        return np.stack([a[:, col[n]] for n in S.REF_UPDATE_ORDER], axis=1)
+
+
+def fresh_meters():
+    from util.utils import AverageMeter
+    return {k: AverageMeter() for k in NAMES}
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+
+
+def build_model(cfg, dtype, state):
+    from test_hip_model import build
+    return build(cfg, dtype, state=state)
+
+
+def run_traj(dtype, golden_dir):
+    import engine_cl
+    from gslora_hip.optim import CosineLRScheduler, FusedAdamW
+    g = np.load(os.path.join(golden_dir, "engine_cl_traj.npz"))
+    cfg, T = recipe.cfg_full(), S.TRAJ
+    rem, forg, test_rem, test_forg = S.class_loaders(cfg, T["n_remain"], T["n_forget"], T["batch"])
+    state = recipe.make_state(cfg)
+    state["mlp_head.0.bias"], state["loss.weight"] = g["head_bias"], g["loss_weight"]      # fixture data (discriminative frozen head)
+    model = build_model(cfg, dtype, state)
+    proto = S.prototypes(cfg)
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=T["lr"], weight_decay=T["wd"], eps=1e-8)
+    sched = CosineLRScheduler(opt, t_initial=T["epochs"], lr_min=T["lr_min"])
+    crit = torch.nn.CrossEntropyLoss()
+    dev = torch.device("cuda")
+    x_ev = torch.cat([test_rem.batches[0][0], test_forg.batches[0][0]]).cuda()
+    y_ev = torch.cat([test_rem.batches[0][1], test_forg.batches[0][1]]).cuda()
+    out = {}
+
+    def snapshot(tag):
+        with torch.no_grad():
+            out[f"acc_forget_{tag}"] = engine_cl.eval_data(model, test_forg, dev, "forget", 0)
+            out[f"acc_remain_{tag}"] = engine_cl.eval_data(model, test_rem, dev, "remain", 0)
+            model.eval()
+            out[f"eval_logits_{tag}"] = model(x_ev, y_ev)[0].float().cpu().numpy()
+            out[f"eval_emb_{tag}"] = model(x_ev).float().cpu().numpy()
+        model.train()
+
+    snapshot("before")
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": T["BND_pro"], "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+    meters = fresh_meters()
+    batch_ctr, hmean, epoch_avgs = 0, 0.0, []
+    with UpdateLog() as log:
+        for epoch in range(T["epochs"]):
+            sched.step(epoch)
+            assert abs(opt.param_groups[0]["lr"] - S.cosine_lr(epoch, T["epochs"], T["lr"], T["lr_min"])) < 1e-12
+            ret = engine_cl.train_one_epoch(
+                model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=epoch,
+                beta=T["beta"], alpha=T["alpha"], BND=T["BND"], batch=batch_ctr, testloader_forget=None, testloader_remain=None,
+                forget_acc_before=T["forget_acc_before"], highest_H_mean=hmean, cfg=cfgd, task_i="0", use_prototype=True,
+                prototype_dict=proto, prototype_weight_forget=T["pro_f_weight"], prototype_weight_remain=T["pro_r_weight"], **meters)
+            batch_ctr, hmean = ret[0], ret[1]
+            meters = dict(losses_forget=ret[2], losses_remain=ret[3], top1_forget=ret[4], top1_remain=ret[5], losses_total=ret[6],
+                          losses_structure=ret[7], losses_prototype_forget=ret[8], losses_prototype_remain=ret[9])
+            epoch_avgs.append([meters[k].avg for k in NAMES])
+    out["step_updates"] = log.steps_in_reference_order()
+    out["epoch_avgs"] = np.array(epoch_avgs)
+    out["batch_ctr"] = batch_ctr
+    snapshot("after")
+    st = {n: p.detach().cpu().numpy() for n, p in model.named_parameters() if p.requires_grad}
+    out["lora_norms_after"] = np.array([np.linalg.norm(v) for v in st.values()])
+    out["params"] = st
+
+    # ---- part 2: evaluate() inside the engine -------------------------------------------------------------------------------------
+    work = tempfile.mkdtemp(prefix="gsl_test_")
+    open(os.path.join(work, "config.txt"), "w").write("cfg\n")
+    for i, name in enumerate(["Backbone_VIT_Epoch_1_Batch_10_Time_old_checkpoint.pth", "Backbone_VIT_Epoch_1_Batch_20_Time_old_checkpoint.pth"]):
+        p = os.path.join(work, name)
+        torch.save({"dummy": torch.zeros(1)}, p)
+        os.utime(p, (time.time() - 1000 + 10 * i, time.time() - 1000 + 10 * i))
+    meters = fresh_meters()
+    with UpdateLog() as log:
+        ret = engine_cl.train_one_epoch(
+            model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=4,
+            beta=T["beta"], alpha=T["alpha"], BND=T["BND"], batch=S.EVAL["batch0"], testloader_forget=test_forg,
+            testloader_remain=test_rem, forget_acc_before=S.EVAL["forget_acc_before"], highest_H_mean=0.0, cfg=dict(cfgd, WORK_PATH=work),
+            task_i="0", use_prototype=True, prototype_dict=proto, prototype_weight_forget=T["pro_f_weight"],
+            prototype_weight_remain=T["pro_r_weight"], **meters)
+    assert model.training
+    out["eval_step_updates"] = log.steps_in_reference_order()
+    out["eval_hmean"], out["eval_batch_ctr"] = ret[1], ret[0]
+    files = sorted(os.listdir(work))
+    out["files"] = files
+    new = [f for f in files if f.endswith(".pth") and "_old_" not in f]
+    out["ckpt"] = torch.load(os.path.join(work, new[0])) if new else None
+    shutil.rmtree(work)
+    work2 = tempfile.mkdtemp(prefix="gsl_test_")
+    with torch.no_grad():
+        out["eval2_hmean"] = engine_cl.evaluate(model, test_forg, test_rem, dev, batch=199, epoch=5,
+                                                forget_acc_before=S.EVAL["forget_acc_before"] - 30.0, highest_H_mean=float(ret[1]),
+                                                cfg=dict(cfgd, WORK_PATH=work2), optimizer=opt, task_i="0")
+    out["eval2_n_files"] = len(os.listdir(work2))
+    shutil.rmtree(work2)
+    model.train()
+    snapshot("final")
+    return g, out
+
+
+def test_engine_cl_trajectory_f32_matches_reference(golden_dir):
+    g, o = run_traj("fp32", golden_dir)
+    # accuracies of the reference's eval_data on the held-out samples: identical counts (12 forget / 24 remain samples)
+    for tag in ("before", "after", "final"):
+        assert abs(o[f"acc_forget_{tag}"] - float(g[f"acc_forget_{tag}"])) < 1e-9, tag
+        assert abs(o[f"acc_remain_{tag}"] - float(g[f"acc_remain_{tag}"])) < 1e-9, tag
+    assert np.abs(o["eval_logits_before"] - g["eval_logits_before"]).max() < 1e-4       # north_star: logits within 1e-4 fp32
+    assert np.abs(o["eval_emb_before"] - g["eval_emb_before"]).max() < 1e-4
+    # 24 optimizer steps later: per-step meters (8 values per step, reference order) within 1e-3 (relative to max(1, |v|))
+    assert o["step_updates"].shape == g["step_updates"].shape == (24, 8)
+    e_first, e_all = relmax(o["step_updates"][:6], g["step_updates"][:6]), relmax(o["step_updates"], g["step_updates"])
+    print(f"[traj f32] per-step meters: first epoch {e_first:.2e}, all 24 steps {e_all:.2e}; "
+          f"eval logits after {np.abs(o['eval_logits_after'] - g['eval_logits_after']).max():.2e}")
+    assert e_first < 1e-4 and e_all < 1e-3
+    assert relmax(o["epoch_avgs"], g["epoch_avgs"]) < 1e-3
+    assert o["batch_ctr"] == int(g["batch_ctr"])
+    assert relmax(o["lora_norms_after"], g["lora_norms_after"]) < 1e-3
+    for k in [k for k in g.files if k.startswith("param_after::")]:
+        r = g[k]
+        assert np.abs(o["params"][k.split("::", 1)[1]] - r).max() < 2e-3 * max(1.0, np.abs(r).max()), k
+    assert np.abs(o["eval_logits_after"] - g["eval_logits_after"]).max() < 2e-2          # logit scale 64: 3e-4 on the cosine
+    # evaluate() inside the engine: H-mean, save of the best checkpoint, prune to two (oldest dummy removed), training resumed
+    assert abs(o["eval_hmean"] - float(g["eval_hmean"])) < 1e-6
+    assert o["eval_batch_ctr"] == int(g["eval_batch_ctr"])
+    assert len(o["files"]) == int(g["eval_n_files"])
+    kept = [int(any("Batch_10_" in f for f in o["files"])), int(any("Batch_20_" in f for f in o["files"]))]
+    assert kept == g["eval_kept_old"].tolist()
+    new = [f for f in o["files"] if f.endswith(".pth") and "_old_" not in f]
+    assert len(new) == 1 and "_Epoch_5_Batch_100_" in new[0]
+    ck = o["ckpt"]
+    assert len(ck) == int(g["ckpt_n_keys"])
+    w = ck["transformer.layers.0.1.fn.fn.net.0.weight"].double().cpu()
+    assert abs(w.sum().item() - float(g["ckpt_merged_w_l0_net0_sum"])) < 5e-2           # sum over 1 M merged weights
+    assert np.abs(w[7].float().numpy() - g["ckpt_merged_w_l0_net0_row7"]).max() < 1e-4
+    assert relmax(o["eval_step_updates"], g["eval_step_updates"]) < 2e-3
+    assert abs(o["eval2_hmean"] - float(g["eval2_hmean_returned"])) < 1e-6 and o["eval2_n_files"] == int(g["eval2_n_files"])
+    assert np.abs(o["eval_logits_final"] - g["eval_logits_final"]).max() < 3e-2
+
+
+def test_engine_cl_trajectory_bf16_within_band(golden_dir):
+    """The benchmarked mode along the same 24 + 6 steps. Declared band: per-step losses within 5 % (relative to max(1, |v|)),
+    eval logits within 1.0 absolute (CosFace scale 64: 1.6e-2 on the cosine — this scenario's class signal is a 6 % modulation of
+    the feature, far harsher than a trained backbone), accuracies within one sample of the reference, H-mean within 5 points."""
+    g, o = run_traj("bf16", golden_dir)
+    loss_cols = [i for i, n in enumerate(S.REF_UPDATE_ORDER) if not n.startswith("top1")]
+    e_loss = relmax(o["step_updates"][:, loss_cols], g["step_updates"][:, loss_cols])
+    d_log_b = np.abs(o["eval_logits_before"] - g["eval_logits_before"]).max()
+    d_log_a = np.abs(o["eval_logits_after"] - g["eval_logits_after"]).max()
+    top1_same = float((o["eval_logits_after"].argmax(1) == g["eval_logits_after"].argmax(1)).mean())
+    accs = {t: (o[f"acc_forget_{t}"] - float(g[f"acc_forget_{t}"]), o[f"acc_remain_{t}"] - float(g[f"acc_remain_{t}"])) for t in ("before", "after", "final")}
+    print(f"[traj bf16] per-step losses {e_loss:.3e}; eval logits before {d_log_b:.3f} after {d_log_a:.3f}; top-1 agreement {top1_same:.3f}; "
+          f"accuracy deltas (forget, remain) {accs}; H-mean {o['eval_hmean']:.3f} vs {float(g['eval_hmean']):.3f}")
+    assert e_loss < 5e-2
+    assert d_log_b < 1.0 and d_log_a < 1.0
+    for t, (df, dr) in accs.items():
+        assert abs(df) <= 100.0 / 12 + 1e-9 and abs(dr) <= 100.0 / 24 + 1e-9, (t, df, dr)
+    assert abs(o["eval_hmean"] - float(g["eval_hmean"])) < 5.0
+    assert o["eval_batch_ctr"] == int(g["eval_batch_ctr"])
+
+
+@pytest.mark.parametrize("name", list(S.SINGLE))
+def test_engine_single_f32_matches_reference(name, golden_dir):
+    import engine as eng
+    from gslora_hip.optim import FusedAdamW
+    g = np.load(os.path.join(golden_dir, "engine_single.npz"))
+    cfg, sc, H = recipe.cfg_small2(), S.SINGLE[name], S.SINGLE_HYPER
+    model = build_model(cfg, "fp32", recipe.make_state(cfg))
+    rem, forg = S.loaders(cfg, sc["n_remain"], sc["n_forget"], sc["batch"], seed=sc["seed"])
+    proto = S.prototypes(cfg, sc["proto_scale"])
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=H["lr"], weight_decay=H["wd"], eps=1e-8)
+    crit = torch.nn.CrossEntropyLoss()
+    dev = torch.device("cuda")
+    cfgd = {"few_shot": sc["few_shot"], "ALPHA_EPOCH": sc["ALPHA_EPOCH"], "NUM_LAYERS": cfg["depth"], "GROUP_TYPE": sc["GROUP_TYPE"],
+            "GROUP_POS": "FFN", "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT", "HIP_GRAPH": False}
+    meters = fresh_meters()
+    with UpdateLog() as log:
+        ret = eng.train_one_epoch(
+            model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=sc["epoch"],
+            beta=H["beta"], alpha=H["alpha"], BND=H["BND"], batch=0, testloader_forget=None, testloader_remain=None,
+            forget_acc_before=0.0, highest_H_mean=0.0, cfg=cfgd, prototype_weight_forget=H["pro_f_weight"],
+            prototype_weight_remain=H["pro_r_weight"], use_prototype=sc["use_prototype"], prototype_dict=proto, **meters)
+    ref = g[f"{name}::step_updates"]
+    got = log.steps_in_reference_order()
+    assert got.shape == ref.shape, (got.shape, ref.shape)       # the loop inversion sets the number of steps
+    assert ret[0] == int(g[f"{name}::batch_ctr"]) and len(ret) == 10
+    assert relmax(got, ref) < 2e-4, (got, ref)
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            r = g[f"{name}::grad_last::{n}"]
+            assert np.abs(p.grad.cpu().numpy() - r).max() < 2e-4 * max(1.0, np.abs(r).max()), n
+            rp = g[f"{name}::param::{n}"]
+            well = np.abs(r) > 1e-5          # AdamW is ill-conditioned where |g| ~ eps (see test_hip_model.py)
+            d = np.abs(p.detach().cpu().numpy() - rp)
+            assert d[well].max(initial=0.0) < 1e-3 and d.max() <= 2.05 * H["lr"] * ref.shape[0], n
+    if name == "normal":
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        work = tempfile.mkdtemp(prefix="gsl_test_")
+        with torch.no_grad():
+            acc_f = eng.eval_data(model, forg, dev, "forget", 0)
+            acc_r = eng.eval_data(model, rem, dev, "remain", 0)
+            hm = eng.evaluate(model, forg, rem, dev, batch=9, epoch=0, forget_acc_before=100.0, highest_H_mean=0.0,
+                              cfg=dict(cfgd, WORK_PATH=work), optimizer=opt)
+        n_files = len(os.listdir(work))
+        shutil.rmtree(work)
+        assert acc_f == float(g["normal::acc_forget"]) and acc_r == float(g["normal::acc_remain"])
+        assert abs(hm - float(g["normal::hmean"])) < 1e-9 and n_files == int(g["normal::n_files"])
+        # reference engine.py:449,514 evaluate a deep copy: the training model keeps its mode and its weights BIT FOR BIT
+        assert model.training and all(m.training for m in model.modules())
+        assert all(torch.equal(before[n], p) for n, p in model.named_parameters())
+
+
+def test_engine_single_fewshot_graph_replay_equals_eager(golden_dir):
+    """The few-shot regime is the launch-bound one: the same inverted epoch through the HIP-graph stepper gives the eager meters."""
+    import engine as eng
+    from gslora_hip.optim import FusedAdamW
+    cfg, sc, H = recipe.cfg_small2(), S.SINGLE["fewshot"], S.SINGLE_HYPER
+    res = {}
+    for mode in (False, True):
+        model = build_model(cfg, "fp32", recipe.make_state(cfg))
+        rem, forg = S.loaders(cfg, sc["n_remain"], sc["n_forget"], sc["batch"], seed=sc["seed"])
+        opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=H["lr"], weight_decay=H["wd"], eps=1e-8)
+        cfgd = {"few_shot": True, "ALPHA_EPOCH": 0, "NUM_LAYERS": cfg["depth"], "GROUP_TYPE": "lora", "GROUP_POS": "FFN",
+                "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT", "HIP_GRAPH": mode}
+        with UpdateLog() as log:
+            eng.train_one_epoch(model=model, dataloader_forget=forg, dataloader_remain=rem, device=torch.device("cuda"),
+                                criterion=torch.nn.CrossEntropyLoss(), optimizer=opt, epoch=1, beta=H["beta"], alpha=H["alpha"], BND=H["BND"],
+                                batch=0, testloader_forget=None, testloader_remain=None, forget_acc_before=0.0, highest_H_mean=0.0,
+                                cfg=cfgd, prototype_weight_forget=H["pro_f_weight"], prototype_weight_remain=H["pro_r_weight"],
+                                use_prototype=True, prototype_dict=S.prototypes(cfg, sc["proto_scale"]), **fresh_meters())
+        res[mode] = log.steps_in_reference_order()
+    assert np.array_equal(res[False], res[True])
+
+
+def test_two_task_chain_f32_matches_reference(golden_dir):
+    """train -> eval() -> save merged state -> load_state_dict -> reinitialize_lora_parameters -> train (train_own_forget_cl.py:515-536,
+    1696-1705), issued on the build's modules exactly as the reference driver issues it."""
+    import engine_cl
+    from gslora_hip.optim import FusedAdamW
+    from util.cal_norm import get_norm_of_lora
+    from util.utils import reinitialize_lora_parameters
+    g = np.load(os.path.join(golden_dir, "chain2.npz"))
+    cfg, C = recipe.cfg_full(), S.CHAIN
+    model = build_model(cfg, "fp32", recipe.make_state(cfg))
+    dev = torch.device("cuda")
+    crit = torch.nn.CrossEntropyLoss()
+    proto = S.prototypes(cfg)
+    work = tempfile.mkdtemp(prefix="gsl_test_")
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": C["BND_pro"], "MULTI_GPU": False, "WORK_PATH": work, "BACKBONE_NAME": "VIT"}
+    model.train()
+    x_ev = torch.tensor(recipe.make_images(cfg, 3, seed=901, tag="xev")).cuda()
+    y_ev = torch.tensor(recipe.make_labels(cfg, 3, seed=901, tag="yev")).cuda()
+    try:
+        for task in range(2):
+            if task > 0:
+                model.load_state_dict(torch.load(os.path.join(work, "task-level", f"Backbone_task_{task - 1}.pth")))
+                reinitialize_lora_parameters(model)
+                st = {n: p.detach().cpu().numpy() for n, p in model.named_parameters() if p.requires_grad}
+                assert all(np.all(v == 0) for k, v in st.items() if k.endswith("lora_B"))
+                for k, v in st.items():
+                    if k.endswith("lora_A"):       # kaiming_uniform(a = sqrt(50)): U(+-sqrt(6 / (51 fan_in)))
+                        b = np.sqrt(6.0 / (51.0 * v.shape[1]))
+                        assert 0.8 * b < np.abs(v).max() <= b, k
+                with torch.no_grad():
+                    for k, v in S.chain_lora_A(cfg, task).items():
+                        model.get_parameter(k).copy_(v.cuda())
+                    lo = model(x_ev, y_ev)[0].cpu().numpy()
+                assert np.abs(lo - g["logits_after_reload_reinit"]).max() < 1e-4
+                assert np.abs(lo - g["task0::eval_logits"]).max() < 1e-4        # B = 0: the merged base carries task 0's adapters
+            rem, forg = S.loaders(cfg, C["n_remain"], C["n_forget"], C["batch"], seed=10 + task)
+            opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=C["lr"], weight_decay=C["wd"], eps=1e-8)
+            with UpdateLog() as log:
+                engine_cl.train_one_epoch(
+                    model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=0,
+                    beta=C["betas"][task], alpha=C["alpha"], BND=C["BND"], batch=0, testloader_forget=None, testloader_remain=None,
+                    forget_acc_before=0.0, highest_H_mean=0.0, cfg=cfgd, task_i=task, use_prototype=True, prototype_dict=proto,
+                    prototype_weight_forget=C["pro_f_weight"], prototype_weight_remain=C["pro_r_weight"], **fresh_meters())
+            assert relmax(log.steps_in_reference_order(), g[f"task{task}::step_updates"]) < 1e-3
+            norms = np.array([float(v) for v in get_norm_of_lora(model, type="L2", group_num=cfg["depth"])])
+            assert np.abs(norms - g[f"task{task}::norm_list"]).max() < 1e-3
+            model.eval()
+            os.makedirs(os.path.join(work, "task-level"), exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(work, "task-level", f"Backbone_task_{task}.pth"))
+            with torch.no_grad():
+                lo = model(x_ev, y_ev)[0].cpu().numpy()
+            assert np.abs(lo - g[f"task{task}::eval_logits"]).max() < 2e-3
+            sd = model.state_dict()
+            assert np.abs(sd["transformer.layers.3.1.fn.fn.net.3.weight"][5].cpu().numpy() - g[f"task{task}::saved_w_l3_net3_row5"]).max() < 1e-4
+            rb = g[f"task{task}::saved_lora_B_l3_net3"]
+            assert np.abs(sd["transformer.layers.3.1.fn.fn.net.3.lora_B"].cpu().numpy() - rb).max() < 1e-3 * max(1.0, np.abs(rb).max())
+            model.train()
+    finally:
+        shutil.rmtree(work)
