@@ -1297,6 +1297,316 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* _
     }
 }
 
+// ------------------------------------------------------------------ bf16 MFMA kernel, persistent ping-pong schedule
+// One workgroup per CU, two groups of four waves (one wave of each group per SIMD). In every SLOT one group runs the K loop of its
+// 128x256 output tile (wave tile 128x64, 32 MFMAs per 32-deep K slice) while the other group runs the EPILOGUE of the tile it finished
+// in the previous slot (bias / GELU / GELU' / dropout on the VALU, LDS staging, full-row stores); then they swap. The matrix pipe and the
+// VALU are separate pipes of a SIMD, so the epilogue — which the 256x256 kernel above runs after its K loop with nothing to overlap —
+// executes under the other group's MFMAs. Both groups hit the same s_barrier once per K slice ("phase"): the K group needs it for the
+// LDS ring, the epilogue group paces its 32 output fragments over the phases.
+//   * LDS ring: 5 slots of one 32-deep K slice each (A 128 x 32 + W 256 x 32 bf16 = 24 KB; rows of 64 B, 16-byte chunks swizzled with
+//     SWZ = {0,2,3,1}[(row >> 2) & 3] on the DMA source and on the fragment read). In phase p the K group multiplies slice p from
+//     registers, reads slice p+1 from LDS into the other register set, and issues the LDS-DMA of slice p+4 into the slot slice p-1 left;
+//     the counted wait at the end of phase p (vmcnt(12): two younger slices in flight) retires slice p+2 one barrier before it is read.
+//   * the slice stream does not stop at a tile boundary: in the last four phases of a slot the K group has nothing left to fetch, and the
+//     OTHER group (its epilogue is finished by then) issues the first four slices of ITS next tile into the slots that fall free, so a
+//     K loop starts with its pipeline full. A group therefore issues, counts and waits for its own DMAs only; its (older) output stores
+//     can only make a counted wait conservative — loads retire in order, and no store is issued between a DMA and its wait.
+//   * persistent tile order: a workgroup walks the N tiles of one 128-row A panel (half a panel when the N-tile count is even; the two
+//     halves run on workgroups b and b^8, i.e. on one XCD), group 0 / group 1 taking alternate tiles: the A panel is fetched from HBM
+//     once and re-read from L2 by the same CU.
+// Epilogues: STORE (alpha, bias) and BIAS_GELU (two bf16 outputs); bf16 outputs only (N % 8 == 0, ldo % 8 == 0).
+constexpr int PP_TM = 128, PP_TN = 256, PP_BK = 32;
+constexpr int PP_A_B = PP_TM * PP_BK * 2;                      // 8192: A part of a slot (bytes)
+constexpr int PP_SLOT_B = (PP_TM + PP_TN) * PP_BK * 2;         // 24576
+constexpr int PP_NSLOT = 5;
+constexpr int PP_RING_B = PP_NSLOT * PP_SLOT_B;                // 122880
+constexpr int PP_CST_B = 2 * 16 * CLD * 2;                     // 4608 per wave: two outputs x 16 rows x 72 bf16
+constexpr int PP_BIAS_B = 64 * 4;                              // 256 per wave: the wave's 64 bias values
+constexpr int PP_SMEM_B = PP_RING_B + 4 * PP_CST_B + 8 * PP_BIAS_B;   // 143360 of 163840
+
+typedef unsigned int u32x4_pp __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pp_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);
+}
+__device__ __forceinline__ void pp_lds_write_b64(uint32_t addr, uint2 v) {
+  const unsigned long long q = ((unsigned long long)v.y << 32) | v.x;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(q) : "memory");
+}
+__device__ __forceinline__ u32x4_pp pp_lds_read_b128(uint32_t addr) {      // the caller waits (lgkmcnt) before it uses the value
+  u32x4_pp r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                           const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                           const bf16_t* __restrict__ A2, int lda2,
+                                                           const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  static_assert(EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU, "ping-pong kernel: bf16-output epilogues");
+  resolve_drop(e.drop);
+  __shared__ __attribute__((aligned(16))) char smem[PP_SMEM_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int fr = lane & 15, fc = lane >> 4;
+  const int nk1 = K1 / 64, nk = nk1 + K2 / 64;
+  const int NB = 2 * nk;                                       // phases (barriers) per slot
+  // ---- this workgroup's tile stream
+  const int ntm = (e.M + PP_TM - 1) / PP_TM, ntn = (e.N + PP_TN - 1) / PP_TN;
+  const int up = (ntn % 2 == 0) ? 2 : 1, tpu = ntn / up;
+  const int nunits = ntm * up;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int pb = (up == 2 && (G % 16) == 0) ? ((((b >> 4) * 8 + (b & 7)) << 1) | ((b >> 3) & 1)) : b;
+  const int my_units = (pb < nunits) ? (nunits - pb + G - 1) / G : 0;
+  const int n_tiles = my_units * tpu;
+  // tile t of this workgroup's unit ui: rows of panel u / up, N tile (u % up) * tpu + t   (up is 1 or 2)
+  auto tile_of = [&](int ui, int t, int& m0, int& n0) {
+    const int u = ui * G + pb;
+    m0 = ((up == 2) ? (u >> 1) : u) * PP_TM;
+    n0 = (((up == 2) ? (u & 1) : 0) * tpu + t) * PP_TN;
+  };
+
+  // ---- DMA of one K slice (slice x of the tile at (m0, n0)) into ring position rp: this wave's 2 A + 4 W instructions (16 rows each)
+  const int lrow = lane >> 2, lc = lane & 3;
+  const int csw = (lc ^ swz9(lrow)) * 8;                       // source chunk (elements); (row >> 2) & 3 == (lrow >> 2) & 3 for every 16-row block
+  const int abl = e.T;      // development ablation bits (GSL_PP_ABL): 1 A DMA from 16 hot rows, 2 W DMA from 16 hot rows, 8 no DMA, 16 no epilogue math, 32 no output stores
+  auto dma_slice = [&](int m0, int n0, int x, int rp) {
+    if (abl & 8) return;
+    const int kk = x >> 1, half = x & 1;
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kk < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kk * 64 + half * 32; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kk - nk1) * 64 + half * 32; }
+    char* slot = smem + rp * PP_SLOT_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = w4 * 2 + i;
+      const int gm = (abl & 1) ? lrow : min(m0 + rb * 16 + lrow, e.M - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + csw), (lptr_t)(slot + rb * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = w4 * 4 + i;
+      const int gn = (abl & 2) ? lrow : min(n0 + rb * 16 + lrow, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + ((abl & 2) ? 0 : k0) + csw), (lptr_t)(slot + PP_A_B + rb * 1024), 16, 0, 0);
+    }
+  };
+  // fragment read offsets inside a slot (bytes): A rows i*16 + fr, W rows w4*64 + j*16 + fr; chunk fc ^ swz9(fr)
+  const int fchunk = (fc ^ swz9(fr)) * 16;
+  const int aoff = fr * 64 + fchunk;
+  const int boff = PP_A_B + (w4 * 64 + fr) * 64 + fchunk;
+
+  f32x4_t acc[8][4];
+  bf16x8_t al[4], ah[4], bf0[4], bf1[4];
+  int ring = 0;            // ring position of slice 0 of the tile whose K loop runs in the current slot
+  float* bias_w = reinterpret_cast<float*>(smem + PP_RING_B + 4 * PP_CST_B) + wave * 64;      // wave-private
+  bf16_t* cst = reinterpret_cast<bf16_t*>(smem + PP_RING_B + w4 * PP_CST_B);                  // shared by waves w4 of both groups (never both in the epilogue role)
+
+  // development: cycle stamps of waves 0 and 4 of workgroup 0 after every barrier (GSL_PP_ABL bit 256, buffer = the unused `res` argument)
+  unsigned long long* dbg = ((abl & 256) && e.res && blockIdx.x == 0 && w4 == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(e.res)) + grp * 1024 : nullptr;
+  int stamp_i = 0;
+#define PP_STAMP()                                                                              \
+  if (dbg) { if (stamp_i < 1024) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) dbg[stamp_i] = t_; } ++stamp_i; }
+  // register operands: the W fragments of a slice (4 x 16 columns) are double buffered per phase, the A fragments per HALF phase
+  // (row fragments 0..3 / 4..7): 64 operand registers beside the 128 accumulators
+#define PP_READ_B(BF, RP)                                                                        \
+  if (!(abl & 128)) { const char* sl_ = smem + (RP) * PP_SLOT_B;                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) BF[j] = *reinterpret_cast<const bf16x8_t*>(sl_ + boff + j * 1024); }
+#define PP_READ_A(AF, RP, HALF)                                                                 \
+  if (!(abl & 128)) { const char* sl_ = smem + (RP) * PP_SLOT_B + (HALF) * 4096;                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = *reinterpret_cast<const bf16x8_t*>(sl_ + aoff + i * 1024); }
+#define PP_MFMA(AF, BF, ROW0, ZERO)                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
+      acc[(ROW0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(ROW0) + i][j], 0, 0, 0);
+  // one K-role phase: slice p is multiplied from registers (al = row fragments 0..3 and BC already loaded); the upper A half of slice p
+  // and the operands of slice p+1 are read meanwhile, the DMA of slice p+4 is issued, then the counted wait and the barrier
+  // One K-role phase. Every variant is straight-line code (DMA: the slice p+4 exists; NEXT: the slice p+1 exists; VM: the counted wait,
+  // -1 = none) and its instruction mix is pinned: the K wave is alone on its SIMD's matrix pipe, so its LDS reads and DMA issues
+  // must sit BETWEEN its MFMAs, not in front of them; the reads end 8 MFMAs before the phase does, so that the lgkmcnt wait is short.
+#define PP_VMWAIT(VM)                                                                           \
+  if ((VM) == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                             \
+  else if ((VM) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                        \
+  else if ((VM) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          \
+  else if ((VM) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define PP_PHASE(P, BC, BN, ZERO, DMA, NEXT, VM)                                                \
+  {                                                                                             \
+    const int p_ = (P);                                                                         \
+    PP_READ_A(ah, (ring + p_) % PP_NSLOT, 1)                                                    \
+    if (DMA) dma_slice(km0, kn0, p_ + 4, (ring + p_ + 4) % PP_NSLOT);                           \
+    PP_MFMA(al, BC, 0, ZERO)                                                                    \
+    if (NEXT) { PP_READ_B(BN, (ring + p_ + 1) % PP_NSLOT) PP_READ_A(al, (ring + p_ + 1) % PP_NSLOT, 0) } \
+    PP_MFMA(ah, BC, 4, ZERO)                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+    if (DMA) { _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } } \
+    else __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                    \
+    if (NEXT) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); }                            \
+    else __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    PP_VMWAIT(VM)                                                                               \
+    __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0), as a builtin: the compiler's own scoreboard starts the next phase clean */ \
+    if (!(abl & 64)) __builtin_amdgcn_s_barrier();                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    PP_STAMP()                                                                                  \
+  }
+
+  // ---- prologue: group 0 fills the pipeline of the first tile
+  if (grp == 0 && n_tiles > 0) {
+    int m0, n0;
+    tile_of(0, 0, m0, n0);
+#pragma unroll 1
+    for (int x = 0; x < 4 && x < NB; ++x) dma_slice(m0, n0, x, x);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  int em0 = 0, en0 = 0;     // tile whose epilogue this group owes
+  int cm0 = 0, cn0 = 0, xm0 = 0, xn0 = 0;      // tile s (K role) and tile s+1 (prefetched by the epilogue group)
+  int xui = 0, xt = 0;                          // stream position of tile s+1
+  if (n_tiles > 0) tile_of(0, 0, cm0, cn0);
+  if (n_tiles > 1) { xt = 1; if (xt == tpu) { xt = 0; xui = 1; } tile_of(xui, xt, xm0, xn0); }
+#pragma unroll 1
+  for (int s = 0; s <= n_tiles; ++s) {
+    const bool k_turn = (grp == (s & 1));
+    if (k_turn) {
+      // =============================================================== K role: tile s
+      if (s < n_tiles) {
+        const int km0 = cm0, kn0 = cn0;
+        __builtin_amdgcn_s_setprio(1);
+        float bval = 0.f;
+        { const int n = kn0 + w4 * 64 + lane; if (e.bias && n < e.N) bval = e.bias[n]; }      // older than slice 4's DMA (see the counted waits)
+        PP_READ_B(bf0, ring)
+        PP_READ_A(al, ring, 0)
+        // first K tile (phases 0, 1): the accumulators start from zero in phase 0
+        PP_PHASE(0, bf0, bf1, true, true, true, 13)
+        PP_PHASE(1, bf1, bf0, false, true, true, 13)
+#pragma unroll 1
+        for (int kt = 1; kt + 2 < nk; ++kt) {          // phases 2 .. NB - 5: steady state
+          PP_PHASE(2 * kt, bf0, bf1, false, true, true, 12)
+          PP_PHASE(2 * kt + 1, bf1, bf0, false, true, true, 12)
+        }
+        // the last four phases: this tile's slice stream has run dry (the other group issues the next tile's slices meanwhile)
+        PP_PHASE(NB - 4, bf0, bf1, false, false, true, 6)
+        PP_PHASE(NB - 3, bf1, bf0, false, false, true, 0)
+        PP_PHASE(NB - 2, bf0, bf1, false, false, true, -1)
+        PP_PHASE(NB - 1, bf1, bf0, false, false, false, -1)
+        bias_w[lane] = bval;
+        __builtin_amdgcn_s_setprio(0);
+        em0 = km0; en0 = kn0;
+      } else {
+#pragma unroll 1
+        for (int p = 0; p < NB; ++p) { if (!(abl & 64)) __builtin_amdgcn_s_barrier(); PP_STAMP() }
+      }
+    } else {
+      // =============================================================== epilogue role: tile s-1; prefetch for tile s+1
+      const bool has_tile = (s >= 1);
+      const bool has_next = (s + 1 < n_tiles);
+      const int nm0 = xm0, nn0 = xn0;
+      int p = 0;
+      const int PE = (NB > 4) ? NB - 4 : 1;
+      int quota = (32 + PE - 1) / PE;             // fragments that must be done before phase p may end: ceil((p + 1) * 32 / PE)
+      auto end_phase = [&]() {
+        if (has_next && p >= NB - 4) dma_slice(nm0, nn0, p - (NB - 4), (ring + p + 4) % PP_NSLOT);
+        if (has_next && p == NB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (!(abl & 64)) __builtin_amdgcn_s_barrier();
+        PP_STAMP()
+        ++p;
+        quota = ((p + 1) * 32 + PE - 1) / PE;
+      };
+      if (has_tile) {
+        const int mw = em0, nw = en0 + w4 * 64;
+        const int crow = lane >> 3, cch = lane & 7;
+        float bj[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias_w + j * 16 + fc * 4);
+          bj[j][0] = b4[0]; bj[j][1] = b4[1]; bj[j][2] = b4[2]; bj[j][3] = b4[3];
+        }
+        constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
+        constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
+        uint32_t wrow = 0u, rowstep = 0u;
+        if constexpr (DROPW) {
+          if (e.drop.thr) {
+            wrow = drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1);
+            rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
+          }
+        }
+        const bool full = (mw + PP_TM <= e.M) && (nw + 64 <= e.N);
+        bf16_t* o1 = reinterpret_cast<bf16_t*>(e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
+        bf16_t* o2 = e.out2 ? reinterpret_cast<bf16_t*>(e.out2) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8) : nullptr;
+        const size_t step8 = (size_t)8 * (size_t)e.ldo;
+        const uint32_t cst_a = pp_lds_addr(cst + fr * CLD + fc * 4);             // fragment-layout staging address (column fragment j: + 32 bytes)
+        const uint32_t cst_r = pp_lds_addr(cst + crow * CLD + cch * 8);          // row-layout read-back address
+        int done = 0;
+        // runtime loop over the 8 row fragments (16-row chunks) of the wave tile: the accumulators of chunk i are moved into a fixed
+        // register set first (static register indices everywhere; 16 moves per 1024 outputs)
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+          f32x4_t t4[4];
+          switch (i) {
+#define PP_CASE(I) case I: t4[0] = acc[I][0]; t4[1] = acc[I][1]; t4[2] = acc[I][2]; t4[3] = acc[I][3]; break;
+            PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) PP_CASE(4) PP_CASE(5) PP_CASE(6) default: t4[0] = acc[7][0]; t4[1] = acc[7][1]; t4[2] = acc[7][2]; t4[3] = acc[7][3]; break;
+#undef PP_CASE
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v[4] = {t4[j][0], t4[j][1], t4[j][2], t4[j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
+            const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
+            if (!(abl & 16) && (full || (m < e.M && n < e.N))) {
+              if constexpr (EPI == GSL_EPI_STORE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * e.alpha + bj[j][r];
+              } else {
+                epi_math<EPI, bf16_t, DROPW>(e, m, n, v, g, bj[j], wrow + (uint32_t)(j * 8) * DROP_PHI);
+              }
+            }
+            // staging through inline asm: the compiler would put s_waitcnt vmcnt(0) in front of every LDS access of a code path that also
+            // issues LDS-DMAs (they may alias for all it knows) — here that would drain this wave's output stores once per fragment
+            pp_lds_write_b64(cst_a + j * 32, make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])));
+            if constexpr (NOUT == 2) pp_lds_write_b64(cst_a + j * 32 + 16 * CLD * 2, make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3])));
+            ++done;
+            // pace: phase p may end once ceil((p + 1) * 32 / PE) fragments are done (the last four phases carry the next tile's DMAs)
+            while (p < PE && p < NB && done >= quota) end_phase();
+          }
+          wrow += rowstep;
+          // copy this 16-row chunk out as full 128-byte rows (the wave's DS operations execute in order: no barrier needed)
+          {
+            u32x4_pp val[2], val2[2];
+            val[0] = pp_lds_read_b128(cst_r);
+            val[1] = pp_lds_read_b128(cst_r + 8 * CLD * 2);
+            if constexpr (NOUT == 2) { val2[0] = pp_lds_read_b128(cst_r + 16 * CLD * 2); val2[1] = pp_lds_read_b128(cst_r + 24 * CLD * 2); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const int mm = mw + i * 16 + r * 8 + crow, nn = nw + cch * 8;
+              if (!(abl & 32) && (full || (mm < e.M && nn < e.N))) {
+                __builtin_nontemporal_store(val[r], reinterpret_cast<u32x4_pp*>(o1 + (size_t)r * step8));
+                if constexpr (NOUT == 2) { if (o2) __builtin_nontemporal_store(val2[r], reinterpret_cast<u32x4_pp*>(o2 + (size_t)r * step8)); }
+              }
+            }
+          }
+          o1 += 2 * step8;
+          if constexpr (NOUT == 2) { if (o2) o2 += 2 * step8; }
+        }
+      }
+      while (p < NB) end_phase();
+    }
+    // next slot: tile s+1 becomes the K tile, the stream advances
+    cm0 = xm0; cn0 = xn0;
+    if (s + 2 < n_tiles) { ++xt; if (xt == tpu) { xt = 0; ++xui; } tile_of(xui, xt, xm0, xn0); }
+    ring = (ring + NB) % PP_NSLOT;
+  }
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+#undef PP_PHASE
+#undef PP_STAMP
+#undef PP_VMWAIT
+}
+
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
@@ -1344,7 +1654,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 template <int EPI>
 static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
-                       int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e, hipStream_t st) {
+                       int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e_in, hipStream_t st) {
+  const EpiArgs& e = e_in;
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage, 8 = 256x256 8-phase ping-pong,
@@ -1359,6 +1670,18 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     if (EPI == GSL_EPI_BIAS_GELU && !ev && variant == 8) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
+    if (variant == 10 && (K1 + K2) >= 192 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && e.N >= 8) {
+      if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU) {
+        EpiArgs e = e_in;
+        { const char* ab = getenv("GSL_PP_ABL"); e.T = ab ? atoi(ab) : 0; }
+        const int ntm = (e.M + PP_TM - 1) / PP_TM, ntn = (e.N + PP_TN - 1) / PP_TN;
+        const int nunits = ntm * ((ntn % 2 == 0) ? 2 : 1);
+        int grid = nunits < 256 ? nunits : 256;
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(grid), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
+                           (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+        return check_launch("gsl_gemm_nt(pp)");
+      }
+    }
     if (variant == 9) {
       EpiArgs e9 = e;
       if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }

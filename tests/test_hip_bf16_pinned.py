@@ -74,8 +74,9 @@ def test_bias_gelu_bf16_dropout_matches_mask(ops, M, lora_seg):
     g0 = torch.empty_like(gp)
     ops.gemm_nt(c(A), c(W), h0, epilogue=L.EPI_BIAS_GELU, A2=c(A2), W2=c(W2), bias=bias.cuda(), out2=g0)
     sc = h0.float().cpu() * keep / (1 - p)
-    # (two independent bf16 roundings, 2^-9 relative each: of g * s in the dropped call, of g before the scaling here)
-    assert ((hh - sc).abs() - 1.02 * ulp * sc.abs()).max().item() < 1e-6
+    # (two independent bf16 roundings, each up to 2^-8 relative at the bottom of a binade: of g * s in the dropped call, of g before
+    # the scaling here)
+    assert ((hh - sc).abs() - 2.05 * ulp * sc.abs()).max().item() < 1e-6
 
 
 HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, BND_pro=2.0, pro_f_weight=0.05, pro_r_weight=0.1)
