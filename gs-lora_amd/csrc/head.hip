@@ -284,12 +284,16 @@ __device__ __forceinline__ float row_lse(const float* row, int D, int lane) {
 }
 
 __global__ __launch_bounds__(256) void proto_kl_rows_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
-                                                            const float* __restrict__ proto, float* __restrict__ rows, int B, int D) {
+                                                            const float* __restrict__ proto, float* __restrict__ rows, int B, int D, int C) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
   const float* a = emb + (size_t)r * D;
-  const float* t = proto + (size_t)labels[r] * D;
+  const long y = (long)labels[r];
+  // a label outside the prototype table (the reference raises KeyError, engine_cl.py:587-589): no out-of-bounds read, the loss turns
+  // NaN — a class missing INSIDE the table holds NaN rows (losses.prototype_table), with the same effect
+  if (y < 0 || y >= C) { if (lane == 0) rows[r] = __int_as_float(0x7fc00000); return; }
+  const float* t = proto + (size_t)y * D;
   const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
   float acc = 0.f;
   for (int d = lane; d < D; d += 64) {
@@ -302,19 +306,24 @@ __global__ __launch_bounds__(256) void proto_kl_rows_kernel(const float* __restr
 extern "C" int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, float* row_ws, int B,
                                 int D, int C, gsl_stream_t s) {
   GSL_CHECK_ARG(emb && labels && proto && out1 && row_ws && B > 0 && D > 0 && C > 0, "null/size");
-  hipLaunchKernelGGL(proto_kl_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, row_ws, B, D);
+  hipLaunchKernelGGL(proto_kl_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, row_ws, B, D, C);
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, as_stream(s), row_ws, out1, B, 1);
   return check_launch("gsl_proto_kl_fwd");
 }
 
 __global__ __launch_bounds__(256) void proto_kl_bwd_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
                                                            const float* __restrict__ proto, const float* __restrict__ coef,
-                                                           float scale, float* demb, int B, int D, int accumulate) {
+                                                           float scale, float* demb, int B, int D, int C, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
   const float* a = emb + (size_t)r * D;
-  const float* t = proto + (size_t)labels[r] * D;
+  const long y = (long)labels[r];
+  if (y < 0 || y >= C) {       // see proto_kl_rows_kernel
+    for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = __int_as_float(0x7fc00000);
+    return;
+  }
+  const float* t = proto + (size_t)y * D;
   const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
   const float k = coef[0] * scale;
   for (int d = lane; d < D; d += 64) {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void proto_kl_bwd_kernel(const float* __restri
 extern "C" int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef, float scale,
                                 float* demb, int B, int D, int C, int accumulate, gsl_stream_t s) {
   GSL_CHECK_ARG(emb && labels && proto && coef && demb && B > 0 && D > 0 && C > 0, "null/size");
-  hipLaunchKernelGGL(proto_kl_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, coef, scale, demb, B, D, accumulate);
+  hipLaunchKernelGGL(proto_kl_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(s), emb, labels, proto, coef, scale, demb, B, D, C, accumulate);
   return check_launch("gsl_proto_kl_bwd");
 }
 

@@ -178,7 +178,9 @@ def prototype_table(prototype_dict, device, dim=None):
         return ent[1]
     C = max(int(k) for k in prototype_dict) + 1
     any_v = next(iter(prototype_dict.values()))
-    table = torch.zeros(C, any_v.numel(), dtype=torch.float32)
+    # a class without a prototype holds NaN: the reference raises KeyError when a batch label misses (engine_cl.py:587-589); here the
+    # look-up happens on the device without a host sync, so the loss (and the meters) turn NaN instead of silently using zeros
+    table = torch.full((C, any_v.numel()), float("nan"), dtype=torch.float32)
     for k, v in prototype_dict.items():
         table[int(k)] = v.detach().float().cpu().reshape(-1)
     table = table.to(device)

@@ -52,6 +52,52 @@ class FusedAdamW(torch.optim.Optimizer):
     def graph_capturable(self):
         return bool(self._flat) and all(e.get("ok") for e in self._flat.values())
 
+    # ---- checkpointing: the moments live in flat buffers; state_dict() / load_state_dict() speak torch.optim.AdamW's layout
+    # (per parameter: step, exp_avg, exp_avg_sq), so an optimizer checkpoint moves between this class and torch.optim.AdamW
+    def _param_index(self):
+        return {id(p): i for i, p in enumerate(p for g in self.param_groups for p in g["params"])}
+
+    def state_dict(self):
+        sd = super().state_dict()
+        idx = self._param_index()
+        state = {}
+        for ent in self._flat.values():
+            if ent.get("ok"):
+                off = 0
+                for p in ent["order"]:
+                    n = p.numel()
+                    state[idx[id(p)]] = {"step": torch.tensor(float(ent["step"])), "exp_avg": ent["m"][off:off + n].view(p.shape).clone(),
+                                         "exp_avg_sq": ent["v"][off:off + n].view(p.shape).clone()}
+                    off += n
+        for p, st in self.state.items():      # scattered parameters (one launch per tensor)
+            if st:
+                state[idx[id(p)]] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
+        sd["state"] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        params = [p for g in self.param_groups for p in g["params"]]
+        self._loaded = {id(params[int(i)]): st for i, st in state.items()}
+        self._flat.clear()
+        self.state.clear()
+
+    def _apply_loaded(self, ent):
+        """Fill a freshly built flat group from a loaded checkpoint (called once, when the group is first seen after load_state_dict)."""
+        loaded = getattr(self, "_loaded", None)
+        if not loaded:
+            return
+        off = 0
+        for p in ent["order"]:
+            st = loaded.pop(id(p), None)
+            n = p.numel()
+            if st is not None:
+                ent["m"][off:off + n].copy_(st["exp_avg"].reshape(-1).to(ent["m"].device))
+                ent["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(ent["v"].device))
+                ent["step"] = int(float(st["step"]))
+            off += n
+
     def _flat_state(self, gi, group):
         """Detect that a group's grad-bearing params tile one contiguous f32 range (the LoRA bucket)."""
         ps = [p for p in group["params"] if p.grad is not None]
@@ -79,6 +125,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 ent["m"] = torch.zeros(n, device=first.device, dtype=torch.float32)
                 ent["v"] = torch.zeros(n, device=first.device, dtype=torch.float32)
                 ent["step"] = 0
+                self._apply_loaded(ent)
         self._flat[gi] = ent
         return ent
 
@@ -106,6 +153,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                    ld = getattr(self, "_loaded", {}).pop(id(p), None)
+                    if ld is not None:
+                        st["step"] = int(float(ld["step"]))
+                        st["m"].copy_(ld["exp_avg"].to(p.device)); st["v"].copy_(ld["exp_avg_sq"].to(p.device))
                 st["step"] += 1
                 ops.adamw_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["m"].view(-1), st["v"].view(-1),
                                group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])

@@ -116,9 +116,21 @@ def _check_not_replicated(model):
                            "(python -m torch.distributed.run --nproc-per-node N ...): gs_lora_step is data-parallel there.")
 
 
+class _EagerComm:
+    """The two exchanges of a data-parallel step, issued eagerly (the gradient one overlapped with the end of the backward)."""
+
+    @staticmethod
+    def all_reduce_scalars(pack):
+        dist.all_reduce(pack)
+
+    @staticmethod
+    def bucket_reducer(net, backend):
+        return _OverlappedBucketReduce(net, backend)
+
+
 def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
                  group_type="block", use_prototype=False, proto_table=None, w_f=0.0, w_r=0.0, BND_pro=0.0,
-                 backend=HipBackend, fuse_batches=True):
+                 backend=HipBackend, fuse_batches=True, _comm=_EagerComm):
     """Runs forward x2, the three-term loss, backward, gradient all-reduce and optimizer.step().
     Returns a packed DEVICE tensor of the 8 meter values (no host sync here):
       [beta*loss_forget, loss_remain, total, alpha*structure, top1_forget%, top1_remain%,
@@ -174,15 +186,60 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     kz = torch.zeros((), device=dev) if not use_prototype else None
     pack = torch.stack([f(ce_r_sum), f(ce_f_sum), f(hit_r), f(hit_f), torch.full((), n_r, device=dev), torch.full((), n_f, device=dev),
                         f(kl_f_sum) if use_prototype else kz, f(kl_r_sum) if use_prototype else kz])
-    dist.all_reduce(pack)
+    _comm.all_reduce_scalars(pack)
     structure = backend.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else None
     total, meters = backend.combine_pack(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro)
     optimizer.zero_grad()
-    reducer = _OverlappedBucketReduce(net, backend)
+    reducer = _comm.bucket_reducer(net, backend)
     total.backward()
     reducer.finish()
     optimizer.step()
     return meters
+
+
+class _SegmentedCapture:
+    """Captures a data-parallel step as HIP-graph SEGMENTS around its two collectives: [forward, loss sums, pack] | all-reduce(pack) |
+    [scalar tail, backward] | all-reduce(gradient bucket) | [AdamW, meters]. The collectives stay eager (any backend; nothing of RCCL is
+    captured), the ~190-370 kernel launches between them are replayed. During the capture pass the eager collectives run on
+    not-yet-computed buffers, which is harmless: only replays produce values. All segments share one memory pool."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs, self.colls, self._ctx = [], [], None
+
+    def begin(self):
+        g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local")
+        self._ctx.__enter__()
+        self.graphs.append(g)
+
+    def end(self, exc=(None, None, None)):
+        ctx, self._ctx = self._ctx, None
+        if ctx is not None:
+            ctx.__exit__(*exc)
+
+    def _cut(self, tensor):
+        self.end()
+        dist.all_reduce(tensor)
+        self.colls.append(tensor)
+        self.begin()
+
+    def all_reduce_scalars(self, pack):
+        self._cut(pack)
+
+    def bucket_reducer(self, net, backend):
+        cap = self
+
+        class _R:
+            def finish(self_inner):
+                cap._cut(backend.grad_bucket(net))
+        return _R()
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.colls):
+                dist.all_reduce(self.colls[i])
 
 
 class GraphedStep:
@@ -193,7 +250,8 @@ class GraphedStep:
     Everything else is part of the key — shapes, the loss hyper-parameters, the prototype table, train/eval state, the versions of
     the frozen weights (eval()/train() merge round trips, load_state_dict) — and a key change falls back to one eager step (which
     also refreshes the operand caches) followed by a fresh capture. Replays are bit-identical to eager steps (same kernels, same
-    seeds; tests/test_hip_graph.py). Single process only: with torch.distributed initialised the step stays eager."""
+    seeds; tests/test_hip_graph.py). Under torch.distributed (one process per GPU) the step is captured as three graph segments
+    around its two eager collectives (_SegmentedCapture): the few-shot / batch-48 regimes are launch-bound on every rank."""
 
     MAX_GRAPHS = 3      # captured configurations kept (e.g. the regular batch and the ragged last batches of the two loaders)
 
@@ -203,18 +261,22 @@ class GraphedStep:
         self._frozen = [p for n, p in self.net.named_parameters() if "lora_" not in n]
         self.graphs = {}            # key -> dict(graph, static, nfwd), insertion-ordered (oldest evicted)
         self.pending = None         # key seen once (ran eagerly); captured at its second sighting
+        self.failed = set()         # keys whose capture failed: they run eagerly
         self.seed_dev, self._seed_val = None, None
         self.replays = self.captures = self.eager_steps = 0
 
     def _key(self, x_r, y_r, x_f, y_f, kw):
         pt = kw.get("proto_table")
+        # everything a captured kernel launch bakes in by value: shapes, loss hyper-parameters, train/eval state, frozen weights, and the
+        # optimizer's betas / eps / weight decay and the dropout rates (lr and the step count are read from device memory)
+        hyper = tuple((g["betas"], g["eps"], g["weight_decay"]) for g in self.optimizer.param_groups)
+        drop = (getattr(self.net, "dropout_p", None), getattr(self.net, "emb_dropout_p", None))
         return (tuple(x_r.shape), tuple(x_f.shape), x_r.dtype, y_r.dtype, self.net.training, self.net.compute_dtype,
                 sum(p._version for p in self._frozen), None if pt is None else (pt.data_ptr(), tuple(pt.shape)),
-                tuple(sorted((k, v) for k, v in kw.items() if k != "proto_table")))
+                tuple(sorted((k, v) for k, v in kw.items() if k != "proto_table")), hyper, drop)
 
     def _usable(self):
-        return (_world() == 1 and hasattr(self.optimizer, "graph_capturable") and _plain_ce(self.criterion)
-                and not isinstance(self.model, nn.DataParallel))
+        return (hasattr(self.optimizer, "graph_capturable") and _plain_ce(self.criterion) and not isinstance(self.model, nn.DataParallel))
 
     def _eager(self, x_r, y_r, x_f, y_f, kw):
         self.eager_steps += 1
@@ -224,13 +286,22 @@ class GraphedStep:
         if not self._usable():
             return self._eager(x_r, y_r, x_f, y_f, kw)
         key = self._key(x_r, y_r, x_f, y_f, kw)
+        if key in self.failed:
+            return self._eager(x_r, y_r, x_f, y_f, kw)
         ent = self.graphs.get(key)
         if ent is None:
             if key != self.pending or not self.optimizer.graph_capturable():
                 # first sighting of this configuration: one eager step (warms operand caches, optimizer state, gradient bucket)
                 self.pending = key
                 return self._eager(x_r, y_r, x_f, y_f, kw)
-            ent = self._capture(x_r, y_r, x_f, y_f, kw)
+            try:
+                ent = self._capture(x_r, y_r, x_f, y_f, kw)
+            except Exception as exc:      # a capture that cannot complete (e.g. another thread touched the allocator): stay eager for this key
+                import warnings
+                warnings.warn(f"gs-lora_amd: HIP-graph capture of the step failed ({type(exc).__name__}: {exc}); this configuration runs eagerly")
+                self.failed.add(key)
+                self.pending = None
+                return self._eager(x_r, y_r, x_f, y_f, kw)
             frozen_now = key[6]
             for k in [k for k in self.graphs if k[6] != frozen_now]:      # graphs captured against older frozen weights are stale
                 del self.graphs[k]
@@ -266,11 +337,23 @@ class GraphedStep:
         self.optimizer.graph_sync()
         calls0 = r.drop_calls
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         self.optimizer.graph_mode, r.seed_dev = True, self.seed_dev
         try:
-            with torch.cuda.graph(graph):
-                static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *static[:4], **kw)
+            if _world() > 1:
+                graph = _SegmentedCapture()
+                graph.begin()
+                try:
+                    static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *static[:4], _comm=graph, **kw)
+                except BaseException:
+                    import sys
+                    graph.end(sys.exc_info())
+                    raise
+                graph.end()
+            else:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: allocator / stream activity of OTHER host threads (a DataLoader's pin_memory thread) does not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *static[:4], **kw)
         finally:
             self.optimizer.graph_mode, r.seed_dev = False, None     # eager forwards keep passing the seed by value
             nfwd = r.drop_calls - calls0

@@ -127,12 +127,21 @@ class ViTRunner:
         self._packs, self._pack_tables, self._retired = {}, {}, []
         self._rank = 0
         self.seed_dev = None      # int64 [1] device tensor: dropout seed of a step that is being captured / replayed as a HIP graph
-        self.drop_seed = 0x5EED
+        # dropout stream: torch.manual_seed() selects it (like the reference's nn.Dropout), and every data-parallel rank draws its own
+        self.drop_seed = self._initial_drop_seed()
         self.drop_calls = 0
         self.grad_hook = None     # callable(layer) invoked when the LoRA gradients of `layer` are complete (data-parallel overlap, step.py)
 
     def __deepcopy__(self, memo):   # copies of the model build their own runner lazily
         return None
+
+    @staticmethod
+    def _initial_drop_seed():
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        z = (torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        return int(z & 0x7FFFFFFFFFF)      # 43 bits: (seed << 20) + call counter stays below 2^63
 
     # ------------------------------------------------------------------ caches
     def _cached(self, cache, key, param, fn):
@@ -333,6 +342,9 @@ class ViTRunner:
             l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
             lora_on = r > 0 and not attn_site and not l1.merged
+            if lora_on and (abs(l1.scaling * r - 1.0) > 1e-9 or abs(l2.scaling * r - 1.0) > 1e-9):
+                raise NotImplementedError("gs-lora_amd: the fused LoRA path uses scaling = 1 / r (lora_alpha = 1, the only value GS-LoRA "
+                                          f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
             u1 = u2 = None
             h = torch.empty(M, mlp, device=img.device, dtype=dt)
             gp = torch.empty(M, mlp, device=img.device, dtype=dt) if save else None

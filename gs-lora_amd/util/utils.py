@@ -73,7 +73,13 @@ def calculate_prototypes(backbone, dataset, batch_size=32, device="cuda", aug_nu
             images, labels = images.to(device), labels.to(device).long()
             _, emb = backbone(images, labels)
             if sums is None:
-                ncls = backbone.loss.weight.shape[0]
+                head = getattr(backbone, "loss", None)          # ViT_face: CosFace head; ModifiedViT: torchvision's heads.head
+                if head is not None and hasattr(head, "weight"):
+                    ncls = head.weight.shape[0]
+                elif hasattr(backbone, "heads"):
+                    ncls = backbone.heads.head.out_features
+                else:
+                    ncls = int(labels.max().item()) + 1
                 sums = torch.zeros(ncls, emb.shape[1], device=emb.device)
                 counts = torch.zeros(ncls, device=emb.device)
             sums.index_add_(0, labels, emb)

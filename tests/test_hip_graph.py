@@ -122,3 +122,53 @@ def test_graphs_of_several_batch_shapes_are_kept():
         if a.requires_grad:
             assert torch.equal(a, c), n
     assert (g.eager_steps, g.captures, g.replays) == (2, 2, 6) and len(g.graphs) == 2
+
+
+def test_segmented_graph_replay_under_data_parallel_equals_eager(monkeypatch):
+    """With torch.distributed active the step is captured as three graph segments around its two eager collectives (config 5: few-shot
+    batches on 8 GPUs are launch-bound on every rank). One process here: the world size is faked to 2 and the collectives are replaced by
+    stand-ins that scale their argument (so that a skipped or doubled collective would show), which exercises exactly the
+    capture / replay machinery of gslora_hip.step._SegmentedCapture; replays must be BIT-IDENTICAL to eager data-parallel steps."""
+    import torch.distributed as dist
+    from gslora_hip import step as S
+    from gslora_hip.optim import FusedAdamW
+    calls = {"n": 0}
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls["n"] += 1
+        t.mul_(1.25)              # a visible, deterministic "sum over ranks"
+        return _Work() if async_op else None
+    monkeypatch.setattr(S, "_world", lambda: 2)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    cfg, b = recipe.cfg_small2(), 4
+    m1 = build(cfg, "bf16", 0.1)
+    m2 = copy.deepcopy(m1)
+    mk_opt = lambda m: FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    o1, o2 = mk_opt(m1), mk_opt(m2)
+    crit = torch.nn.CrossEntropyLoss()
+    proto = torch.tensor(recipe.make_prototypes(cfg)).cuda()
+    kw = dict(beta=0.15, alpha=1e-2, BND=105.0, use_structure=True, group_type="block", use_prototype=True, proto_table=proto,
+              w_f=0.05, w_r=0.1, BND_pro=2.0)
+    g = S.GraphedStep(m2, o2, crit)
+    for s in range(6):
+        if s == 4:
+            for o in (o1, o2):
+                o.param_groups[0]["lr"] = 5e-3
+        xr, yr, xf, yf = batch(cfg, b, s)
+        n0 = calls["n"]
+        p1 = S.gs_lora_step(m1, o1, crit, xr, yr, xf, yf, **kw)
+        n_eager = calls["n"] - n0
+        p2 = g(xr, yr, xf, yf, **kw)
+        n_graph = calls["n"] - n0 - n_eager
+        assert n_eager == 3                       # packed scalars + the two messages of the overlapped gradient reduction
+        assert n_graph == (3 if s == 0 else 2)    # replays: packed scalars + ONE gradient message between the segments
+        assert torch.equal(p1, p2), (s, p1.tolist(), p2.tolist())
+        for (n, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()):
+            if a.requires_grad:
+                assert torch.equal(a, c), (s, n)
+    assert (g.eager_steps, g.captures, g.replays) == (1, 1, 5)
+    assert len(g.graphs[next(iter(g.graphs))]["graph"].graphs) == 3

@@ -500,3 +500,62 @@ def test_single_task_engine_alpha_gate_grouping_and_fewshot_swap():
     assert ret[0] == 3
     ret, met = run(1, dict(base, few_shot=False), 3, 1)
     assert ret[0] == 1
+
+
+def test_fused_adamw_state_dict_round_trip():
+    """FusedAdamW.state_dict() speaks torch.optim.AdamW's layout (step / exp_avg / exp_avg_sq per parameter): a checkpoint taken after two
+    steps continues identically in a fresh FusedAdamW and in torch.optim.AdamW (the flat moments used to be dropped)."""
+    from gslora_hip.optim import FusedAdamW
+    cfg = recipe.cfg_small2()
+    proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
+    m = build(cfg, "fp32").train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=1e-2, weight_decay=0.05, eps=1e-8)
+    for s in range(2):
+        xr, yr, xf, yf = batches(cfg, 3, s)
+        total, _ = total_loss(m, xr, yr, xf, yf, HYPER, proto)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    assert len(sd["state"]) == len(params) and all(float(v["step"]) == 2.0 for v in sd["state"].values())
+    p0 = [p.detach().clone() for p in params]
+    xr, yr, xf, yf = batches(cfg, 3, 2)
+    total, _ = total_loss(m, xr, yr, xf, yf, HYPER, proto)
+    opt.zero_grad()
+    total.backward()
+    grads = [p.grad.detach().clone() for p in params]
+    opt.step()
+    want = [p.detach().clone() for p in params]
+    # (1) torch.optim.AdamW restored from the same checkpoint, same gradients
+    tp = [torch.nn.Parameter(q.clone()) for q in p0]
+    topt = torch.optim.AdamW(tp, lr=1e-2, weight_decay=0.05, eps=1e-8)
+    topt.load_state_dict(sd)
+    for q, g in zip(tp, grads):
+        q.grad = g.clone()
+    topt.step()
+    for q, w in zip(tp, want):
+        assert (q.detach() - w).abs().max() < 2e-6
+    # (2) a fresh FusedAdamW restored from the checkpoint
+    with torch.no_grad():
+        for p, q in zip(params, p0):
+            p.copy_(q)
+    opt2 = FusedAdamW(params, lr=1e-2, weight_decay=0.05, eps=1e-8)
+    opt2.load_state_dict(sd)
+    for p, g in zip(params, grads):
+        p.grad.copy_(g)
+    opt2.step()
+    for p, w in zip(params, want):
+        assert torch.equal(p.detach(), w)
+
+
+def test_prototype_label_outside_table_is_loud():
+    """A batch label without a prototype: the reference raises KeyError (engine_cl.py:587-589); the device-side look-up cannot raise
+    without a host sync, so the loss turns NaN — never an out-of-bounds read, never a silent all-zero prototype."""
+    import engine_cl
+    emb = torch.randn(4, 64, device="cuda")
+    proto = {0: torch.randn(64), 2: torch.randn(64)}
+    ok = engine_cl.get_prototype_loss(emb, torch.tensor([0, 2, 2, 0], device="cuda"), proto)
+    assert torch.isfinite(ok)
+    assert torch.isnan(engine_cl.get_prototype_loss(emb, torch.tensor([0, 1, 2, 0], device="cuda"), proto))      # class 1: hole in the table
+    assert torch.isnan(engine_cl.get_prototype_loss(emb, torch.tensor([0, 2, 7, 0], device="cuda"), proto))      # class 7: beyond the table

@@ -558,3 +558,36 @@ def test_data_prefetcher_ring_delivers_batches_in_order(ops):
     pf = data_prefetcher(dev_batches, torch.device("cuda"), prefetch=True)
     x0, _ = pf.next()
     assert x0.data_ptr() == dev_batches[0][0].data_ptr()
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(5713, 2048, 512, 64), (1031, 1536, 512, 0), (2600, 512, 2048, 0), (640, 256, 192, 0)])
+def test_gemm_pingpong_variant(ops, monkeypatch, M, N, K1, K2):
+    """The persistent ping-pong kernel (GSL_GEMM_VARIANT=10; measured, not the default — profiles/r02_pp_pingpong.md): STORE and
+    BIAS_GELU (+ dropout) results against fp32 torch on the bf16-rounded operands, ragged M and N-tile counts of 8 / 6 / 2 / 1."""
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_GEMM_VARIANT", "10")
+    dt = torch.bfloat16
+    A1, W1 = rnd(M, K1, seed=11), rnd(N, K1, seed=12, scale=K1 ** -0.5)
+    A2 = W2 = None
+    acc = as_dt(A1, dt) @ as_dt(W1, dt).t()
+    if K2:
+        A2, W2 = rnd(M, K2, seed=13), rnd(N, K2, seed=14, scale=0.1)
+        A2[:, 8:] = 0
+        acc = acc + as_dt(A2, dt) @ as_dt(W2, dt).t()
+    c = lambda t: None if t is None else t.cuda().to(dt)
+    bias = rnd(N, seed=15)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(c(A1), c(W1), out, A2=c(A2), W2=c(W2), alpha=0.5, bias=bias.cuda())
+    assert relerr(out.float().cpu(), 0.5 * acc + bias) < 1.5e-2
+    out2 = torch.empty(M, N, device="cuda", dtype=dt)
+    p, seed, site = 0.1, 991, 9
+    ops.gemm_nt(c(A1), c(W1), out, epilogue=L.EPI_BIAS_GELU, A2=c(A2), W2=c(W2), bias=bias.cuda(), out2=out2, p_drop=p, seed=seed, site=site)
+    keep = ops.dropout_mask(M * N, p, seed, site, "cuda").cpu().reshape(M, N).float()
+    a = (acc + bias).requires_grad_(True)
+    g = F.gelu(a)
+    gp, = torch.autograd.grad(g.sum(), a)
+    ref_h, ref_g = g.detach() * keep / (1 - p), gp * keep / (1 - p)
+    hh, gg = out.float().cpu(), out2.float().cpu()
+    assert (hh[keep == 0] == 0).all() and (gg[keep == 0] == 0).all()
+    assert ((hh - ref_h).abs() - 2.0 ** -8 * ref_h.abs()).max() < 2e-3
+    assert ((gg - ref_g).abs() - 2.0 ** -8 * ref_g.abs()).max() < 2e-3
