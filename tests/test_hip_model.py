@@ -530,7 +530,7 @@ def test_fused_adamw_state_dict_round_trip():
     # (1) torch.optim.AdamW restored from the same checkpoint, same gradients
     tp = [torch.nn.Parameter(q.clone()) for q in p0]
     topt = torch.optim.AdamW(tp, lr=1e-2, weight_decay=0.05, eps=1e-8)
-    topt.load_state_dict(sd)
+    topt.load_state_dict(copy.deepcopy(sd))      # (torch keeps references to the tensors it is handed and steps them in place)
     for q, g in zip(tp, grads):
         q.grad = g.clone()
     topt.step()
