@@ -1607,6 +1607,228 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #undef PP_VMWAIT
 }
 
+// ------------------------------------------------------------------ bf16 MFMA kernel, in-wave software-pipelined epilogue ("iw")
+// What profiles/r02_pp_pingpong.md taught: for the fused FFN1 the epilogue's VALU work (~35 issue slots per output) equals the tile's
+// matrix-pipe work, a wave issues one instruction per ~4.5 cycles, and a wave that is alone on its SIMD hides nothing. So here EVERY wave
+// carries both streams: it keeps TWO accumulator sets (its 64x64 tile of the current 128x256 workgroup tile and of the previous one),
+// and each 32-deep K slice ("step": 8 fragment reads, 3 LDS-DMA issues, 16 MFMAs) of the current tile carries the epilogue of ONE 16x16
+// fragment of the previous tile (bias / GELU / GELU' / dropout, packed into a wave-private LDS chunk; every fourth step the 16-row chunk
+// is copied out as full 128-byte rows). The two instruction streams are independent, both waves of a SIMD run them, and the step body is
+// straight-line code whose MFMA : VALU mix is pinned with sched_group_barrier. 16 fragments over the 2*NK >= 16 steps of a tile.
+//   * persistent: a workgroup walks the N tiles of (half) a 128-row A panel, the 5-slot slice ring and its DMA stream run across tile
+//     boundaries (steps NB-4 .. NB-1 fetch the next tile's first slices);
+//   * counted waits: vmcnt retires in issue order on gfx9 / CDNA (loads and stores; LLVM's own waitcnt insertion relies on it), so the
+//     wait for slice p+1 at the end of step p is vmcnt(9) — the 9 DMA instructions of slices p+2 .. p+4 may stay in flight; output
+//     stores that are younger than those can only make it wait longer;
+//   * full tiles only (M % 128 == 0, N % 256 == 0, K = NK * 64 with NK in {8, 9}): no bounds tests inside a step. Other shapes run on the
+//     8-phase kernel.
+constexpr int IW_TM = 128, IW_TN = 256;
+constexpr int IW_A_B = IW_TM * 32 * 2;                         // 8192
+constexpr int IW_SLOT_B = (IW_TM + IW_TN) * 32 * 2;            // 24576
+constexpr int IW_NSLOT = 5;
+constexpr int IW_RING_B = IW_NSLOT * IW_SLOT_B;                // 122880
+constexpr int IW_CST_B = 2 * 16 * CLD * 2;                     // 4608 per wave
+constexpr int IW_BIAS_B = 2 * 64 * 4;                          // 512 per wave: bias of the current and of the previous tile
+constexpr int IW_SMEM_B = IW_RING_B + 8 * IW_CST_B + 8 * IW_BIAS_B;   // 163840: all of the CU's LDS
+
+__device__ __forceinline__ void iw_lds_write_b32(uint32_t addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+
+template <int EPI, int NK>
+__global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                           const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                           const bf16_t* __restrict__ A2, int lda2,
+                                                           const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  static_assert(EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU, "iw kernel: bf16-output epilogues");
+  static_assert(NK >= 8, "16 output fragments are spread over the 2 NK steps of a tile");
+  constexpr int NB = 2 * NK;
+  constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
+  resolve_drop(e.drop);
+  __shared__ __attribute__((aligned(16))) char smem[IW_SMEM_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fc = lane >> 4;
+  const int nk1 = K1 / 64;
+  // ---- tile stream (as in the ping-pong kernel): unit = (half) an A panel, its N tiles are consecutive
+  const int ntm = e.M / IW_TM, ntn = e.N / IW_TN;
+  const int up = (ntn % 2 == 0) ? 2 : 1, tpu = ntn / up;
+  const int nunits = ntm * up;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int pb = (up == 2 && (G % 16) == 0) ? ((((b >> 4) * 8 + (b & 7)) << 1) | ((b >> 3) & 1)) : b;
+  const int my_units = (pb < nunits) ? (nunits - pb + G - 1) / G : 0;
+  const int n_tiles = my_units * tpu;
+  if (n_tiles == 0) return;
+  auto tile_of = [&](int ui, int t, int& m0, int& n0) {
+    const int u = ui * G + pb;
+    m0 = ((up == 2) ? (u >> 1) : u) * IW_TM;
+    n0 = (((up == 2) ? (u & 1) : 0) * tpu + t) * IW_TN;
+  };
+  // ---- DMA: a slice = 8 A row blocks + 16 W row blocks of 16 rows; wave w issues blocks w, w + 8, w + 16
+  // addresses: wave-uniform 64-bit base (SALU) + one 32-bit per-lane byte offset per operand panel (no per-lane 64-bit pointers)
+  const int lrow = lane >> 2, lc = lane & 3;
+  const int csw = (lc ^ swz9(lrow)) * 8;
+  const uint32_t la1 = (uint32_t)(((wave * 16 + lrow) * lda1 + csw) * 2), la2 = (uint32_t)(((wave * 16 + lrow) * lda2 + csw) * 2);
+  const uint32_t lw1 = (uint32_t)(((wave * 16 + lrow) * ldw1 + csw) * 2), lw2 = (uint32_t)(((wave * 16 + lrow) * ldw2 + csw) * 2);
+  auto dma_slice = [&](int m0, int n0, int x, int rp) {
+    const int kk = x >> 1, half = x & 1;
+    const bool seg1 = kk < nk1;
+    const int k0 = (seg1 ? kk : kk - nk1) * 64 + half * 32;
+    const char* Au = reinterpret_cast<const char*>(seg1 ? A1 : A2) + ((size_t)m0 * (size_t)(seg1 ? lda1 : lda2) + (size_t)k0) * 2;
+    const char* Wu = reinterpret_cast<const char*>(seg1 ? W1 : W2) + ((size_t)n0 * (size_t)(seg1 ? ldw1 : ldw2) + (size_t)k0) * 2;
+    const size_t w8 = (size_t)(seg1 ? ldw1 : ldw2) * 256;          // 128 W rows further (row block + 8)
+    const uint32_t la = seg1 ? la1 : la2, lw = seg1 ? lw1 : lw2;
+    char* slot = smem + rp * IW_SLOT_B;
+    // development ablation (GSL_PP_ABL through e.T): 1 = no A DMA, 2 = no W DMA (wrong results; measures what the DMA stream costs)
+    if (!(e.T & 1)) __builtin_amdgcn_global_load_lds((gptr_t)(Au + la), (lptr_t)(slot + wave * 1024), 16, 0, 0);
+    if (!(e.T & 2)) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wu + lw), (lptr_t)(slot + IW_A_B + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wu + w8 + lw), (lptr_t)(slot + IW_A_B + (wave + 8) * 1024), 16, 0, 0);
+    }
+  };
+  const int fchunk = (fc ^ swz9(fr)) * 16;
+  const int aoff = (wm * 64 + fr) * 64 + fchunk;
+  const int boff = IW_A_B + (wn * 64 + fr) * 64 + fchunk;
+  bf16_t* cst = reinterpret_cast<bf16_t*>(smem + IW_RING_B + wave * IW_CST_B);
+  const uint32_t bias_a = pp_lds_addr(smem + IW_RING_B + 8 * IW_CST_B + wave * IW_BIAS_B);
+  const int crow = lane >> 3, cch = lane & 7;
+  const uint32_t cst_a = pp_lds_addr(cst + fr * CLD + fc * 4);
+  const uint32_t cst_r = pp_lds_addr(cst + crow * CLD + cch * 8);
+
+  f32x4_t accc[4][4], accp[4][4];          // current tile (K loop) / previous tile (epilogue)
+  bf16x8_t af[4], bf[4];
+  u32x4_pp bnx;                             // bias values of the next step's fragment (read from LDS one step ahead)
+  int ring = 0, par = 0;                    // par: LDS bias slot of the CURRENT tile (the previous tile's is par ^ 1)
+  // per-tile epilogue state of the PREVIOUS tile
+  bf16_t* o1 = nullptr; bf16_t* o2 = nullptr;
+  uint32_t wrow = 0u;
+  const uint32_t rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
+  const size_t step8 = (size_t)8 * (size_t)e.ldo;
+
+  using IC0 = std::integral_constant<int, 0>;
+  // one step = one 32-deep K slice of the current tile (KON) + one output fragment of the previous tile (EON)
+  auto step = [&](auto pc, auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool KON = decltype(konc)::value, EON = decltype(eonc)::value;
+    if constexpr (KON) {
+      const char* sl = smem + ((ring + P) % IW_NSLOT) * IW_SLOT_B;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(sl + boff + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sl + aoff + i * 1024);
+      // slice P + 4: of this tile, or the first slices of the next one (a workgroup without a next tile re-reads its own: no branch)
+      if constexpr (P + 4 < NB) dma_slice(km0, kn0, P + 4, (ring + P + 4) % IW_NSLOT);
+      else dma_slice(nm0, nn0, P + 4 - NB, (ring + P + 4) % IW_NSLOT);
+    }
+    if constexpr (EON && P < 16) {
+      constexpr int I = P >> 2, J = P & 3;
+      float v[4] = {accp[I][J][0], accp[I][J][1], accp[I][J][2], accp[I][J][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
+      const float bq[4] = {__uint_as_float(bnx[0]), __uint_as_float(bnx[1]), __uint_as_float(bnx[2]), __uint_as_float(bnx[3])};
+      if constexpr (EPI == GSL_EPI_STORE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * e.alpha + bq[r];
+      } else {
+        epi_math<EPI, bf16_t, true>(e, 0, 0, v, g, bq, wrow + (uint32_t)(J * 8) * DROP_PHI);
+      }
+      pp_lds_write_b64(cst_a + J * 32, make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])));
+      if constexpr (NOUT == 2) pp_lds_write_b64(cst_a + J * 32 + 16 * CLD * 2, make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3])));
+    }
+    if constexpr (KON) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], (P == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : accc[i][j], 0, 0, 0);
+      // instruction mix of the step: the fragment reads first, the DMA issues among the first epilogue instructions (they also cover
+      // the LDS latency), then one MFMA per 7 VALU instructions
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EON && P < 16 && (P & 3) == 3) {
+      // chunk (P >> 2) complete: copy its 16 rows out as full 128-byte rows (the wave's own DS operations execute in order)
+      u32x4_pp val[2], val2[2];
+      val[0] = pp_lds_read_b128(cst_r);
+      val[1] = pp_lds_read_b128(cst_r + 8 * CLD * 2);
+      if constexpr (NOUT == 2) { val2[0] = pp_lds_read_b128(cst_r + 16 * CLD * 2); val2[1] = pp_lds_read_b128(cst_r + 24 * CLD * 2); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        __builtin_nontemporal_store(val[r], reinterpret_cast<u32x4_pp*>(o1 + (size_t)r * step8));
+        if constexpr (NOUT == 2) __builtin_nontemporal_store(val2[r], reinterpret_cast<u32x4_pp*>(o2 + (size_t)r * step8));
+      }
+      o1 += 2 * step8;
+      if constexpr (NOUT == 2) o2 += 2 * step8;
+      wrow += rowstep;
+    }
+    // bias of the next step's fragment (column fragment (P + 1) & 3 of the previous tile): covered by the lgkmcnt wait below
+    if constexpr (EON && P + 1 < 16) bnx = pp_lds_read_b128(bias_a + (uint32_t)((par ^ 1) * 256 + (((P + 1) & 3) * 16 + fc * 4) * 4));
+    if constexpr (KON) {
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            // slice P + 1 has landed (slices P + 2 .. P + 4 may still fly)
+      __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto tile_body = [&](auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
+    constexpr bool KON = decltype(konc)::value;
+    float bval = 0.f;
+    if constexpr (KON) { if (e.bias) bval = e.bias[kn0 + wn * 64 + lane]; }
+    [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+      (step(std::integral_constant<int, Ps>{}, konc, eonc, km0, kn0, nm0, nn0), ...);
+    }(std::make_integer_sequence<int, NB>{});
+    if constexpr (KON) iw_lds_write_b32(bias_a + (uint32_t)(par * 256 + lane * 4), bval);      // this tile's bias, for its epilogue during the next tile
+  };
+  // hand the finished tile over to the epilogue side
+  auto hand_over = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accp[i][j] = accc[i][j];
+    par ^= 1;                                                     // the finished tile's bias slot is now "previous"
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bnx = pp_lds_read_b128(bias_a + (uint32_t)((par ^ 1) * 256 + (fc * 4) * 4));      // column fragment 0 of step 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    o1 = reinterpret_cast<bf16_t*>(e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
+    o2 = reinterpret_cast<bf16_t*>(NOUT == 2 ? e.out2 : e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
+    wrow = e.drop.thr ? drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1) : 0u;
+  };
+
+  using T_ = std::true_type; using F_ = std::false_type;
+  int cm0, cn0, xm0, xn0, xui = 0, xt = 0;
+  tile_of(0, 0, cm0, cn0);
+  xm0 = cm0; xn0 = cn0;
+  if (n_tiles > 1) { xt = 1; if (xt == tpu) { xt = 0; xui = 1; } tile_of(xui, xt, xm0, xn0); }
+  // prologue: slices 0 .. 3 of the first tile
+#pragma unroll
+  for (int x = 0; x < 4; ++x) dma_slice(cm0, cn0, x, x);
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // first tile: K loop only
+  tile_body(T_{}, F_{}, cm0, cn0, xm0, xn0);
+  ring = (ring + NB) % IW_NSLOT;
+#pragma unroll 1
+  for (int s = 1; s < n_tiles; ++s) {
+    hand_over(cm0, cn0);
+    cm0 = xm0; cn0 = xn0;
+    if (s + 1 < n_tiles) { ++xt; if (xt == tpu) { xt = 0; ++xui; } tile_of(xui, xt, xm0, xn0); }
+    tile_body(T_{}, T_{}, cm0, cn0, xm0, xn0);
+    ring = (ring + NB) % IW_NSLOT;
+  }
+  // drain: the epilogue of the last tile
+  hand_over(cm0, cn0);
+  tile_body(F_{}, T_{}, 0, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A1, int lda1,
@@ -1680,6 +1902,23 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(grid), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
                            (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
         return check_launch("gsl_gemm_nt(pp)");
+      }
+    }
+    if (variant == 11 && (e.M % IW_TM) == 0 && (e.N % IW_TN) == 0 && (e.ldo % 8) == 0 && (K1 % 64) == 0 && (K2 % 64) == 0 &&
+        ((K1 + K2) == 512 || (K1 + K2) == 576) && (EPI != GSL_EPI_BIAS_GELU || e.out2)) {
+      if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU) {
+        EpiArgs e = e_in;
+        { const char* ab = getenv("GSL_PP_ABL"); e.T = ab ? atoi(ab) : 0; }
+        const int ntm = e.M / IW_TM, ntn = e.N / IW_TN;
+        const int nunits = ntm * ((ntn % 2 == 0) ? 2 : 1);
+        const int grid = nunits < 256 ? nunits : 256;
+        if ((K1 + K2) == 576)
+          hipLaunchKernelGGL((gemm_bf16_iw_kernel<EPI, 9>), dim3(grid), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
+                             (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+        else
+          hipLaunchKernelGGL((gemm_bf16_iw_kernel<EPI, 8>), dim3(grid), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
+                             (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e);
+        return check_launch("gsl_gemm_nt(iw)");
       }
     }
     if (variant == 9) {

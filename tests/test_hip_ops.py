@@ -591,3 +591,36 @@ def test_gemm_pingpong_variant(ops, monkeypatch, M, N, K1, K2):
     assert (hh[keep == 0] == 0).all() and (gg[keep == 0] == 0).all()
     assert ((hh - ref_h).abs() - 2.0 ** -8 * ref_h.abs()).max() < 2e-3
     assert ((gg - ref_g).abs() - 2.0 ** -8 * ref_g.abs()).max() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(2560, 2048, 512, 64), (1536, 1536, 512, 0), (1280, 256, 512, 0)])
+def test_gemm_inwave_pipelined_variant(ops, monkeypatch, M, N, K1, K2):
+    """The in-wave software-pipelined kernel (GSL_GEMM_VARIANT=11; measured, not the default — profiles/r02_pp_pingpong.md): full tiles
+    only (M % 128 == 0, N % 256 == 0, K in {512, 576}); N-tile counts 8 / 6 / 1, workgroups with one and with several tiles."""
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_GEMM_VARIANT", "11")
+    dt = torch.bfloat16
+    A1, W1 = rnd(M, K1, seed=21), rnd(N, K1, seed=22, scale=K1 ** -0.5)
+    A2 = W2 = None
+    acc = as_dt(A1, dt) @ as_dt(W1, dt).t()
+    if K2:
+        A2, W2 = rnd(M, K2, seed=23), rnd(N, K2, seed=24, scale=0.1)
+        A2[:, 8:] = 0
+        acc = acc + as_dt(A2, dt) @ as_dt(W2, dt).t()
+    c = lambda t: None if t is None else t.cuda().to(dt)
+    bias = rnd(N, seed=25)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(c(A1), c(W1), out, A2=c(A2), W2=c(W2), alpha=0.5, bias=bias.cuda())
+    assert relerr(out.float().cpu(), 0.5 * acc + bias) < 1.5e-2
+    out2 = torch.empty(M, N, device="cuda", dtype=dt)
+    p, seed, site = 0.1, 1234, 13
+    ops.gemm_nt(c(A1), c(W1), out, epilogue=L.EPI_BIAS_GELU, A2=c(A2), W2=c(W2), bias=bias.cuda(), out2=out2, p_drop=p, seed=seed, site=site)
+    keep = ops.dropout_mask(M * N, p, seed, site, "cuda").cpu().reshape(M, N).float()
+    a = (acc + bias).requires_grad_(True)
+    g = F.gelu(a)
+    gp, = torch.autograd.grad(g.sum(), a)
+    ref_h, ref_g = g.detach() * keep / (1 - p), gp * keep / (1 - p)
+    hh, gg = out.float().cpu(), out2.float().cpu()
+    assert (hh[keep == 0] == 0).all() and (gg[keep == 0] == 0).all()
+    assert ((hh - ref_h).abs() - 2.0 ** -8 * ref_h.abs()).max() < 2e-3
+    assert ((gg - ref_g).abs() - 2.0 ** -8 * ref_g.abs()).max() < 2e-3
