@@ -64,13 +64,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const int64_t* __restrict__ label, float* __restrict__ emb,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                        float* __restrict__ logits, int D, int C, float cs, float cm,
-                                                       const float* __restrict__ hbias, int linear) {
+                                                       const float* __restrict__ hbias, int linear, int pool_mean) {
   __shared__ float e[HEAD_MAXD];
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (size_t)b * T * D;
   float s = 0.f;
-  for (int d = tid; d < D; d += 256) { e[d] = xr[d]; s += e[d]; }
+  for (int d = tid; d < D; d += 256) {
+    float pv = xr[d];                               // pool = 'cls': token 0 (vit_face.py:540)
+    if (pool_mean) {                                // pool = 'mean': x.mean(dim=1) over all T tokens, summed in token order
+      for (int t = 1; t < T; ++t) pv += xr[(size_t)t * D + d];
+      pv = pv / (float)T;
+    }
+    e[d] = pv; s += pv;
+  }
   const float mu = block_sum(s, sm) / D;
   float q = 0.f;
   for (int d = tid; d < D; d += 256) { const float c = e[d] - mu; q += c * c; }
@@ -116,12 +123,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 extern "C" int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps, const float* Wn,
                             const int64_t* label, float* emb, float* mean, float* rstd, float* logits, int B, int D, int C,
-                            float cos_s, float cos_m, const float* head_bias, int linear_head, gsl_stream_t s) {
+                            float cos_s, float cos_m, const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
   GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
   hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, as_stream(s), x, T, gamma, beta, eps, Wn, label, emb, mean, rstd,
-                     logits, D, C, cos_s, cos_m, head_bias, linear_head);
+                     logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
   return check_launch("gsl_head_fwd");
 }
 
@@ -131,14 +138,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ emb, const float* __restrict__ Wn,
                                                        float* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
-                                                       DropCfg drop, int linear) {
+                                                       DropCfg drop, int linear, int pool_mean) {
   resolve_drop(drop);
   __shared__ float de[HEAD_MAXD];   // d emb
   __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
+  __shared__ float xp[HEAD_MAXD];   // pooled row (pool = 'mean')
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x;
-  // zero the non-cls token rows of this image (their stream gradient is exactly 0)
-  {
+  // pool = 'cls': zero the non-cls token rows of this image (their stream gradient is exactly 0)
+  if (!pool_mean) {
     float4* z = reinterpret_cast<float4*>(dx + ((size_t)b * Tn + 1) * D);
     const long n4 = (long)(Tn - 1) * D / 4;
     for (long i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -168,41 +176,58 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const float proj = block_sum(dotp, sm) / (nrm * nrm);   // (e-hat . d e-hat) / ||e||
   const float mu = mean[b], rs = rstd[b];
   const float* xr = x + (size_t)b * Tn * D;
+  for (int d = tid; d < D; d += 256) {          // the pooled row the forward normalised (same summation order)
+    float pv = xr[d];
+    if (pool_mean) {
+      for (int t = 1; t < Tn; ++t) pv += xr[(size_t)t * D + d];
+      pv = pv / (float)Tn;
+    }
+    xp[d] = pv;
+  }
   float s1 = 0.f, s2 = 0.f;
   for (int d = tid; d < D; d += 256) {
     float g = linear ? de[d] : (de[d] - er[d] * proj) / nrm;   // d emb from the Linear / CosFace head
     if (demb_in) g += demb_in[(size_t)b * D + d];
     g *= gamma[d];
     de[d] = g;
-    const float xh = (xr[d] - mu) * rs;
+    const float xh = (xp[d] - mu) * rs;
     s1 += g;
     s2 += g * xh;
   }
   const float c1 = block_sum(s1, sm) / D;
   const float c2 = block_sum(s2, sm) / D;
   for (int d = tid; d < D; d += 256) {
-    const float xh = (xr[d] - mu) * rs;
+    const float xh = (xp[d] - mu) * rs;
     const float g = rs * (de[d] - c1 - xh * c2);
-    const size_t o = (size_t)b * Tn * D + d;
-    dx[o] = g;
-    if (dxb) Elem<T>::st(dxb + o, g * drop_mul(drop, (uint64_t)o));
+    if (!pool_mean) {
+      const size_t o = (size_t)b * Tn * D + d;
+      dx[o] = g;
+      if (dxb) Elem<T>::st(dxb + o, g * drop_mul(drop, (uint64_t)o));
+    } else {                                     // every token receives d pooled / T
+      const float gt = g / (float)Tn;
+      for (int t = 0; t < Tn; ++t) {
+        const size_t o = ((size_t)b * Tn + t) * D + d;
+        dx[o] = gt;
+        if (dxb) Elem<T>::st(dxb + o, gt * drop_mul(drop, (uint64_t)o));
+      }
+    }
   }
 }
 
 extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
                             const float* mean, const float* rstd, const float* emb, const float* Wn, float* dx, void* dxb,
                             int B, int D, int C, float cos_s, int dtype, float p_drop, uint64_t seed, uint32_t site,
-                            int linear_head, gsl_stream_t s) {
+                            int linear_head, int pool_mean, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T > 1, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
   GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
   const DropCfg drop = make_drop(p_drop, seed, site);
   if (dtype == GSL_BF16)
     hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head);
+                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (float*)dxb, D, C, cos_s, drop, linear_head);
+                       Wn, dx, (float*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
   else return fail(GSL_ERR_ARG, "gsl_head_bwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_head_bwd");
 }

@@ -37,8 +37,8 @@ SIGNATURES = {
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
-    "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _vp],
-    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _u64, _u32, _i, _vp],
+    "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _u64, _u32, _i, _i, _vp],
     "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -222,7 +222,7 @@ def cosface_prep(W):
     return Wn
 
 
-def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=None, linear=False):
+def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=None, linear=False, pool_mean=False):
     _need(x, gamma, beta, Wn, label, head_bias)
     dev = x.device
     emb = torch.empty(B, D, device=dev, dtype=torch.float32)
@@ -231,19 +231,20 @@ def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=No
     C = Wn.shape[0] if Wn is not None else 0
     logits = torch.empty(B, C, device=dev, dtype=torch.float32) if (label is not None or linear) else None
     L.check(L.load().gsl_head_fwd(_p(x), T, _p(gamma), _p(beta), float(eps), _p(Wn), _p(label), _p(emb), _p(mean), _p(rstd),
-                                  _p(logits), B, D, C, float(cos_s), float(cos_m), _p(head_bias), 1 if linear else 0, _stream()),
-            "gsl_head_fwd")
+                                  _p(logits), B, D, C, float(cos_s), float(cos_m), _p(head_bias), 1 if linear else 0,
+                                  1 if pool_mean else 0, _stream()), "gsl_head_fwd")
     return logits, emb, mean, rstd
 
 
-def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False):
+def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False,
+             pool_mean=False):
     _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn)
     dx = torch.empty(B * T, D, device=x.device, dtype=torch.float32)
     dxb = torch.empty(B * T, D, device=x.device, dtype=dtype)
     C = Wn.shape[0] if Wn is not None else 0
     L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
                                   _p(dxb), B, D, C, float(cos_s), code(dtype), float(p_drop), int(seed), int(site), 1 if linear else 0,
-                                  _stream()), "gsl_head_bwd")
+                                  1 if pool_mean else 0, _stream()), "gsl_head_bwd")
     return dx, dxb
 
 

@@ -44,10 +44,11 @@ class ModelSpec:
                     LN eps 1e-6, scale head_dim^-0.5, nn.Linear head with bias, the label argument is ignored."""
     __slots__ = ("patch_size", "num_tokens", "dim", "heads", "attn_scale", "ln_eps", "dropout_p", "emb_dropout_p", "lora_rank",
                  "patch_w", "patch_is_conv", "patch_b", "cls", "pos", "blocks", "final_ln", "head_kind", "head_w", "head_b",
-                 "cos_s", "cos_m", "lora_site")
+                 "cos_s", "cos_m", "lora_site", "pool")
 
     def __init__(self, **kw):
         kw.setdefault("lora_site", "ffn")      # "ffn" (GS-LoRA) or "attention" (--lora_pos Attention ablation)
+        kw.setdefault("pool", "cls")           # "cls" (token 0) or "mean" (mean over the tokens, vit_face.py:540)
         for k in self.__slots__:
             setattr(self, k, kw[k])
 
@@ -381,7 +382,7 @@ class ViTRunner:
         else:
             Wn = ops.cosface_prep(sp.head_w.detach().contiguous()) if label is not None else None
             logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, label,
-                                                     sp.cos_s, sp.cos_m)
+                                                     sp.cos_s, sp.cos_m, pool_mean=(sp.pool == "mean"))
         saved = None
         if save:
             saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, sflag=sflag, p_drop=p_drop,
@@ -414,7 +415,7 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
-                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head)
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"))
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -429,7 +430,7 @@ class ViTRunner:
             # The network pools x[:, 0] (vit_face.py:540): the stream gradient entering the LAST block is exactly zero
             # outside the B cls rows, so its FFN backward, LoRA-gradient reductions, LN2 backward, out-proj dX and the
             # attention backward (a rank-1 cls-query form) run on B rows instead of B*T. Exact, not an approximation.
-            sparse = (i == nl - 1)
+            sparse = (i == nl - 1) and sp.pool == "cls"      # (with pool='mean' every token carries gradient: dense last block)
             if sparse:
                 dyb, xn2, h, gp, u1, u2 = (cls_rows(dxb, D), cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), cls_rows(st["gp"], mlp),
                                            cls_rows(st["u1"], PADK), cls_rows(st["u2"], PADK))
@@ -524,7 +525,7 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
-                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head)
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"))
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
@@ -535,7 +536,7 @@ class ViTRunner:
             if st["uq"] is None:
                 raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
             mlp = l1.weight.shape[0]
-            sparse = (i == nl - 1)      # only the cls rows of the last block carry gradient (see the FFN-site path)
+            sparse = (i == nl - 1) and sp.pool == "cls"      # only the cls rows of the last block carry gradient (see the FFN-site path)
             if sparse:
                 dyb, gp = cls_rows(dxb, D), cls_rows(st["gp"], mlp)
             else:

@@ -61,11 +61,21 @@ def calculate_prototypes(backbone, dataset, batch_size=32, device="cuda", aug_nu
     """Per-class mean embedding in eval (merged-LoRA) mode; leaves the model in eval() like the
     reference does. Class sums are accumulated on the device (one index_add per batch) instead of a
     per-sample Python loop; the result dict holds CPU tensors as before."""
-    if aug_num != 0:
-        raise NotImplementedError("RandAugment prototype augmentation (aug_num>0) is data plumbing outside the hot path")
-    from torch.utils.data import DataLoader
+    from torch.utils.data import ConcatDataset, DataLoader
     backbone.eval()
     backbone.to(device)
+    if aug_num != 0:
+        # GS-LoRA++ prototype augmentation (reference :506-523): the data set's transform is REPLACED by RandAugment(num_ops=2,
+        # magnitude=aug_num) + ToTensor and the set is visited 20 times; the prototypes are the class means over all 20 passes.
+        # torchvision supplies the augmentation itself (host-side PIL work, outside the GPU hot path); without it there is nothing to run.
+        try:
+            import torchvision.transforms as transforms
+        except Exception as exc:      # pragma: no cover
+            raise RuntimeError("calculate_prototypes(aug_num > 0) needs torchvision.transforms (RandAugment), as in the reference") from exc
+        transform = transforms.Compose([transforms.RandAugment(num_ops=2, magnitude=aug_num), transforms.ToTensor()])
+        dataset.transform = transform
+        dataset = ConcatDataset([dataset] * 20)
+        dataset.transform = transform
     loader = DataLoader(dataset, batch_size=batch_size, shuffle=False)
     sums = counts = None
     with torch.no_grad():

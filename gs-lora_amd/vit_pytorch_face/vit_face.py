@@ -168,8 +168,6 @@ class ViT_face(HipModelMixin, nn.Module):
             f"your number of patches ({num_patches}) is way too small for attention to be effective (at least 16). "
             "Try decreasing your patch size")
         assert pool in {"cls", "mean"}, "pool type must be either cls (cls token) or mean (mean pooling)"
-        if pool != "cls":
-            raise NotImplementedError("gs-lora_amd implements pool='cls' (every GS-LoRA configuration uses it)")
         if patch_dim % 64 or dim % 64 or mlp_dim % 64:
             raise NotImplementedError("gs-lora_amd GEMM tiles need patch_dim, dim and mlp_dim to be multiples of 64")
         self.patch_size = patch_size
@@ -222,7 +220,7 @@ class ViT_face(HipModelMixin, nn.Module):
                          patch_b=self.patch_to_embedding.bias, cls=self.cls_token, pos=self.pos_embedding, blocks=blocks,
                          final_ln=self.mlp_head[0], head_kind="cosface", head_w=self.loss.weight if has_loss else None,
                          head_b=None, cos_s=self.loss.s if has_loss else 64.0, cos_m=self.loss.m if has_loss else 0.35,
-                         lora_site="attention" if self.lora_pos == "Attention" else "ffn")
+                         lora_site="attention" if self.lora_pos == "Attention" else "ffn", pool=self.pool)
 
     # ---- reference API ---------------------------------------------------------------------------
     def forward(self, img, label=None, mask=None):

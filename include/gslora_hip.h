@@ -135,13 +135,14 @@ int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s);  
 int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps,
                  const float* Wn, const int64_t* label, float* emb, float* mean, float* rstd,
                  float* logits, int B, int D, int C, float cos_s, float cos_m,
-                 const float* head_bias, int linear_head, gsl_stream_t s);
-/* dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: cls rows get the gradient, others zero.
- * dxb[dtype] = dx * dropmask(site) (nullable). */
+                 const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s);
+/* pool_mean = 0: the head pools token 0 (pool='cls'); 1: the mean over the T tokens (pool='mean', vit_face.py:540).
+ * dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: with pool='cls' the cls rows get the gradient and the others are zeroed,
+ * with pool='mean' every token row gets d pooled / T. dxb[dtype] = dx * dropmask(site) (nullable). */
 int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
                  float* dx, void* dxb, int B, int D, int C, float cos_s, int dtype,
-                 float p_drop, uint64_t seed, uint32_t site, int linear_head, gsl_stream_t s);
+                 float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
  * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */

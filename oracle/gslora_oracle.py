@@ -101,7 +101,7 @@ def vit_forward(st, img, label, cfg, merged=False, dropout_masks=None, dropout_p
         y = lora_linear(h, st[f"{f}.fn.net.3.weight"], st[f"{f}.fn.net.3.bias"],
                         st.get(f"{f}.fn.net.3.lora_A"), st.get(f"{f}.fn.net.3.lora_B"), rf, merged)
         x = dp(y) + x
-    x = x[:, 0]  # pool='cls' (vit_face.py:540)
+    x = x.mean(dim=1) if cfg.get("pool", "cls") == "mean" else x[:, 0]      # vit_face.py:540
     emb = F.layer_norm(x, (d,), st["mlp_head.0.weight"], st["mlp_head.0.bias"], LN_EPS)
     if label is None:
         return None, emb

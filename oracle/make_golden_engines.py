@@ -268,6 +268,61 @@ def gen_chain(out):
           float(np.abs(res["logits_after_reload_reinit"] - res["task0::eval_logits"]).max()))
 
 
+def gen_poolmean(out):
+    """ViT_face(pool='mean') (vit_face.py:540): forward, eval forward and the LoRA gradients of the three-term loss on the 3-layer model."""
+    import engine as eng
+    import engine_cl
+    from vit_pytorch_face import ViT_face
+    import loralib as lora
+    cfg = recipe.cfg_small2()
+    model = ViT_face(loss_type="CosFace", GPU_ID=[0], num_class=cfg["num_class"], image_size=cfg["image_size"], patch_size=cfg["patch_size"],
+                     dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"], mlp_dim=cfg["mlp_dim"], lora_rank=cfg["lora_rank"], pool="mean")
+    model.load_state_dict({k: torch.tensor(v) for k, v in recipe.make_state(cfg).items()}, strict=True)
+    lora.mark_only_lora_as_trainable(model)
+    model.train()
+    rem, forg = S.loaders(cfg, 1, 1, 3, seed=5)
+    (xr, yr), (xf, yf) = rem.batches[0], forg.batches[0]
+    proto = S.prototypes(cfg)
+    H = S.SINGLE_HYPER
+    crit = torch.nn.CrossEntropyLoss()
+    lo_r, em_r = model(xr, yr)
+    lo_f, em_f = model(xf, yf)
+    sl = eng.get_structure_loss(model, num_layers=cfg["depth"], group_type="block", group_pos="FFN")
+    kl_f = engine_cl.get_prototype_loss(em_f, yf, proto)
+    kl_r = engine_cl.get_prototype_loss(em_r, yr, proto)
+    total = (H["beta"] * torch.relu(H["BND"] - crit(lo_f, yf)) + crit(lo_r, yr) + H["alpha"] * sl
+             + H["pro_f_weight"] * torch.relu(2.0 - kl_f) + H["pro_r_weight"] * kl_r)
+    model.zero_grad()
+    total.backward()
+    res = {"logits_r": lo_r.detach().numpy(), "emb_r": em_r.detach().numpy(), "total": np.float64(total.item())}
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            res[f"grad::{n}"] = p.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        res["eval_logits_f"] = model(xf, yf)[0].numpy()
+    np.savez_compressed(os.path.join(out, "pool_mean_small2.npz"), **res)
+    print("[golden] pool_mean_small2: total", res["total"])
+
+
+def gen_protoaug(out):
+    """calculate_prototypes(aug_num = 3) of the reference (util/utils.py:502-549) with the deterministic transforms stand-in."""
+    from unittest import mock
+    from util import utils as rutil
+    cfg = recipe.cfg_small2()
+    model = build_reference_model(cfg, recipe.make_state(cfg))
+    x = torch.tensor(recipe.make_images(cfg, 7, seed=77, tag="xp"))
+    y = torch.tensor(recipe.make_labels(cfg, 7, seed=77, tag="yp", lo=0, hi=4))
+    ds = S.TransformDataset(x, y)
+    with mock.patch.object(rutil, "transforms", S.StubTransforms), mock.patch.object(rutil, "DataLoader", torch.utils.data.DataLoader), \
+            mock.patch.object(rutil, "ConcatDataset", torch.utils.data.ConcatDataset):
+        protos = rutil.calculate_prototypes(model, ds, batch_size=5, device="cpu", aug_num=3)
+    keys = sorted(protos)
+    np.savez_compressed(os.path.join(out, "proto_aug_small2.npz"), keys=np.array(keys, dtype=np.int64),
+                        vals=np.stack([protos[k].numpy() for k in keys]).astype(np.float32))
+    print("[golden] proto_aug_small2:", keys)
+
+
 def main():
     install_shims()
     torch.manual_seed(0)
@@ -280,6 +335,10 @@ def main():
         gen_chain(out)
     if not only or "traj" in only:
         gen_traj(out)
+    if not only or "poolmean" in only:
+        gen_poolmean(out)
+    if not only or "protoaug" in only:
+        gen_protoaug(out)
 
 
 if __name__ == "__main__":

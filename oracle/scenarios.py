@@ -149,3 +149,43 @@ def chain_lora_A(cfg, task):
 # reference order of the 8 AverageMeter.update calls of one step (engine_cl.py:68-117 == engine.py:66-133)
 REF_UPDATE_ORDER = ("losses_remain", "top1_remain", "losses_forget", "top1_forget", "losses_structure", "losses_prototype_forget",
                     "losses_prototype_remain", "losses_total")
+
+
+# ---- prototype augmentation plumbing (util/utils.py:502-549 with aug_num > 0): torchvision is absent in both containers, so BOTH flows
+# run with this deterministic stand-in for `torchvision.transforms` (the augmentation itself is torchvision's; what is pinned is the
+# reference's plumbing: the data set's transform is replaced, the set is visited 20 times, class means over all passes)
+class StubTransforms:
+    class RandAugment:
+        def __init__(self, num_ops=2, magnitude=9):
+            self.num_ops, self.magnitude, self.calls = num_ops, magnitude, 0
+
+        def __call__(self, img):
+            self.calls += 1
+            return img * (1.0 - 0.002 * self.magnitude * (self.calls % 7)) + 0.001 * self.num_ops * (self.calls % 3)
+
+    class ToTensor:
+        def __call__(self, img):
+            return img
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, img):
+            for t in self.ts:
+                img = t(img)
+            return img
+
+
+class TransformDataset(torch.utils.data.Dataset):
+    """ImageFolder-like: applies self.transform (if any) in __getitem__."""
+
+    def __init__(self, images, labels):
+        self.images, self.labels, self.transform = images, labels, None
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def __getitem__(self, i):
+        x = self.images[i]
+        return (self.transform(x) if self.transform is not None else x), int(self.labels[i])

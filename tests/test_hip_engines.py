@@ -349,3 +349,75 @@ def test_two_task_chain_f32_matches_reference(golden_dir):
             model.train()
     finally:
         shutil.rmtree(work)
+
+
+def test_pool_mean_f32_matches_reference(golden_dir):
+    """ViT_face(pool='mean') (reference vit_face.py:540; no GS-LoRA script uses it, the constructor contract lists it): forward, eval
+    forward and the LoRA gradients of the three-term loss against the golden of the real reference; the last block runs DENSE (every
+    token carries gradient), unlike pool='cls'."""
+    import engine as eng
+    import engine_cl
+    import loralib as lora
+    from vit_pytorch_face import ViT_face
+    g = np.load(os.path.join(golden_dir, "pool_mean_small2.npz"))
+    cfg = recipe.cfg_small2()
+    H = S.SINGLE_HYPER
+    for dtype, tol_l, tol_g in (("fp32", 1e-4, 1e-4), ("bf16", 0.25, None)):
+        m = ViT_face(loss_type="CosFace", GPU_ID=[0], num_class=cfg["num_class"], image_size=cfg["image_size"], patch_size=cfg["patch_size"],
+                     dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"], mlp_dim=cfg["mlp_dim"], lora_rank=cfg["lora_rank"], pool="mean")
+        m.load_state_dict({k: torch.tensor(v) for k, v in recipe.make_state(cfg).items()}, strict=True)
+        lora.mark_only_lora_as_trainable(m)
+        m = m.cuda().set_compute_dtype(dtype).train()
+        rem, forg = S.loaders(cfg, 1, 1, 3, seed=5)
+        (xr, yr), (xf, yf) = [(x.cuda(), y.cuda()) for x, y in (rem.batches[0], forg.batches[0])]
+        proto = S.prototypes(cfg)
+        crit = torch.nn.CrossEntropyLoss()
+        lo_r, em_r = m(xr, yr)
+        lo_f, em_f = m(xf, yf)
+        sl = eng.get_structure_loss(m, num_layers=cfg["depth"], group_type="block", group_pos="FFN")
+        kl_f = engine_cl.get_prototype_loss(em_f, yf, proto)
+        kl_r = engine_cl.get_prototype_loss(em_r, yr, proto)
+        total = (H["beta"] * torch.relu(H["BND"] - crit(lo_f, yf)) + crit(lo_r, yr) + H["alpha"] * sl
+                 + H["pro_f_weight"] * torch.relu(2.0 - kl_f) + H["pro_r_weight"] * kl_r)
+        m.zero_grad()
+        total.backward()
+        assert np.abs(lo_r.detach().cpu().numpy() - g["logits_r"]).max() < tol_l
+        assert np.abs(em_r.detach().cpu().numpy() - g["emb_r"]).max() < (1e-4 if dtype == "fp32" else 0.05)
+        if tol_g is not None:
+            assert abs(total.item() - float(g["total"])) < 1e-4 * max(1.0, abs(float(g["total"])))
+            for n, p in m.named_parameters():
+                if p.requires_grad:
+                    r = g[f"grad::{n}"]
+                    assert np.abs(p.grad.cpu().numpy() - r).max() < tol_g * max(1.0, np.abs(r).max()), n
+        else:
+            for n, p in m.named_parameters():
+                if p.requires_grad:
+                    r, a = g[f"grad::{n}"].ravel(), p.grad.cpu().numpy().ravel()
+                    if np.linalg.norm(r) > 0:
+                        assert np.linalg.norm(a - r) / np.linalg.norm(r) < 0.06, n
+        m.eval()
+        with torch.no_grad():
+            le = m(xf, yf)[0].cpu().numpy()
+        assert np.abs(le - g["eval_logits_f"]).max() < tol_l
+
+
+def test_calculate_prototypes_with_augmentation_matches_reference(golden_dir, monkeypatch):
+    """GS-LoRA++ prototype augmentation (aug_num > 0, reference util/utils.py:506-523): transform replaced, 20 passes, class means.
+    torchvision exists in neither container, so both flows run with the same deterministic transforms stand-in (oracle/scenarios.py)."""
+    import sys
+    import types
+    from util.utils import calculate_prototypes
+    tv = types.ModuleType("torchvision")
+    tv.transforms = S.StubTransforms
+    monkeypatch.setitem(sys.modules, "torchvision", tv)
+    monkeypatch.setitem(sys.modules, "torchvision.transforms", S.StubTransforms)
+    g = np.load(os.path.join(golden_dir, "proto_aug_small2.npz"))
+    cfg = recipe.cfg_small2()
+    model = build_model(cfg, "fp32", recipe.make_state(cfg))
+    x = torch.tensor(recipe.make_images(cfg, 7, seed=77, tag="xp"))
+    y = torch.tensor(recipe.make_labels(cfg, 7, seed=77, tag="yp", lo=0, hi=4))
+    protos = calculate_prototypes(model, S.TransformDataset(x, y), batch_size=5, device="cuda", aug_num=3)
+    assert sorted(protos) == g["keys"].tolist()
+    for k, v in zip(g["keys"].tolist(), g["vals"]):
+        assert np.abs(protos[k].numpy() - v).max() < 1e-4, k
+    assert not model.training            # the reference leaves the model in eval()
