@@ -132,12 +132,12 @@ extern "C" int gsl_head_fwd(const float* x, int T, const float* gamma, const flo
   return check_launch("gsl_head_fwd");
 }
 
-template <typename T>
+template <typename T, typename S>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ demb_in,
                                                        const float* __restrict__ x, int Tn, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ emb, const float* __restrict__ Wn,
-                                                       float* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
+                                                       S* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
                                                        DropCfg drop, int linear, int pool_mean) {
   resolve_drop(drop);
   __shared__ float de[HEAD_MAXD];   // d emb
@@ -147,9 +147,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const int b = blockIdx.x, tid = threadIdx.x;
   // pool = 'cls': zero the non-cls token rows of this image (their stream gradient is exactly 0)
   if (!pool_mean) {
-    float4* z = reinterpret_cast<float4*>(dx + ((size_t)b * Tn + 1) * D);
     const long n4 = (long)(Tn - 1) * D / 4;
-    for (long i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      S* z = dx + ((size_t)b * Tn + 1) * D;
+      const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (long i = tid; i < n4; i += 256) Elem<S>::st4(z + i * 4, zero4);
+    }
     if (dxb) {
       T* zb = dxb + ((size_t)b * Tn + 1) * D;
       const float zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -201,13 +204,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const float g = rs * (de[d] - c1 - xh * c2);
     if (!pool_mean) {
       const size_t o = (size_t)b * Tn * D + d;
-      dx[o] = g;
+      Elem<S>::st(dx + o, g);
       if (dxb) Elem<T>::st(dxb + o, g * drop_mul(drop, (uint64_t)o));
     } else {                                     // every token receives d pooled / T
       const float gt = g / (float)Tn;
       for (int t = 0; t < Tn; ++t) {
         const size_t o = ((size_t)b * Tn + t) * D + d;
-        dx[o] = gt;
+        Elem<S>::st(dx + o, gt);
         if (dxb) Elem<T>::st(dxb + o, gt * drop_mul(drop, (uint64_t)o));
       }
     }
@@ -215,19 +218,23 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
-                            const float* mean, const float* rstd, const float* emb, const float* Wn, float* dx, void* dxb,
-                            int B, int D, int C, float cos_s, int dtype, float p_drop, uint64_t seed, uint32_t site,
+                            const float* mean, const float* rstd, const float* emb, const float* Wn, void* dx, void* dxb,
+                            int B, int D, int C, float cos_s, int dtype, int stream_dtype, float p_drop, uint64_t seed, uint32_t site,
                             int linear_head, int pool_mean, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T > 1, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
   GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
   const DropCfg drop = make_drop(p_drop, seed, site);
-  if (dtype == GSL_BF16)
-    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
+  GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
+  if (dtype == GSL_BF16 && stream_dtype == GSL_BF16)
+    hipLaunchKernelGGL((head_bwd_kernel<bf16_t, bf16_t>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
+                       Wn, (bf16_t*)dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
+  else if (dtype == GSL_BF16)
+    hipLaunchKernelGGL((head_bwd_kernel<bf16_t, float>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
+                       Wn, (float*)dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
   else if (dtype == GSL_F32)
-    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, dx, (float*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
+    hipLaunchKernelGGL((head_bwd_kernel<float, float>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
+                       Wn, (float*)dx, (float*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
   else return fail(GSL_ERR_ARG, "gsl_head_bwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_head_bwd");
 }

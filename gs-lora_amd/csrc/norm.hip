@@ -63,11 +63,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <int NPL, typename T>
+// S: element type of the residual-GRADIENT stream (dres in, dx out): f32, or bf16 in speed mode (the stream is re-read and re-written by
+// every LayerNorm backward of the chain: 2 x 413 MB per call at M = 201 728 in f32)
+template <int NPL, typename T, typename S>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, long xs,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* dres,
-                                                     float* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
+                                                     const float* __restrict__ rstd, const S* dres,
+                                                     S* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
                                                      long drop_row_stride) {
   resolve_drop(drop);
   constexpr int D = NPL * 64;
@@ -131,14 +133,18 @@ static int ln_fwd_launch(const float* x, long xs, const float* gamma, const floa
 
 template <int NPL>
 static int ln_bwd_launch(const void* dy, const float* x, long xs, const float* gamma, const float* mean, const float* rstd,
-                         const float* dres, float* dx, long ios, void* dxb, int M, int dtype, DropCfg drop, long drs, hipStream_t st) {
+                         const void* dres, void* dx, long ios, void* dxb, int M, int dtype, int sdtype, DropCfg drop, long drs,
+                         hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
-  if (dtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
-                       dres, dx, ios, (bf16_t*)dxb, M, drop, drs);
+  if (dtype == GSL_BF16 && sdtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
+                       (const bf16_t*)dres, (bf16_t*)dx, ios, (bf16_t*)dxb, M, drop, drs);
+  else if (dtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
+                       (const float*)dres, (float*)dx, ios, (bf16_t*)dxb, M, drop, drs);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, float>), dim3(grid), dim3(256), 0, st, (const float*)dy, x, xs, gamma, mean, rstd,
-                       dres, dx, ios, (float*)dxb, M, drop, drs);
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, float, float>), dim3(grid), dim3(256), 0, st, (const float*)dy, x, xs, gamma, mean, rstd,
+                       (const float*)dres, (float*)dx, ios, (float*)dxb, M, drop, drs);
   return check_launch("gsl_layernorm_bwd");
 }
 
@@ -164,15 +170,17 @@ extern "C" int gsl_layernorm_fwd(const float* x, long x_row_stride, const float*
 }
 
 extern "C" int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma, const float* mean,
-                                 const float* rstd, const float* dres, float* dx, long io_row_stride, void* dxb, int M, int D,
-                                 int dtype, float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s) {
+                                 const float* rstd, const void* dres, void* dx, long io_row_stride, void* dxb, int M, int D,
+                                 int dtype, int stream_dtype, float p_drop, uint64_t seed, uint32_t site, long drop_row_stride,
+                                 gsl_stream_t s) {
   GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
   const DropCfg drop = make_drop(p_drop, seed, site);
   const long ios = io_row_stride > 0 ? io_row_stride : D, drs = drop_row_stride > 0 ? drop_row_stride : D;
   GSL_CHECK_ARG((ios % 4) == 0, "io row stride alignment");
-#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, drop, drs, as_stream(s))
+#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, drop, drs, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
 }

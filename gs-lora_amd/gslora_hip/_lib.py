@@ -30,7 +30,7 @@ SIGNATURES = {
     "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
                                  _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _f, _u64, _u32, _l, _vp],
+    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _u64, _u32, _l, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
@@ -38,7 +38,7 @@ SIGNATURES = {
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
     "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
-    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _u64, _u32, _i, _i, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _vp],
     "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -131,15 +131,19 @@ def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
 
 def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
                   io_row_stride=0, drop_row_stride=0):
-    """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place."""
+    """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the
+    residual-gradient stream (dres / dx: f32, or bf16 in bf16 mode) is taken from dres / dx."""
     _need(dy, x, gamma, mean, rstd)
     M, D = dy.shape
+    sdt = dx.dtype if dx is not None else (dres.dtype if dres is not None else torch.float32)
     if dx is None:
         _need(dres)
-        dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+        dx = torch.empty(M, D, device=dy.device, dtype=sdt)
+    elif dres is not None and dres.dtype != dx.dtype:
+        raise RuntimeError("layernorm_bwd: dres and dx must share one dtype")
     dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if want_copy else None
     L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-                                       int(io_row_stride), _p(dxb), M, D, code(dy.dtype), float(p_drop), int(seed), int(site),
+                                       int(io_row_stride), _p(dxb), M, D, code(dy.dtype), code(sdt), float(p_drop), int(seed), int(site),
                                        int(drop_row_stride), _stream()), "gsl_layernorm_bwd")
     return dx, dxb
 
@@ -237,14 +241,14 @@ def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=No
 
 
 def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False,
-             pool_mean=False):
+             pool_mean=False, stream_dtype=torch.float32):
     _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn)
-    dx = torch.empty(B * T, D, device=x.device, dtype=torch.float32)
+    dx = torch.empty(B * T, D, device=x.device, dtype=stream_dtype)
     dxb = torch.empty(B * T, D, device=x.device, dtype=dtype)
     C = Wn.shape[0] if Wn is not None else 0
     L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
-                                  _p(dxb), B, D, C, float(cos_s), code(dtype), float(p_drop), int(seed), int(site), 1 if linear else 0,
-                                  1 if pool_mean else 0, _stream()), "gsl_head_bwd")
+                                  _p(dxb), B, D, C, float(cos_s), code(dtype), code(stream_dtype), float(p_drop), int(seed), int(site),
+                                  1 if linear else 0, 1 if pool_mean else 0, _stream()), "gsl_head_bwd")
     return dx, dxb
 
 

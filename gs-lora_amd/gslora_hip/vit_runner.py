@@ -19,6 +19,9 @@ PADK = 64                                  # LoRA K-segment width fed to the GEM
 SITE_EMB = 1_000_000
 # development knob: 0 = the two [M, mlp] LoRA-gradient reductions run as separate gsl_lora_grad launches instead of inside the FFN2-dX epilogue
 FUSE_LORA_GRAD = os.environ.get("GSL_FUSE_LORA_GRAD", "1") != "0"
+# bf16 speed mode carries the residual-GRADIENT stream (the f32 [M, dim] tensor every LayerNorm backward re-reads and re-writes) in bf16:
+# -25 % of the bytes of each LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32 (the parity mode always does).
+GRAD_STREAM_BF16 = os.environ.get("GSLORA_GRAD_STREAM", "bf16").lower() != "f32"
 
 
 class BlockSpec:
@@ -415,7 +418,8 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
-                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"))
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
+                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32)
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -525,7 +529,8 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
-                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"))
+                               site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
+                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32)
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()

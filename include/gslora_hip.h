@@ -99,13 +99,15 @@ int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int
  * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
 int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                       void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s);
-/* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D] (dense).
+/* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D] (dense). dres / dx — the residual-GRADIENT
+ * stream — are `stream_dtype`: f32, or bf16 when dtype is bf16 (speed mode: the stream is re-read and re-written by every LayerNorm
+ * backward of the chain).
  * dres/dx rows are io_row_stride elements apart (0 -> D; dres may alias dx: in-place update of strided rows,
  * used for the cls-row-only backward of the last block); the dropout counter of element (row, d) is
  * row*drop_row_stride + d (0 -> D). dxb is always dense [M,D]. */
 int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma,
-                      const float* mean, const float* rstd, const float* dres,
-                      float* dx, long io_row_stride, void* dxb, int M, int D, int dtype,
+                      const float* mean, const float* rstd, const void* dres,
+                      void* dx, long io_row_stride, void* dxb, int M, int D, int dtype, int stream_dtype,
                       float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s);
 
 /* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
@@ -138,10 +140,11 @@ int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, f
                  const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s);
 /* pool_mean = 0: the head pools token 0 (pool='cls'); 1: the mean over the T tokens (pool='mean', vit_face.py:540).
  * dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: with pool='cls' the cls rows get the gradient and the others are zeroed,
- * with pool='mean' every token row gets d pooled / T. dxb[dtype] = dx * dropmask(site) (nullable). */
+ * with pool='mean' every token row gets d pooled / T. dxb[dtype] = dx * dropmask(site) (nullable). dx is `stream_dtype` (see
+ * gsl_layernorm_bwd). */
 int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
-                 float* dx, void* dxb, int B, int D, int C, float cos_s, int dtype,
+                 void* dx, void* dxb, int B, int D, int C, float cos_s, int dtype, int stream_dtype,
                  float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
