@@ -47,6 +47,7 @@ struct EpiArgs {
   const bf16_t* gy2;              // Y2 [M, N] (row stride ldo): G2[n, j] = sum_m Y2[m, n] * t[m, j]
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
   int gR;                         // 8 or 16
+  unsigned long long* stamps;     // development (GSL_P8_STAMPS = device address of 256 x 4 u64): cycle stamps of every 64th workgroup of the 8-phase kernel
 };
 
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
@@ -428,45 +429,51 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
   f32x4_t b4 = f32x4_t{0.f, 0.f, 0.f, 0.f}, c4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (n < e.N) b4 = *reinterpret_cast<const f32x4_t*>(e.bias + n);
   if constexpr (EPI == GSL_EPI_PATCH) { if (n < e.N) c4 = *reinterpret_cast<const f32x4_t*>(e.cls + n); }
+  // 32 rows per round, 8 residual loads (8 KB per wave) each; the loads of round q + 1 are issued before round q is processed, so one
+  // memory latency is exposed per tile instead of one per round (the operand-fragment registers of the K loop are free by now)
+  constexpr int NQ = NI / 2;
+  auto fetch = [&](int q, f32x4_t (&rs)[8]) {
 #pragma unroll
-  for (int ib = 0; ib < NI; ib += 4) {
+    for (int r = 0; r < 8; ++r) {
+      const int m = min(mw + q * 32 + r * 4 + crow, e.M - 1);
+      if constexpr (EPI == GSL_EPI_PATCH) rs[r] = *reinterpret_cast<const f32x4_t*>(e.pos + (size_t)(m % e.T) * e.N + min(n, e.N - 4));
+      else rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
+    }
+  };
+  f32x4_t rsa[8], rsb[8];      // BIAS_RES_F32: the residual rows; PATCH: the position-embedding rows of the tokens (vit_face.py:531-537)
+  fetch(0, rsa);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {          // 32 rows at a time: 8 residual loads in flight per lane
-      f32x4_t rs[8];      // BIAS_RES_F32: the residual rows; PATCH: the position-embedding rows of the tokens (vit_face.py:531-537)
+  for (int q = 0; q < NQ; ++q) {
+    const int ib = (q >> 1) * 4, half = q & 1;
+    f32x4_t (&rs)[8] = (q & 1) ? rsb : rsa;
+    if (q + 1 < NQ) fetch(q + 1, (q & 1) ? rsa : rsb);
+    if (half == 0) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int m = min(mw + ib * 16 + half * 32 + r * 4 + crow, e.M - 1);
-        if constexpr (EPI == GSL_EPI_PATCH) rs[r] = *reinterpret_cast<const f32x4_t*>(e.pos + (size_t)(m % e.T) * e.N + min(n, e.N - 4));
-        else rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
-      }
-      if (half == 0) {
+      for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x4_t v = acc[ib + ii][j];
-            if (e.alpha != 1.0f) v *= e.alpha;
-            *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
-          }
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = half * 32 + r * 4 + crow;
-        const int m = mw + ib * 16 + row;
-        const f32x4_t c = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cq * 4);
-        float dm[4];
-        drop_mul4(e.drop, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, dm);
-        f32x4_t o;
-        if constexpr (EPI == GSL_EPI_PATCH) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout
-          const bool is_cls = (m % e.T) == 0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = ((is_cls ? c4[k] : c[k] + b4[k]) + rs[r][k]) * dm[k];
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
+        for (int j = 0; j < 4; ++j) {
+          f32x4_t v = acc[ib + ii][j];
+          if (e.alpha != 1.0f) v *= e.alpha;
+          *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
         }
-        if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = half * 32 + r * 4 + crow;
+      const int m = mw + ib * 16 + row;
+      const f32x4_t c = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cq * 4);
+      float dm[4];
+      drop_mul4(e.drop, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, dm);
+      f32x4_t o;
+      if constexpr (EPI == GSL_EPI_PATCH) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout
+        const bool is_cls = (m % e.T) == 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ((is_cls ? c4[k] : c[k] + b4[k]) + rs[r][k]) * dm[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
       }
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
     }
   }
 }
@@ -872,6 +879,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     for (int j = 0; j < 2; ++j) { const int row = wn * 32 + j * 16 + fr; boff[j][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
   }
 
+  // development: cycle stamps (kernel start, prologue landed, K loop done, epilogue done) of every 64th workgroup
+  unsigned long long* dbg8 = (e.stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0 && tid == 0) ? e.stamps + (blockIdx.x / 64) * 4 : nullptr;
+  if (dbg8) dbg8[0] = __builtin_readcyclecounter();
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
   stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
@@ -879,6 +889,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (dbg8) dbg8[1] = __builtin_readcyclecounter();
   if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
 
   bf16x8_t af[4][2], bf0[2][2], bf1[2][2], pf[2];
@@ -963,6 +974,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   }
 #undef GSL_P8_MFMA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
+  if (dbg8) dbg8[2] = __builtin_readcyclecounter();
   if constexpr (LORA && GRAD) {
     // same as below with t kept as [256][16] behind the staging regions (the K-loop stages end before it: no barrier needed first)
     bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
@@ -1041,6 +1053,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4 && (EPI != GSL_EPI_PATCH || e.ldo == e.N)) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
       epilogue_staged_res_f32<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+      if (dbg8) dbg8[3] = __builtin_readcyclecounter();
       return;
     }
   }
@@ -1050,10 +1063,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       if constexpr (EPI == GSL_EPI_MUL) {
         if (e.N >= 8) {
           epilogue_staged_mul<8>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+          if (dbg8) dbg8[3] = __builtin_readcyclecounter();
           return;
         }
       }
       epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
+      if (dbg8) dbg8[3] = __builtin_readcyclecounter();
       return;
     }
   }
@@ -1927,8 +1942,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       hipLaunchKernelGGL(gemm_bf16_k32x2_kernel<EPI>, dim3(((e.M + 255) / 256) * ((e.N + 127) / 128)), dim3(512), 0, st, (const bf16_t*)A1, lda1,
                          (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e9);
     } else if (variant == 8) {
+      const EpiArgs& e8 = e;
       hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e8);
     } else if (variant == 4) {
       GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
     } else if (variant == 3) {
@@ -1978,8 +1994,9 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
-  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
+  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -2014,8 +2031,9 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   e.alpha = 1.0f; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
-  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 1; }
+  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
@@ -2094,6 +2112,7 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   e.krot = 0;   // every N tile must accumulate t = s A P^T in the same K order: G2 contracts the tile-local t, which has to equal tout bit for bit
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   const int R = (r <= 8) ? 8 : 16;
   const int ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;
   const size_t NR = (size_t)N * R;

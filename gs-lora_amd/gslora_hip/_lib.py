@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgslora_hip.so")
+# GSLORA_HIP_LIB: development override (A/B of kernel build variants, tools/probes/); the default is the in-tree build
+LIB_PATH = os.environ.get("GSLORA_HIP_LIB") or os.path.join(_HERE, "libgslora_hip.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32 = 0, 1, 2, 3, 4, 5
