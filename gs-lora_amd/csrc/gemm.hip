@@ -1720,10 +1720,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restr
   const size_t step8 = (size_t)8 * (size_t)e.ldo;
 
   using IC0 = std::integral_constant<int, 0>;
-  // one step = one 32-deep K slice of the current tile (KON) + one output fragment of the previous tile (EON)
-  auto step = [&](auto pc, auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
+  // development (GSL_P8_STAMPS): workgroup 64 accumulates, per wave row, the cycles of the three parts of a step over all its steps:
+  // [0] the MFMA block, [1] everything else up to the waits in front of the barrier, [2] the barrier itself
+  const bool dbgon = e.stamps && blockIdx.x == 64;
+  unsigned long long dsum0 = 0, dsum1 = 0, dsum2 = 0, dlast = 0;
+  auto mfma_blk = [&](auto zc) {            // the 16 MFMAs of one 32-deep slice on the fragments in af / bf
+    constexpr bool Z = decltype(zc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], Z ? f32x4_t{0.f, 0.f, 0.f, 0.f} : accc[i][j], 0, 0, 0);
+  };
+  // one step = one 32-deep K slice of the current tile (KON) + one output fragment of the previous tile (EON).
+  // The two waves of a SIMD (wave w and w + 4: wave rows 0 and 1) run in ANTI-PHASE: row 0 does fragment reads, DMA issue and the
+  // epilogue arithmetic first and its 16 MFMAs last; row 1 (R1) starts a step with the MFMAs of the PREVIOUS step (operands kept in
+  // registers across the barrier) and then reads / issues / does its epilogue arithmetic — so in every half of a step one wave
+  // feeds the matrix pipe while the other one owns the VALU port, instead of both waiting on LDS and then queueing on the pipe.
+  // Both rows read slice P between the same two barriers: the ring hazards are those of the unstaggered form.
+  auto step = [&](auto pc, auto konc, auto eonc, auto rowc, int km0, int kn0, int nm0, int nn0) {
     constexpr int P = decltype(pc)::value;
-    constexpr bool KON = decltype(konc)::value, EON = decltype(eonc)::value;
+    constexpr bool KON = decltype(konc)::value, EON = decltype(eonc)::value, R1 = decltype(rowc)::value;
+    unsigned long long t0 = 0, t1 = 0;
+    if (dbgon) { t0 = __builtin_readcyclecounter(); if (dlast) dsum2 += t0 - dlast; __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (KON && R1 && P > 0) {
+      mfma_blk(std::integral_constant<bool, P == 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (dbgon) { t1 = __builtin_readcyclecounter(); dsum0 += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+    }
     if constexpr (KON) {
       const char* sl = smem + ((ring + P) % IW_NSLOT) * IW_SLOT_B;
 #pragma unroll
@@ -1747,19 +1771,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restr
       pp_lds_write_b64(cst_a + J * 32, make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])));
       if constexpr (NOUT == 2) pp_lds_write_b64(cst_a + J * 32 + 16 * CLD * 2, make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3])));
     }
-    if constexpr (KON) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], (P == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : accc[i][j], 0, 0, 0);
-      // instruction mix of the step: the fragment reads first, the DMA issues among the first epilogue instructions (they also cover
-      // the LDS latency), then one MFMA per 7 VALU instructions
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
+    if constexpr (KON && !R1) {
+      __builtin_amdgcn_sched_barrier(0);       // reads, DMA issue and the epilogue arithmetic above; this row's MFMAs close the step
+      if (dbgon) { t1 = __builtin_readcyclecounter(); dsum1 += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+      mfma_blk(std::integral_constant<bool, P == 0>{});
+      if (dbgon) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_readcyclecounter(); dsum0 += t1 - t0; t0 = t1; }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (EON && P < 16 && (P & 3) == 3) {
@@ -1784,6 +1800,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restr
     if constexpr (KON) {
       asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            // slice P + 1 has landed (slices P + 2 .. P + 4 may still fly)
       __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0)
+      if (dbgon) { __builtin_amdgcn_sched_barrier(0); dlast = __builtin_readcyclecounter(); dsum1 += dlast - t0; __builtin_amdgcn_sched_barrier(0); }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -1791,14 +1808,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto tile_body = [&](auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
-    constexpr bool KON = decltype(konc)::value;
+  auto tile_rows = [&](auto konc, auto eonc, auto rowc, int km0, int kn0, int nm0, int nn0) {
+    constexpr bool KON = decltype(konc)::value, R1 = decltype(rowc)::value;
     float bval = 0.f;
     if constexpr (KON) { if (e.bias) bval = e.bias[kn0 + wn * 64 + lane]; }
     [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-      (step(std::integral_constant<int, Ps>{}, konc, eonc, km0, kn0, nm0, nn0), ...);
+      (step(std::integral_constant<int, Ps>{}, konc, eonc, rowc, km0, kn0, nm0, nn0), ...);
     }(std::make_integer_sequence<int, NB>{});
+    if constexpr (KON && R1) {               // row 1 still owes the MFMAs of the tile's last slice (before the accumulators are handed over)
+      mfma_blk(std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (KON) iw_lds_write_b32(bias_a + (uint32_t)(par * 256 + lane * 4), bval);      // this tile's bias, for its epilogue during the next tile
+  };
+  const bool row1 = (wm == 1) && !(e.T & 512);      // development ablation (GSL_PP_ABL bit 512): both wave rows in phase
+  auto tile_body = [&](auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
+    if (row1) tile_rows(konc, eonc, std::true_type{}, km0, kn0, nm0, nn0);
+    else tile_rows(konc, eonc, std::false_type{}, km0, kn0, nm0, nn0);
   };
   // hand the finished tile over to the epilogue side
   auto hand_over = [&](int m0, int n0) {
@@ -1842,6 +1868,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restr
   hand_over(cm0, cn0);
   tile_body(F_{}, T_{}, 0, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (dbgon && lane == 0 && (wave == 0 || wave == 4)) {
+    unsigned long long* d = e.stamps + wm * 4;
+    d[0] = dsum0; d[1] = dsum1; d[2] = dsum2; d[3] = (unsigned long long)n_tiles * NB;
+  }
 }
 
 // ------------------------------------------------------------------ f32 kernel (parity mode)
