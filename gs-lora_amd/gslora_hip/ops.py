@@ -33,11 +33,16 @@ def code(dtype):
 
 
 def patchify(img, p, dtype):
-    _need(img)
-    B, Cc, H, W = img.shape
+    """img: one [B, C, H, W] batch or a list of batches of one image shape; the batches land in consecutive row ranges of the output."""
+    parts = list(img) if isinstance(img, (tuple, list)) else [img]
+    _need(*parts)
+    _, Cc, H, W = parts[0].shape
     T = 1 + (H // p) * (W // p)
-    out = torch.empty(B * T, p * p * Cc, device=img.device, dtype=dtype)
-    L.check(L.load().gsl_patchify(_p(img), _p(out), B, Cc, H, W, p, code(dtype), _stream()), "gsl_patchify")
+    out = torch.empty(sum(t.shape[0] for t in parts) * T, p * p * Cc, device=parts[0].device, dtype=dtype)
+    row = 0
+    for t in parts:
+        L.check(L.load().gsl_patchify(_p(t), _p(out[row:]), t.shape[0], Cc, H, W, p, code(dtype), _stream()), "gsl_patchify")
+        row += t.shape[0] * T
     return out
 
 

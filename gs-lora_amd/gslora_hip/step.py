@@ -145,7 +145,10 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         # arithmetically identical to the reference's two forwards and halves the number of kernel launches / tile tails
         nr = x_r.size(0)
         y_all = torch.cat((y_r, y_f), 0)
-        out, emb = model(torch.cat((x_r.float(), x_f.float()), 0), y_all)
+        # (the HIP model takes the two image batches as a tuple and patchifies each into its row range: no 2 x 77 MB concatenated
+        #  copy at batch 512 + 512; any other module gets the concatenated tensor)
+        both = (x_r, x_f) if getattr(net, "accepts_batch_tuple", False) and x_r.shape[1:] == x_f.shape[1:] else torch.cat((x_r.float(), x_f.float()), 0)
+        out, emb = model(both, y_all)
         out_r, out_f, emb_r, emb_f = out[:nr], out[nr:], emb[:nr], emb[nr:]
         if _plain_ce(criterion) and hasattr(backend, "ce_sum_top1_split"):
             split = (out, emb, y_all, nr)       # losses on the two row ranges of the un-sliced tensors (one gradient buffer each)

@@ -282,20 +282,25 @@ class ViTRunner:
 
     # ------------------------------------------------------------------ forward
     def forward(self, img, label, save):
+        """img: [B, C, H, W], or a tuple of such batches that are processed as ONE batch (gs_lora_step hands over the remain and the
+        forget batch this way: each is patchified into its row range of the token matrix, no concatenated image copy is made)."""
         m = self.model
-        if not img.is_cuda:
+        parts = [t.float().contiguous() for t in img] if isinstance(img, (tuple, list)) else [img.float().contiguous()]
+        img = parts[0]
+        if not all(t.is_cuda for t in parts):
             raise RuntimeError(f"{type(m).__name__} (gs-lora_amd): the model runs only on a ROCm GPU through libgslora_hip.so; "
                                "there is no CPU fallback. Move the model and inputs to 'cuda'.")
+        if any(t.shape[1:] != img.shape[1:] for t in parts):
+            raise ValueError("the batches of one forward must share the image shape")
         L.load()
         sp = m.hip_spec()
         dt = m.compute_dtype
-        img = img.float().contiguous()
         linear_head = sp.head_kind == "linear"
         if linear_head:
             label = None                       # modified_VIT.py:23-24: "label is not used in this model"
         elif label is not None:
             label = label.to(device=img.device, dtype=torch.int64).contiguous()
-        B = img.shape[0]
+        B = sum(t.shape[0] for t in parts)
         T, D, H = sp.num_tokens, sp.dim, sp.heads
         M = B * T
         training = m.training
@@ -315,7 +320,7 @@ class ViTRunner:
         s_lora = (1.0 / r) if r > 0 else 0.0
         eps = sp.ln_eps
 
-        patches = ops.patchify(img, sp.patch_size, dt)
+        patches = ops.patchify(parts, sp.patch_size, dt)
         x = torch.empty(M, D, device=img.device, dtype=torch.float32)
         pw = self.w_conv("pe", sp.patch_w, dt) if sp.patch_is_conv else self.w("pe", sp.patch_w, dt)
         ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH, bias=sp.patch_b.detach(),

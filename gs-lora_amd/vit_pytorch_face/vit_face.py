@@ -127,6 +127,7 @@ class HipModelMixin:
     """Shared by the model families that run on ViTRunner (ViT_face, ModifiedViT): compute-dtype switch, the lazily built
     runner / flat LoRA bucket, and the one-autograd-node call."""
     _runner = None
+    accepts_batch_tuple = True      # forward(img) also takes a tuple of image batches, processed as one batch (gslora_hip.step)
 
     def set_compute_dtype(self, name):
         """'bf16' (speed: bf16 MFMA operands, f32 accumulate) or 'fp32' (parity: exact-f32 kernels)."""
