@@ -226,6 +226,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    if env_world == 1 and os.environ.get("GSL_BENCH_DP1") == "1" and not stub:
+        # development knob: a ONE-rank RCCL group with the data-parallel form of the step forced on (every collective is an identity):
+        # measures what the packed all-reduce, the side-stream gradient reduction and RCCL's stream plumbing cost per step on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from gslora_hip import step as _step
+        _step._dp_active = lambda: True
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')}); "
@@ -329,8 +337,19 @@ def main():
         })
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline()
+    # the JSON line must be the LAST line of the job's stdout: RCCL writes its version banner through C stdio, which a piped stdout
+    # only flushes at exit (i.e. after Python's own print) — push every rank's C buffer out first, then let rank 0 print
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if dist.is_initialized() and world > 1:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -19,6 +19,13 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _dp_active():
+    """The data-parallel form of the step (packed scalar all-reduce, gradient all-reduce, graph segments) runs when the process group has
+    more than one rank. (tests/test_hip_graph.py patches this to drive the same form through a ONE-rank RCCL group: every collective is
+    then an identity, so the results must equal the single-process step.)"""
+    return _world() > 1
+
+
 def _plain_ce(criterion):
     return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
             and getattr(criterion, "label_smoothing", 0.0) == 0.0 and criterion.ignore_index == -100)
@@ -175,7 +182,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         kl_f_sum = kl_r_sum = None
     # the scalar tail (hinges, weighted sum, meters, the five upstream gradients) is ONE kernel forward and one 5-element multiply
     # backward instead of ~35 one-element torch kernels (losses.combine / gsl_loss_combine[_pack])
-    if world == 1:
+    if not _dp_active():
         structure = backend.structure_loss(net, group_type, grad_scale=1.0) if use_structure else None
         total, meters = backend.combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha,
                                         w_f, w_r, BND_pro)
@@ -342,7 +349,7 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.optimizer.graph_mode, r.seed_dev = True, self.seed_dev
         try:
-            if _world() > 1:
+            if _dp_active():
                 graph = _SegmentedCapture()
                 graph.begin()
                 try:
