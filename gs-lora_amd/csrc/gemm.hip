@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
     epilogue_staged_mulgrad<8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
                                t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4);
+    if (dbg8) dbg8[3] = __builtin_readcyclecounter();
     return;
   } else if constexpr (LORA) {
     // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
