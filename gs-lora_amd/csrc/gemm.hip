@@ -305,9 +305,26 @@ constexpr int GF_BLOCK_B = 8 * GF_WAVE_B + GF_T16_B;            // 159744 of the
 typedef short gf_v4s_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) gf_v4s_t* gf_lds_v4s_p;
 union GfFrag { gf_v4s_t h[2]; bf16x8_t v; };
+// global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
+struct GfOperands { uint4 ax[4], hx[4], u1a, u1b; };
+__device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int mw, int nw, int ic, int lane) {
+  const int crow = lane >> 3, cch = lane & 7;
+  const int ncl = min(nw + cch * 8, e.N - 8);
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
+    g.ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + ncl);
+    g.hx[r] = *reinterpret_cast<const uint4*>(e.gy2 + (size_t)m * e.ldo + ncl);
+  }
+  const bf16_t* up = e.gu1 + (size_t)min(mw + ic * 32 + (lane & 31), e.M - 1) * e.ldgu1;
+  g.u1a = *reinterpret_cast<const uint4*>(up);
+  g.u1b = *reinterpret_cast<const uint4*>(up + 8);
+}
+// go: the operands of round 0, requested by the caller (right after the K loop, in front of the rank-r tail)
 template <int NI>
 __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_t (&acc)[NI][4], char* wreg, char* partner,
-                                                        const bf16_t* t16w, int mw, int nw, int lane, int wm, int mtile) {
+                                                        const bf16_t* t16w, int mw, int nw, int lane, int wm, int mtile, GfOperands& go) {
   float* cst = reinterpret_cast<float*>(wreg);
   bf16_t* yd = reinterpret_cast<bf16_t*>(wreg + GF_STAGE_B);
   bf16_t* yh = reinterpret_cast<bf16_t*>(wreg + GF_STAGE_B + GF_Y_B);
@@ -320,23 +337,16 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   f32x4_t g1[4], g2[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) g1[t] = g2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // The global operands of a 32-row round (g', h: 4 x 16 B per lane each, U1: 2 x 16 B) are requested as soon as the registers of the
+  // previous round's operands are dead — after its multiply / LDS hand-over, in front of its transpose reads and MFMAs — so that the
+  // round trip (which grows from ~2.5 k to ~5 k cycles when all CUs stream) is covered by that MFMA section and the next round's
+  // staging writes. No second register set: the kernel sits at 252 VGPRs.
+  uint4 (&ax)[4] = go.ax;
+  uint4 (&hx)[4] = go.hx;
+  uint4 &u1a = go.u1a, &u1b = go.u1b;
+  auto request = [&](int ic) { gf_request(e, go, mw, nw, ic, lane); };
 #pragma unroll
   for (int ic = 0; ic < NI / 2; ++ic) {
-    uint4 ax[4], hx[4], u1a, u1b;
-    const int ncl = min(nw + cch * 8, e.N - 8);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = mw + ic * 32 + r * 8 + crow;
-      ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)min(m, e.M - 1) * e.ldo + ncl);
-      hx[r] = (m < e.M) ? *reinterpret_cast<const uint4*>(e.gy2 + (size_t)m * e.ldo + ncl) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    {
-      const int m = mw + ic * 32 + (lane & 31);
-      const bf16_t* up = e.gu1 + (size_t)min(m, e.M - 1) * e.ldgu1;
-      u1a = *reinterpret_cast<const uint4*>(up);
-      u1b = *reinterpret_cast<const uint4*>(up + 8);
-      if (m >= e.M) u1a = u1b = make_uint4(0u, 0u, 0u, 0u);      // rows past M contribute nothing (their dZ is finite: clamped operands)
-    }
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -345,6 +355,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
         if (e.alpha != 1.0f) v *= e.alpha;
         *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
+    __builtin_amdgcn_sched_barrier(0);    // nothing that consumes the requested operands may be scheduled above the staging (it would drag their wait up)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r * 8 + crow;
@@ -361,13 +372,18 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, e.stmode);
       *reinterpret_cast<uint4*>(yd + row * CLD + cch * 8) = ov;
-      *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = hx[r];
+      // rows past M contribute nothing to the reductions (their dZ is finite: clamped operands) — masked where the operand is consumed,
+      // not where it was requested, so that no wait for the loads sits in front of the staging above
+      *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = (m < e.M) ? hx[r] : make_uint4(0u, 0u, 0u, 0u);
     }
     if (lane < 32) {
-      *reinterpret_cast<uint4*>(ub + lane * 16) = u1a;
-      *reinterpret_cast<uint4*>(ub + lane * 16 + 8) = u1b;
+      const bool in = mw + ic * 32 + lane < e.M;
+      *reinterpret_cast<uint4*>(ub + lane * 16) = in ? u1a : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(ub + lane * 16 + 8) = in ? u1b : make_uint4(0u, 0u, 0u, 0u);
     }
     asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
+    if (ic + 1 < NI / 2) request(ic + 1);
+    asm volatile("" ::: "memory");
     GfFrag b1, b2;
     b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
     b1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + (trow + 16) * 16 + tcol));
@@ -1001,6 +1017,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
       qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
     }
+    // round 0 of the epilogue's global operands flies under the rank-r tail (the operand-fragment registers of the K loop are dead).
+    // Placement: behind the t16 hand-over (the compiler closes the K loop's LDS-DMA stream with s_waitcnt vmcnt(0) in front of the
+    // first LDS store) and behind the Q fragments (vmcnt retires in order: the MFMAs below must not wait for these ten loads).
+    asm volatile("" ::: "memory");
+    GfOperands go;
+    gf_request(e, go, m0 + wm * 128, n0 + wn * 64, 0, lane);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(t16 + (wm * 128 + i * 16 + fr) * 16 + (fc & 1) * 8);
@@ -1011,7 +1033,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
     __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
     epilogue_staged_mulgrad<8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
-                               t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4);
+                               t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4, go);
     if (dbg8) dbg8[3] = __builtin_readcyclecounter();
     return;
   } else if constexpr (LORA) {
