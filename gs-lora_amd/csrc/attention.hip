@@ -90,27 +90,31 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * mul, v[1] * mul), pack2bf(v[2] * mul, v[3] * mul));
 }
 
+// hm (layout of the qkv INPUT of the bf16 kernels): 0 = token-major [B*T, 3*H*64] (row stride 3*H*64; the three panels of a head are 64
+// columns wide at column offsets h*64, (H+h)*64, (2H+h)*64), 1 = head-major [B][H][3][T][64] (each (image, head) item is one contiguous
+// block of three [T, 64] panels: every panel row is a full 128-byte line next to its neighbours instead of a 128-byte segment every
+// 3*H*128 bytes). Outputs (o, dqkv) are always token-major — they are A operands of row-major GEMMs.
 // =====================================================================================
 // forward (bf16)
 // =====================================================================================
 template <int NKT>
 __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                            float* __restrict__ lse, int T, int H, float scale, int abl) {
+                                                            float* __restrict__ lse, int T, int H, float scale, int abl, int hm) {
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * HD;
-  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const long ldi = hm ? (long)HD : 3L * H * HD, ko = hm ? (long)T * HD : (long)H * HD;
+  const bf16_t* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * T * HD : (size_t)b * T * ldi + h * HD);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   bf16x8_t qn0, qn1;   // Q fragments of the NEXT query tile: their global-load latency hides under this tile's work
   {                    // (the first tile's are issued before the panel staging and land under it)
-    const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ld;
+    const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ldi;
     qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
   }
   if (abl != 2) {
-    stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
-    stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
+    stage_rowmajor<TP>(Ks, qb + ko, ldi, T);
+    stage_rowmajor<TP>(Vs, qb + 2 * ko, ldi, T);
   }
   __syncthreads();
   if (abl == 1) return;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
     const int qr = qt * 16 + fr;
     const bf16x8_t qf0 = qn0, qf1 = qn1;
     if (qt + nwaves < nqt) {
-      const bf16_t* qrow = qb + (size_t)min((qt + nwaves) * 16 + fr, T - 1) * ld;
+      const bf16_t* qrow = qb + (size_t)min((qt + nwaves) * 16 + fr, T - 1) * ldi;
       qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
     }
     f32x4_t s[NKT];
@@ -193,14 +197,15 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // is empty for every T this kernel accepts (T <= 208) and is not computed at all. Same values, same order: bit-identical.
 template <int NKT, bool FAST>
 __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                                  float* __restrict__ lse, int T, int H, float scale, int nitems) {
+                                                                  float* __restrict__ lse, int T, int H, float scale, int nitems, int hm) {
   constexpr int TP = NKT * 16;
   constexpr int NCW = 13;                 // compute waves = query tiles (host: T <= 208)
   constexpr int NST = 9;                  // loader steps per panel: 24 rows x 8 chunks per step, 9 * 24 = 216 >= 208 rows
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
-  const long ld = 3L * H * HD;
+  const long ld = hm ? (long)HD : 3L * H * HD, ko = hm ? (long)T * HD : (long)H * HD;      // row stride / K-panel offset of the qkv input
+  auto item_base = [&](int it) { return qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)(it / H) * T * ld + (it % H) * HD); };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fc = lane >> 4;
   // rows >= T of the panels are zero for every item: written once
   for (int idx = threadIdx.x; idx < (TP - T) * 8; idx += 1024) {
@@ -218,12 +223,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
     const int li = (wave - NCW) * 64 + lane, col = (li & 7) * 8, row0 = li >> 3;
     u32x4_t dq[NST], dk[NST], dv[NST];
     int item = blockIdx.x;
-    const bf16_t* qb = qkv + (size_t)(item / H) * T * ld + (item % H) * HD;
+    const bf16_t* qb = item_base(item);
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
       dq[k] = *reinterpret_cast<const u32x4_t*>(qb + g);
-      dk[k] = *reinterpret_cast<const u32x4_t*>(qb + g + H * HD);
+      dk[k] = *reinterpret_cast<const u32x4_t*>(qb + g + ko);
     }
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -233,11 +238,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * H * HD);
+    for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * ko);
     wg_barrier_lds();                                   // Q, K of the first item are in LDS
     for (; item < nitems; item += gridDim.x) {
       const int nxt = (item + (int)gridDim.x < nitems) ? item + (int)gridDim.x : item;
-      const bf16_t* nb = qkv + (size_t)(nxt / H) * T * ld + (nxt % H) * HD;
+      const bf16_t* nb = item_base(nxt);
       // phase 1 of `item`: V(item) -> LDS, request Q, K of the next item
 #pragma unroll
       for (int k = 0; k < NST; ++k) *reinterpret_cast<u32x4_t*>(Vs + lds_off(min(row0 + 24 * k, T - 1), col)) = dv[k];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
       for (int k = 0; k < NST; ++k) {
         const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
         dq[k] = *reinterpret_cast<const u32x4_t*>(nb + g);
-        dk[k] = *reinterpret_cast<const u32x4_t*>(nb + g + H * HD);
+        dk[k] = *reinterpret_cast<const u32x4_t*>(nb + g + ko);
       }
       wg_barrier_lds();
       // phase 2 of `item`: Q, K of the next item -> LDS, request its V
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(nb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * H * HD);
+      for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(nb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * ko);
       wg_barrier_lds();
     }
     return;
@@ -326,13 +331,14 @@ template <int NKT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
-                                                               int H, float scale, int abl) {
+                                                               int H, float scale, int abl, int hm) {
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;
+  const bf16_t* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * T * HD : (size_t)b * T * ld + h * HD);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nwaves = blockDim.x >> 6;
   // this wave's first query tile: Q / dO / O fragments come straight from global memory; issued before the panel staging so that
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   Frag dof0, dof1, of0, of1;
   auto load_tile = [&](int qt) {
     const int qrc = min(qt * 16 + fr, T - 1);
-    const bf16_t* qrow = qb + (size_t)qrc * ld;
+    const bf16_t* qrow = qb + (size_t)qrc * ldi;
     const bf16_t* dorow = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
     const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
     qf0 = gl_frag(qrow, 0, fc); qf1 = gl_frag(qrow, 1, fc);
@@ -350,8 +356,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
   };
   load_tile(wave);
   if (abl != 2) {
-    stage_rowmajor<TP>(Ks, qb + H * HD, ld, T);
-    stage_rowmajor<TP>(Vs, qb + 2 * H * HD, ld, T);
+    stage_rowmajor<TP>(Ks, qb + ko, ldi, T);
+    stage_rowmajor<TP>(Vs, qb + 2 * ko, ldi, T);
   }
   __syncthreads();
   if (abl == 1) return;
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 template <int NKT, int NT>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl) {
+                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl, int hm) {
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Os[TP * KLD];   // dO row-major
@@ -419,7 +425,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
   __shared__ __attribute__((aligned(16))) float del_s[TP];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;
+  const bf16_t* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * T * HD : (size_t)b * T * ld + h * HD);
   const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nwaves = blockDim.x >> 6;
@@ -431,15 +438,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
     for (int t = 0; t < NT; ++t) {
       kr[t] = (kp * NT + t) * 16 + fr;
       const int krc = min(kr[t], T - 1);
-      const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
-      const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+      const bf16_t* krow = qb + (size_t)krc * ldi + ko;
+      const bf16_t* vrow = qb + (size_t)krc * ldi + 2 * ko;
       kf[t][0] = gl_frag(krow, 0, fc); kf[t][1] = gl_frag(krow, 1, fc);
       vf[t][0] = gl_frag(vrow, 0, fc); vf[t][1] = gl_frag(vrow, 1, fc);
     }
   };
   load_keys(wave);
   if (abl != 2) {
-    stage_rowmajor<TP>(Qs, qb, ld, T);
+    stage_rowmajor<TP>(Qs, qb, ldi, T);
     stage_rowmajor<TP>(Os, dob, ldo, T);
   }
   for (int t = threadIdx.x; t < TP; t += blockDim.x) {
@@ -532,7 +539,7 @@ template <int NKT, bool FAST>
 __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                      const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                      bf16_t* __restrict__ dqkv, int T, int H, float scale,
-                                                                     unsigned long long* __restrict__ stamps) {
+                                                                     unsigned long long* __restrict__ stamps, int hm) {
   constexpr int TP = NKT * 16;
   // development (GSL_ATTN_STAMPS = device address of 256 x 8 u64): cycle stamps of every 64th workgroup
   unsigned long long* dbg = (stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0) ? stamps + (blockIdx.x / 64) * 8 : nullptr;   // uniform
@@ -544,7 +551,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
   __shared__ __attribute__((aligned(16))) float del_s[TP];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const bf16_t* qb = qkv + (size_t)b * T * ld + h * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
+  const bf16_t* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * T * HD : (size_t)b * T * ld + h * HD);
   const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fc = lane >> 4;
   const int nwaves = blockDim.x >> 6;
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
     Frag dof0, dof1, of0, of1;
     auto load_tile = [&](int qt) {
       const int qrc = min(qt * 16 + fr, T - 1);
-      const bf16_t* qrow = qb + (size_t)qrc * ld;
+      const bf16_t* qrow = qb + (size_t)qrc * ldi;
       const bf16_t* dorow = dob + (size_t)qrc * ldo;
       const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
       qf0 = gl_frag(qrow, 0, fc); qf1 = gl_frag(qrow, 1, fc);
@@ -565,8 +573,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
       of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
     };
     load_tile(wave);
-    stage_rowmajor<TP>(P0, qb + H * HD, ld, T);
-    stage_rowmajor<TP>(P1, qb + 2 * H * HD, ld, T);
+    stage_rowmajor<TP>(P0, qb + ko, ldi, T);
+    stage_rowmajor<TP>(P1, qb + 2 * ko, ldi, T);
     for (int t = threadIdx.x; t < TP; t += blockDim.x) {
       lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;
       del_s[t] = 0.f;
@@ -628,8 +636,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
   auto load_keys = [&](int kp) {
     kr = kp * 16 + fr;
     const int krc = min(kr, T - 1);
-    const bf16_t* krow = qb + (size_t)krc * ld + H * HD;
-    const bf16_t* vrow = qb + (size_t)krc * ld + 2 * H * HD;
+    const bf16_t* krow = qb + (size_t)krc * ldi + ko;
+    const bf16_t* vrow = qb + (size_t)krc * ldi + 2 * ko;
     kf[0] = gl_frag(krow, 0, fc); kf[1] = gl_frag(krow, 1, fc);
     vf[0] = gl_frag(vrow, 0, fc); vf[1] = gl_frag(vrow, 1, fc);
   };
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
     for (int k = 0; k < NPF; ++k) {
       const int c = min(et + k * net, tot - 1);
       const int pnl = c >= T * 8, rc = c - pnl * (T * 8);
-      const bf16_t* src = pnl ? dob + (size_t)(rc >> 3) * ldo : qb + (size_t)(rc >> 3) * ld;
+      const bf16_t* src = pnl ? dob + (size_t)(rc >> 3) * ldo : qb + (size_t)(rc >> 3) * ldi;
       pf[k] = *reinterpret_cast<const u32x4_t*>(src + (rc & 7) * 8);
     }
   }
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
       }
     }
   } else {
-    stage_rowmajor<TP>(P0, qb, ld, T);
+    stage_rowmajor<TP>(P0, qb, ldi, T);
     stage_rowmajor<TP>(P1, dob, ldo, T);
   }
   __syncthreads();
@@ -889,12 +897,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o_cls, const float* __restrict__ lse,
-                                                           T* __restrict__ dqkv, int Tn, int H, float scale) {
+                                                           T* __restrict__ dqkv, int Tn, int H, float scale, int hm) {
   __shared__ float q0[HD], g0[HD], red[32][HD];
   __shared__ float sD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const T* qb = qkv + (size_t)b * Tn * ld + h * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)Tn * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
+  const T* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * Tn * HD : (size_t)b * Tn * ld + h * HD);
   T* db = dqkv + (size_t)b * Tn * ld + h * HD;
   const int tid = threadIdx.x;
   if (tid < HD) {
@@ -914,8 +923,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
     const int j = j0 + grp;
     const bool live = j < Tn;
     const int jc = live ? j : Tn - 1;
-    const T* kr = qb + (size_t)jc * ld + H * HD + sub * 8;
-    const T* vr = qb + (size_t)jc * ld + 2 * H * HD + sub * 8;
+    const T* kr = qb + (size_t)jc * ldi + ko + sub * 8;
+    const T* vr = qb + (size_t)jc * ldi + 2 * ko + sub * 8;
     float kv[8], vv[8];
     Elem<T>::ld4(kr, kv); Elem<T>::ld4(kr + 4, kv + 4);
     Elem<T>::ld4(vr, vv); Elem<T>::ld4(vr + 4, vv + 4);
@@ -953,15 +962,16 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
 }
 
 extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv, int B,
-                                     int T, int H, float scale, int dtype, gsl_stream_t s) {
+                                     int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o && d_o_cls && lse && dqkv && B > 0 && T > 1 && H > 0, "null/size");
+  GSL_CHECK_ARG(qkv_layout == 0 || qkv_layout == 1, "qkv_layout: 0 token-major, 1 head-major");
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)o,
-                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale);
+                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale, qkv_layout);
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)o,
-                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale);
+                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale, qkv_layout);
   else return fail(GSL_ERR_ARG, "gsl_attention_bwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd_cls");
 }
@@ -982,19 +992,21 @@ static inline int attn_abl() { const char* e = getenv("GSL_ATTN_ABL"); return e 
 // C ABI
 // =====================================================================================
 extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype,
-                                 gsl_stream_t s) {
+                                 int qkv_layout, gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o && lse && B > 0 && T > 1 && H > 0, "null/size");
+  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_BF16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
+  const int hm = qkv_layout;
   GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16) {
-    if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else if (attn_persistent() && T <= 208 && B * H >= 2 * attn_num_cus())
     {
-      if (T > 192) hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, true>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H);
-      else hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, false>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H);
+      if (T > 192) hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, true>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
+      else hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, false>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
     }
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl());
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
   } else if (dtype == GSL_F32) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
     else hipLaunchKernelGGL(attn_fwd_f32_kernel<224>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
@@ -1003,8 +1015,10 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
 }
 
 extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
-                                 float* delta_ws, int B, int T, int H, float scale, int dtype, gsl_stream_t s) {
+                                 float* delta_ws, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o && d_o && lse && dqkv && delta_ws && B > 0 && T > 1 && H > 0, "null/size");
+  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_BF16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
+  const int hm = qkv_layout;
   GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
@@ -1012,20 +1026,20 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     const bf16_t* q = (const bf16_t*)qkv; const bf16_t* oo = (const bf16_t*)o; const bf16_t* g = (const bf16_t*)d_o;
     bf16_t* dq = (bf16_t*)dqkv;
     if (T <= 64) {
-      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
-      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
+      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
     } else if (!getenv("GSL_ATTN_BWD_SPLIT") || atoi(getenv("GSL_ATTN_BWD_SPLIT")) == 0) {
       // (a persistent wave-specialised form like the forward's was measured slower here: 795 vs 736 us at B = 1024 — its four
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       const char* sp = getenv("GSL_ATTN_STAMPS");
       unsigned long long* stp = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr;
-      if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp);
-      else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp);
+      if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+      else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
-      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl());
+      hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
       { const char* nt = getenv("GSL_ATTN_NT");     // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us
-        if (!nt || atoi(nt) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl());
-        else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 2>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl()); }
+        if (!nt || atoi(nt) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
+        else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 2>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm); }
     }
   } else if (dtype == GSL_F32) {
     const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;

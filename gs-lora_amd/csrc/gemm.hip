@@ -47,6 +47,7 @@ struct EpiArgs {
   const bf16_t* gy2;              // Y2 [M, N] (row stride ldo): G2[n, j] = sum_m Y2[m, n] * t[m, j]
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
   int gR;                         // 8 or 16
+  int hmT, hmH;                   // STORE_QKV_HM: tokens per image and heads (0 = plain row-major output)
   unsigned long long* stamps;     // development (GSL_P8_STAMPS = device address of 256 x 4 u64): cycle stamps of every 64th workgroup of the 8-phase kernel
 };
 
@@ -121,7 +122,13 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   if (m >= e.M || n >= e.N) return;
   float g[4];
   epi_math<EPI, T>(e, m, n, v, g);
-  const size_t off = (size_t)m * e.ldo + n;
+  size_t off = (size_t)m * e.ldo + n;
+  if constexpr (EPI == GSL_EPI_STORE) {
+    if (e.hmT) {          // STORE_QKV_HM: (row b T + t, column (which, h, d)) -> [b][h][which][t][d]
+      const int b = m / e.hmT, t = m - b * e.hmT, pn = n >> 6, which = pn / e.hmH, h = pn - which * e.hmH;
+      off = ((((size_t)b * e.hmH + h) * 3 + which) * (size_t)e.hmT + t) * 64 + (n & 63);
+    }
+  }
   if constexpr (epi_out_is_f32<EPI>()) {
     Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else {
@@ -168,6 +175,17 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   // dropout: first-stage hash value of this lane's first fragment; fragment (i, j) is 16 i rows and 16 j columns further, i.e.
   // 8 N i + 8 j element pairs (N % 4 == 0): one uniform offset and one add per fragment
   const size_t rowoff0 = (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);     // copy-out: lane's row 0 of the wave tile
+  // STORE_QKV_HM: row m = b T + t of the wave's 64 columns (one (q|k|v, head) panel) goes to [b][h][which][t][64]; the lane walks its
+  // rows in steps of 8, so (b, t) is divided out once and advanced incrementally
+  int hb = 0, ht = 0;
+  size_t hpanel = 0;
+  if constexpr (EPI == GSL_EPI_STORE) {
+    if (e.hmT) {
+      hb = (mw + crow) / e.hmT; ht = (mw + crow) - hb * e.hmT;
+      const int pn = nw >> 6, which = pn / e.hmH, h = pn - which * e.hmH;
+      hpanel = ((size_t)h * 3 + (size_t)which) * (size_t)e.hmT * 64 + (size_t)(cch * 8);
+    }
+  }
   constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
   uint32_t wbase = 0u, rowstep = 0u;
   if constexpr (DROPW) {
@@ -220,7 +238,10 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
           bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
           // element offset = this lane's first row + a wave-uniform row step (scalar multiply): no per-store 64-bit multiply
-          const size_t off = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
+          size_t off = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
+          if constexpr (EPI == GSL_EPI_STORE) {
+            if (e.hmT) off = (size_t)hb * ((size_t)e.hmH * 3 * (size_t)e.hmT * 64) + hpanel + (size_t)ht * 64;
+          }
           if (dst) store_stream16(dst + off, val, e.stmode);
           if constexpr (NOUT == 2 && !SEQ) {
             if (e.out2) {
@@ -228,6 +249,9 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
               store_stream16(reinterpret_cast<bf16_t*>(e.out2) + off, val2, e.stmode);
             }
           }
+        }
+        if constexpr (EPI == GSL_EPI_STORE) {
+          if (e.hmT) { ht += 8; while (ht >= e.hmT) { ht -= e.hmT; ++hb; } }
         }
       }
     }
@@ -2049,11 +2073,16 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  e.hmT = 0; e.hmH = 0;
   { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_F32: return launch_gemm<GSL_EPI_STORE_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
+      GSL_CHECK_ARG(dtype == GSL_BF16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");
+      e.hmT = T; e.hmH = N / 192;
+      return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_RES_F32:
       GSL_CHECK_ARG(bias && res, "bias/res required");
       return launch_gemm<GSL_EPI_BIAS_RES_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -2086,6 +2115,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  e.hmT = 0; e.hmH = 0;
   { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
@@ -2165,6 +2195,7 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
   e.krot = 0;   // every N tile must accumulate t = s A P^T in the same K order: G2 contracts the tile-local t, which has to equal tout bit for bit
   { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  e.hmT = 0; e.hmH = 0;
   { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   const int R = (r <= 8) ? 8 : 16;
   const int ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSLORA_HIP_LIB") or os.path.join(_HERE, "libgslora_hip.so")
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32 = 0, 1, 2, 3, 4, 5
+EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM = 0, 1, 2, 3, 4, 5, 6
 NORM_SPLIT = 8
 SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 
@@ -32,9 +32,9 @@ SIGNATURES = {
                                  _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _u64, _u32, _l, _vp],
-    "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
-    "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
-    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
+    "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
+    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],

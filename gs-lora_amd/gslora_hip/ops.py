@@ -153,29 +153,31 @@ def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_
     return dx, dxb
 
 
-def attention_fwd(qkv, B, T, H, scale):
+def attention_fwd(qkv, B, T, H, scale, layout=0):
+    """layout: 0 = qkv token-major [B*T, 3*H*64], 1 = head-major [B][H][3][T][64] (bf16; see gemm_nt(epilogue=EPI_STORE_QKV_HM))."""
     _need(qkv)
     o = torch.empty(B * T, H * 64, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
-    L.check(L.load().gsl_attention_fwd(_p(qkv), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), _stream()),
+    L.check(L.load().gsl_attention_fwd(_p(qkv), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), int(layout), _stream()),
             "gsl_attention_fwd")
     return o, lse
 
 
-def attention_bwd(qkv, o, d_o, lse, B, T, H, scale):
+def attention_bwd(qkv, o, d_o, lse, B, T, H, scale, layout=0):
+    """dqkv is token-major [B*T, 3*H*64] whatever the layout of the qkv input."""
     _need(qkv, o, d_o, lse)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     L.check(L.load().gsl_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), _p(delta), B, T, H, float(scale),
-                                       code(qkv.dtype), _stream()), "gsl_attention_bwd")
+                                       code(qkv.dtype), int(layout), _stream()), "gsl_attention_bwd")
     return dqkv
 
 
-def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale):
+def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale, layout=0):
     _need(qkv, o, d_o_cls, lse)
     dqkv = torch.empty_like(qkv)
     L.check(L.load().gsl_attention_bwd_cls(_p(qkv), _p(o), _p(d_o_cls), _p(lse), _p(dqkv), B, T, H, float(scale),
-                                           code(qkv.dtype), _stream()), "gsl_attention_bwd_cls")
+                                           code(qkv.dtype), int(layout), _stream()), "gsl_attention_bwd_cls")
     return dqkv
 
 

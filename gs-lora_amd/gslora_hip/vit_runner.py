@@ -22,6 +22,9 @@ FUSE_LORA_GRAD = os.environ.get("GSL_FUSE_LORA_GRAD", "1") != "0"
 # bf16 speed mode carries the residual-GRADIENT stream (the f32 [M, dim] tensor every LayerNorm backward re-reads and re-writes) in bf16:
 # -25 % of the bytes of each LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32 (the parity mode always does).
 GRAD_STREAM_BF16 = os.environ.get("GSLORA_GRAD_STREAM", "bf16").lower() != "f32"
+# layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
+# read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
+QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
 
 
 class BlockSpec:
@@ -332,18 +335,21 @@ class ViTRunner:
             n1, n2 = blk.ln1, blk.ln2
             xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
             qkv = torch.empty(M, 3 * H * 64, device=img.device, dtype=dt)
+            hm = 1 if (QKV_HEAD_MAJOR and dt == torch.bfloat16) else 0
+            epi_qkv = L.EPI_STORE_QKV_HM if hm else L.EPI_STORE
             uq = None
             if attn_site and not blk.qkv_lora.merged:      # q / k / v adapters: one block-diagonal LoRA K segment
                 qo = self.qkv_lora_ops(i, blk.qkv_lora, dt)
                 uq = torch.empty(M, PADK, device=img.device, dtype=dt)
                 ops.gemm_nt(xn, qo["A_rows"], uq, alpha=s_lora)
-                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, A2=uq, W2=qo["Bblk"],
+                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, A2=uq, W2=qo["Bblk"], epilogue=epi_qkv, T=T,
                             bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             else:
-                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, bias=None if blk.qkv_b is None else blk.qkv_b.detach())
+                ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, epilogue=epi_qkv, T=T,
+                            bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             xn_keep = xn if (attn_site and save) else None
             del xn
-            o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale)
+            o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale, layout=hm)
             x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
             ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
                         bias=blk.out.bias.detach(), res=x, p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
@@ -379,7 +385,7 @@ class ViTRunner:
                             W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
                             bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
-                stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
+                stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, qkv_hm=hm, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
                                   xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq))
             x = x2
         hn = sp.final_ln
@@ -500,9 +506,9 @@ class ViTRunner:
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
             ops.gemm_nt(dx1b, self.wT(f"wo{i}", blk.out.weight, dt), d_o)
             if sparse:
-                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
             else:
-                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
             dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)
             ops.gemm_nt(dqkv, self.wT(f"qkv{i}", blk.qkv_w, dt), dxn1)
             del d_o, dqkv, dx1b
@@ -571,9 +577,9 @@ class ViTRunner:
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
             ops.gemm_nt(dx1b, self.wT(f"wo{i}", blk.out.weight, dt), d_o)
             if sparse:
-                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
             else:
-                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale)
+                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
             del d_o, dx1b
             qo = self.qkv_lora_ops(i, ml, dt)
             v = torch.empty(B * T, PADK, device=dev, dtype=dt)

@@ -42,7 +42,9 @@ enum gsl_epilogue {
   GSL_EPI_BIAS_GELU = 2,    /* out[dtype]  = dropout(gelu(acc+bias)); out2[dtype] = gelu'(acc+bias)*dropmask */
   GSL_EPI_MUL = 3,          /* out[dtype]  = acc * aux[dtype]                                   */
   GSL_EPI_PATCH = 4,        /* outf32      = dropout((tok==0 ? cls : acc + bias) + pos[tok]),  tok = m % T */
-  GSL_EPI_STORE_F32 = 5     /* outf32      = acc (+ bias)                                       */
+  GSL_EPI_STORE_F32 = 5,    /* outf32      = acc (+ bias)                                       */
+  GSL_EPI_STORE_QKV_HM = 6  /* bf16 only: STORE of a QKV projection (N = 3*H*64, rows m = b*T + t, T = tokens per image) into the
+                               head-major layout [B][H][3][T][64] that the attention entry points read with qkv_layout = 1 */
 };
 
 int gsl_version(void);
@@ -111,16 +113,18 @@ int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const f
                       float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s);
 
 /* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
- * qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)'), o[dtype] [B*T, H*64], lse f32 [B,H,T]. */
-int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype, gsl_stream_t s);
-/* dqkv[dtype] [B*T,3*H*64]; delta_ws f32 [B,H,T] scratch. */
+ * qkv_layout (the INPUT qkv): 0 = token-major qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)', as the reference's to_qkv output),
+ * 1 = head-major [B][H][3][T][64] (bf16 kernels only; written by gsl_gemm_nt's GSL_EPI_STORE_QKV_HM): every panel row is a full
+ * 128-byte line next to its neighbours. Outputs are token-major in both cases: o[dtype] [B*T, H*64], lse f32 [B,H,T]. */
+int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
+/* dqkv[dtype] [B*T,3*H*64] (token-major, always); delta_ws f32 [B,H,T] scratch. */
 int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
-                      float* delta_ws, int B, int T, int H, float scale, int dtype, gsl_stream_t s);
+                      float* delta_ws, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
 /* Backward when only the cls query (token 0 of every image) carries an output gradient — the last
  * transformer block, because ViT_face pools x[:,0] (vit_face.py:540). d_o_cls[dtype] [B, H*64] is dO of the cls rows;
  * o and lse are the forward's full tensors. Writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens = 0). */
 int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
-                          int B, int T, int H, float scale, int dtype, gsl_stream_t s);
+                          int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
 
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
  * Y[dtype] [M,N] with row stride ldy >= N elements (a column block of a wider tensor is allowed), U[dtype] [M,ldu] (first r columns

@@ -644,3 +644,46 @@ def test_layernorm_bwd_bf16_gradient_stream(ops):
     dxh, _ = ops.head_bwd(None, rnd(4, D, seed=45).cuda(), rnd(4 * 7, D, seed=46).cuda(), 4, 7, D, g.cuda(), torch.zeros(4).cuda(),
                           torch.ones(4).cuda(), rnd(4, D, seed=47).cuda(), None, 64.0, dt, stream_dtype=dt)
     assert dxh.dtype == dt and (dxh.view(4, 7, D)[:, 1:] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------- head-major qkv
+def _to_head_major(qkv, B, T, H):
+    """[B*T, 3*H*64] (q|k|v, head-major inside each) -> [B][H][3][T][64] flattened back to the same 2-D shape."""
+    return qkv.view(B, T, 3, H, 64).permute(0, 3, 2, 1, 4).contiguous().view(B * T, 3 * H * 64)
+
+
+@pytest.mark.parametrize("B,T,H,K2", [(3, 197, 8, 0), (40, 197, 8, 0), (7, 50, 12, 64), (2, 13, 2, 0), (110, 197, 8, 0)])
+def test_gemm_store_qkv_head_major_is_a_permutation_of_the_plain_store(ops, B, T, H, K2):
+    """EPI_STORE_QKV_HM writes exactly the values of EPI_STORE, at [b][h][which][t][64] (every tile kernel: 128x128 at small M, the 8-phase
+    256x256 kernel from ~150 tiles on; ragged last tiles)."""
+    from gslora_hip import _lib as L
+    M, N, K = B * T, 3 * H * 64, 512
+    A, W = rnd(M, K, seed=1).cuda().bfloat16(), rnd(N, K, seed=2, scale=K ** -0.5).cuda().bfloat16()
+    A2 = W2 = None
+    if K2:
+        A2, W2 = rnd(M, K2, seed=3).cuda().bfloat16(), rnd(N, K2, seed=4, scale=0.1).cuda().bfloat16()
+    ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, ref, A2=A2, W2=W2)
+    ops.gemm_nt(A, W, out, A2=A2, W2=W2, epilogue=L.EPI_STORE_QKV_HM, T=T)
+    assert torch.equal(out, _to_head_major(ref, B, T, H))
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 197, 8), (2, 26, 1), (70, 197, 8), (5, 150, 4), (3, 224, 2), (2, 64, 2)])
+def test_attention_head_major_input_bit_identical_to_token_major(ops, B, T, H):
+    """Forward, backward and the cls-row backward of the bf16 attention kernels read the head-major qkv layout with the same arithmetic
+    in the same order: o, lse and (token-major) dqkv are bit-identical."""
+    scale = 64 ** -0.5
+    qkv = (rnd(B * T, 3 * H * 64, seed=5)).cuda().bfloat16()
+    d_o = rnd(B * T, H * 64, seed=6).cuda().bfloat16()
+    hm = _to_head_major(qkv, B, T, H)
+    o0, l0 = ops.attention_fwd(qkv, B, T, H, scale)
+    o1, l1 = ops.attention_fwd(hm, B, T, H, scale, layout=1)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    g0 = ops.attention_bwd(qkv, o0, d_o, l0, B, T, H, scale)
+    g1 = ops.attention_bwd(hm, o0, d_o, l0, B, T, H, scale, layout=1)
+    assert torch.equal(g0, g1)
+    d_cls = d_o.view(B, T, H * 64)[:, 0].contiguous()
+    c0 = ops.attention_bwd_cls(qkv, o0, d_cls, l0, B, T, H, scale)
+    c1 = ops.attention_bwd_cls(hm, o0, d_cls, l0, B, T, H, scale, layout=1)
+    assert torch.equal(c0, c1)
