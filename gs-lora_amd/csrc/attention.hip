@@ -551,6 +551,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
   __shared__ __attribute__((aligned(16))) float del_s[TP];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const bool nostore = hm & 2;      // development ablation (GSL_ATTN_ABL=4): no output stores
+  hm &= 1;
   const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
   const bf16_t* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * T * HD : (size_t)b * T * ld + h * HD);
   const bf16_t* dob = d_o + (size_t)b * T * ldo + h * HD;
@@ -560,15 +562,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
   const int ktf = T >> 4;      // key tiles below this index are completely valid
   const float c2 = scale * 1.4426950408889634f;
   // ------------------------------------------------------------------ phase A: dQ (and delta, kept in LDS)
+  Frag qf0, qf1, dof0, dof1;      // Q / dO fragments of the wave's current query tile (kept past phase A: they are deposited into the phase-B panels)
   {
-    bf16x8_t qf0, qf1;
-    Frag dof0, dof1, of0, of1;
+    Frag of0, of1;
     auto load_tile = [&](int qt) {
       const int qrc = min(qt * 16 + fr, T - 1);
       const bf16_t* qrow = qb + (size_t)qrc * ldi;
       const bf16_t* dorow = dob + (size_t)qrc * ldo;
       const bf16_t* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
-      qf0 = gl_frag(qrow, 0, fc); qf1 = gl_frag(qrow, 1, fc);
+      qf0.v = gl_frag(qrow, 0, fc); qf1.v = gl_frag(qrow, 1, fc);
       dof0.v = gl_frag(dorow, 0, fc); dof1.v = gl_frag(dorow, 1, fc);
       of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
     };
@@ -606,8 +608,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
           continue;
         }
         f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 0, fc), qf0, sa);
-        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 1, fc), qf1, sa);
+        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 0, fc), qf0.v, sa);
+        sa = mfma16(lds_frag_rm(P0, kt * 16 + fr, 1, fc), qf1.v, sa);
         dp = mfma16(lds_frag_rm(P1, kt * 16 + fr, 0, fc), dof0.v, dp);
         dp = mfma16(lds_frag_rm(P1, kt * 16 + fr, 1, fc), dof1.v, dp);
         float ds[4];
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(P0, dt, pr, lane), dsf[pr].v, acc);
-        if (qr < T) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, scale);
+        if (qr < T && !nostore) store4bf(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + fc * 4, acc, scale);
       }
       if (fc == 0 && qr < T) del_s[qr] = dl;
     }
@@ -641,41 +643,58 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
     kf[0] = gl_frag(krow, 0, fc); kf[1] = gl_frag(krow, 1, fc);
     vf[0] = gl_frag(vrow, 0, fc); vf[1] = gl_frag(vrow, 1, fc);
   };
-  // The Q / dO panels of phase B: with nwaves < nqt < 2 nwaves (T = 197: 13 tiles, 8 waves) the last 2 nwaves - nqt waves have no
-  // second query tile in phase A — they fetch the panels into registers while the others finish (the rows >= T of both panels stay
-  // zero from the K / V staging), and put them into LDS after the barrier. Otherwise every thread stages after the barrier.
+  // The Q / dO panels of phase B. Every wave still holds the Q / dO fragments of the LAST query tile it processed in the operand layout
+  // (lane (fr, fc): row fr, 16-byte chunk fc of each 32-column half) — exactly a ds_write_b128 into the row-major panel — so those
+  // rows never come from global memory again. Only the FIRST tiles of the waves that ran two tiles (tiles 0 .. nqt - nwaves - 1: 5 of 13
+  // at T = 197) are re-read: the waves without a second tile fetch them into registers while the others finish. Rows >= T of both
+  // panels stay zero from the K / V staging. (Before: all 13 tiles of both panels were re-read, 412 MB per launch at B = 1024.)
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  constexpr int NPF = 18;
-  const int first_early = nqt - nwaves, tot = 2 * T * 8;
-  const int net = (nwaves - first_early) * 64;                               // threads of the early waves
-  const bool pre = first_early > 0 && first_early < nwaves && net * NPF >= tot;      // uniform
+  constexpr int NPF = 12;
+  const int first_early = max(nqt - nwaves, 0);                             // tiles that need the re-read = first tiles of two-tile waves
+  const int prow = min(first_early * 16, T), tot = 2 * prow * 8;           // 16-byte chunks to re-read (Q rows, then dO rows)
+  const int net = (nwaves - first_early) * 64;                               // threads of the waves without a second tile
+  const bool pre = first_early < nwaves && net * NPF >= tot;                 // uniform (nqt <= 14, 8 waves: always true)
   const bool early = pre && wave >= first_early;
+  const int last_qt = (wave + nwaves < nqt) ? wave + nwaves : wave;          // the tile whose fragments this wave holds now
   u32x4_t pf[NPF];
-  if (early) {
+  if (early && tot > 0) {
     const int et = (wave - first_early) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
       const int c = min(et + k * net, tot - 1);
-      const int pnl = c >= T * 8, rc = c - pnl * (T * 8);
+      const int pnl = c >= prow * 8, rc = c - pnl * (prow * 8);
       const bf16_t* src = pnl ? dob + (size_t)(rc >> 3) * ldo : qb + (size_t)(rc >> 3) * ldi;
       pf[k] = *reinterpret_cast<const u32x4_t*>(src + (rc & 7) * 8);
     }
   }
-  load_keys(wave);
+  // the K / V fragments of the wave's FIRST key tile come out of the K / V panels that are still in LDS (rows >= T are zero there; such
+  // rows are never stored): 8 of the 13 tiles' second read of K and V never leaves the CU (-250 MB per launch at B = 1024)
+  kr = wave * 16 + fr;
+  kf[0] = lds_frag_rm(P0, kr, 0, fc); kf[1] = lds_frag_rm(P0, kr, 1, fc);
+  vf[0] = lds_frag_rm(P1, kr, 0, fc); vf[1] = lds_frag_rm(P1, kr, 1, fc);
+  // (the second tile's fragments — waves 0 .. 4 at T = 197 — stay global loads: holding them across the panel re-staging costs 13
+  //  spilled VGPRs under the 128-register cap and 60 us, measured)
   GSL_ATTN_STAMP(2);      // wave 0 done with its phase-A tiles
   __syncthreads();             // every wave is done with the K / V panels (and del_s is complete)
   GSL_ATTN_STAMP(3);
   if (pre) {
-    if (early) {
+    if (early && tot > 0) {
       const int et = (wave - first_early) * 64 + lane;
 #pragma unroll
       for (int k = 0; k < NPF; ++k) {
         const int c = et + k * net;
         if (c < tot) {
-          const int pnl = c >= T * 8, rc = c - pnl * (T * 8);
+          const int pnl = c >= prow * 8, rc = c - pnl * (prow * 8);
           *reinterpret_cast<u32x4_t*>((pnl ? P1 : P0) + lds_off(rc >> 3, (rc & 7) * 8)) = pf[k];
         }
       }
+    }
+    const int dr = last_qt * 16 + fr;          // deposit the held tile (tiles >= nqt do not exist: waves past the last tile hold nothing)
+    if (last_qt < nqt && dr < T) {
+      *reinterpret_cast<uint4*>(P0 + lds_off(dr, fc * 8)) = qf0.u;
+      *reinterpret_cast<uint4*>(P0 + lds_off(dr, 32 + fc * 8)) = qf1.u;
+      *reinterpret_cast<uint4*>(P1 + lds_off(dr, fc * 8)) = dof0.u;
+      *reinterpret_cast<uint4*>(P1 + lds_off(dr, 32 + fc * 8)) = dof1.u;
     }
   } else {
     stage_rowmajor<TP>(P0, qb, ldi, T);
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
 #pragma unroll 1
     for (int qp = 0; qp < (FAST ? NKT / 2 - 1 : NKT / 2); ++qp) pair_step(qp, std::false_type{});
     if constexpr (FAST) pair_step(NKT / 2 - 1, std::true_type{});
-    if (kr < T) {
+    if (kr < T && !nostore) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16_t* base = dqkv + ((size_t)b * T + kr) * ld + h * HD + dt * 16 + fc * 4;
@@ -1033,7 +1052,7 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       const char* sp = getenv("GSL_ATTN_STAMPS");
       unsigned long long* stp = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr;
-      if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+      if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0));
       else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
