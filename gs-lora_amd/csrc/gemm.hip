@@ -177,13 +177,16 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   const size_t rowoff0 = (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);     // copy-out: lane's row 0 of the wave tile
   // STORE_QKV_HM: row m = b T + t of the wave's 64 columns (one (q|k|v, head) panel) goes to [b][h][which][t][64]; the lane walks its
   // rows in steps of 8, so (b, t) is divided out once and advanced incrementally
-  int hb = 0, ht = 0;
-  size_t hpanel = 0;
+  int ht = 0;
+  size_t hrow = 0, hwrap = 0;        // running element offset of the lane's current row inside [b][h][which]; what a wrap into the next image adds
   if constexpr (EPI == GSL_EPI_STORE) {
     if (e.hmT) {
-      hb = (mw + crow) / e.hmT; ht = (mw + crow) - hb * e.hmT;
+      const int hb = (mw + crow) / e.hmT;
+      ht = (mw + crow) - hb * e.hmT;
       const int pn = nw >> 6, which = pn / e.hmH, h = pn - which * e.hmH;
-      hpanel = ((size_t)h * 3 + (size_t)which) * (size_t)e.hmT * 64 + (size_t)(cch * 8);
+      const size_t img = (size_t)e.hmH * 3 * (size_t)e.hmT * 64;
+      hrow = (size_t)hb * img + ((size_t)h * 3 + (size_t)which) * (size_t)e.hmT * 64 + (size_t)ht * 64 + (size_t)(cch * 8);
+      hwrap = img - (size_t)e.hmT * 64;
     }
   }
   constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
@@ -240,7 +243,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           // element offset = this lane's first row + a wave-uniform row step (scalar multiply): no per-store 64-bit multiply
           size_t off = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
           if constexpr (EPI == GSL_EPI_STORE) {
-            if (e.hmT) off = (size_t)hb * ((size_t)e.hmH * 3 * (size_t)e.hmT * 64) + hpanel + (size_t)ht * 64;
+            if (e.hmT) off = hrow;
           }
           if (dst) store_stream16(dst + off, val, e.stmode);
           if constexpr (NOUT == 2 && !SEQ) {
@@ -251,7 +254,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           }
         }
         if constexpr (EPI == GSL_EPI_STORE) {
-          if (e.hmT) { ht += 8; while (ht >= e.hmT) { ht -= e.hmT; ++hb; } }
+          if (e.hmT) { ht += 8; hrow += 8 * 64; while (ht >= e.hmT) { ht -= e.hmT; hrow += hwrap; } }
         }
       }
     }
