@@ -559,3 +559,25 @@ def test_prototype_label_outside_table_is_loud():
     assert torch.isfinite(ok)
     assert torch.isnan(engine_cl.get_prototype_loss(emb, torch.tensor([0, 1, 2, 0], device="cuda"), proto))      # class 1: hole in the table
     assert torch.isnan(engine_cl.get_prototype_loss(emb, torch.tensor([0, 2, 7, 0], device="cuda"), proto))      # class 7: beyond the table
+
+
+@pytest.mark.parametrize("cfgname", ["small2", "full"])
+def test_bf16_step_identical_in_both_qkv_layouts(monkeypatch, cfgname):
+    """The head-major qkv stash (default in bf16 mode) and the token-major one (GSLORA_QKV_LAYOUT=tm) run the same arithmetic in the same
+    order — the QKV GEMM's store only permutes, the attention kernels only address differently: logits, embeddings, loss and every
+    LoRA gradient of a training step with dropout are BIT-IDENTICAL."""
+    from gslora_hip import vit_runner
+    cfg, b = (recipe.cfg_small2(), 6) if cfgname == "small2" else (recipe.cfg_full(), 2)
+    proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
+    xr, yr, xf, yf = batches(cfg, b)
+    res = {}
+    for hm in (True, False):
+        monkeypatch.setattr(vit_runner, "QKV_HEAD_MAJOR", hm)
+        torch.manual_seed(7)                       # the dropout stream is seeded from torch's seed when the runner is built
+        m = build(cfg, "bf16", dropout=0.1).train()
+        total, aux = total_loss(m, xr, yr, xf, yf, HYPER, proto)
+        total.backward()
+        res[hm] = (aux["logits_r"].detach().clone(), aux["emb_r"].detach().clone(), total.detach().clone(), lora_grads(m))
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    for k, v in res[True][3].items():
+        assert np.array_equal(v, res[False][3][k]), k
