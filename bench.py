@@ -35,9 +35,12 @@ FULL = dict(image_size=112, patch_size=8, dim=512, depth=6, heads=8, mlp_dim=204
 HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-4, BND=105.0, BND_pro=18.0, pro_f=0.01, pro_r=0.01)
 # minimal necessary FLOPs per image (2 m n k, no recompute, no dW of frozen weights)
 FLOP_IMG_ALG = 15.646e9
-# what this path executes: the last block's backward runs on the B cls rows only (its stream gradient is exactly zero elsewhere), i.e.
-# one generic-layer backward (1.43065 GFLOP/img) shrinks to 1/197 of its rows
-FLOP_IMG_EXEC = FLOP_IMG_ALG - 1.43065e9 * (196.0 / 197.0)
+# what this path executes: the head pools the cls token and everything behind a block's attention is token-wise, so in the LAST block
+# only the cls query's attention output and the cls rows of out-proj / LayerNorm / FFN are ever consumed. Its backward (one generic-layer
+# backward, 1.43065 GFLOP/img) and the forward behind its QKV projection (QK^T + PV 0.07948, out-proj 0.10328, FFN 0.82628, LoRA
+# 0.01614 = 1.02518 GFLOP/img) shrink to 1/197 of their rows. Exact (no output of the model depends on the skipped rows); the
+# fractions of the MFMA peak below are quoted on section 8(d)'s ALGORITHMIC count, the executed count is carried beside it.
+FLOP_IMG_EXEC = FLOP_IMG_ALG - (1.43065e9 + 1.02518e9) * (196.0 / 197.0)
 T_TOK = 197
 
 

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o_cls, const float* __restrict__ lse,
-                                                           T* __restrict__ dqkv, int Tn, int H, float scale, int hm) {
+                                                           T* __restrict__ dqkv, int Tn, int H, float scale, int hm, int cls_compact) {
   __shared__ float q0[HD], g0[HD], red[32][HD];
   __shared__ float sD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -928,12 +928,12 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
   if (tid < HD) {
     q0[tid] = Elem<T>::ld(qb + tid);
     g0[tid] = Elem<T>::ld(d_o_cls + (size_t)b * ldo + h * HD + tid);
-    float v = g0[tid] * Elem<T>::ld(o + (size_t)b * Tn * ldo + h * HD + tid);
+    float v = g0[tid] * Elem<T>::ld(o + (size_t)b * (cls_compact ? 1 : Tn) * ldo + h * HD + tid);
     v = wave_sum(v);
     if (tid == 0) sD = v;
   }
   __syncthreads();
-  const float D = sD, l0 = lse[((size_t)b * H + h) * Tn];
+  const float D = sD, l0 = lse[((size_t)b * H + h) * (cls_compact ? 1 : Tn)];
   const int grp = tid >> 3, sub = tid & 7;      // 32 row groups x 8 lanes; lane `sub` owns head dims sub*8 .. sub*8+7
   float qs[8], gs[8], dq[8];
 #pragma unroll
@@ -980,22 +980,110 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
   }
 }
 
+// Forward of the same case: in the LAST block only the cls query's output is ever consumed (the head pools x[:, 0] and everything after
+// the attention is token-wise), so its attention is one query row per (image, head) against the full K / V panels — a streaming
+// softmax-weighted sum, HBM-bound on the K / V rows (8 lanes per row as above). o_cls [B, H*64], lse_cls [B, H].
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__ qkv, T* __restrict__ o_cls, float* __restrict__ lse_cls,
+                                                           int Tn, int H, float scale, int hm) {
+  __shared__ float q0[HD], sc[256], red[32][HD];
+  __shared__ float sm[16];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)Tn * HD : (long)H * HD;
+  const T* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * Tn * HD : (size_t)b * Tn * ld + h * HD);
+  const int tid = threadIdx.x;
+  if (tid < HD) q0[tid] = Elem<T>::ld(qb + tid);
+  __syncthreads();
+  const int grp = tid >> 3, sub = tid & 7;
+  float qs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qs[i] = q0[sub * 8 + i];
+  for (int j0 = 0; j0 < Tn; j0 += 32) {
+    const int j = j0 + grp;
+    const int jc = j < Tn ? j : Tn - 1;
+    const T* kr = qb + (size_t)jc * ldi + ko + sub * 8;
+    float kv[8];
+    Elem<T>::ld4(kr, kv); Elem<T>::ld4(kr + 4, kv + 4);
+    float sdot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sdot = fmaf(qs[i], kv[i], sdot);
+#pragma unroll
+    for (int sh = 1; sh < 8; sh <<= 1) sdot += __shfl_xor(sdot, sh, 64);
+    if (j < Tn && sub == 0) sc[j] = sdot * scale;
+  }
+  __syncthreads();
+  float m = -3.0e38f;
+  for (int j = tid; j < Tn; j += 256) m = fmaxf(m, sc[j]);
+  m = block_max(m, sm);
+  float e = 0.f;
+  for (int j = tid; j < Tn; j += 256) { const float p = expf(sc[j] - m); sc[j] = p; e += p; }
+  e = block_sum(e, sm);        // (its barriers also publish the p values)
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int j0 = 0; j0 < Tn; j0 += 32) {
+    const int j = j0 + grp;
+    if (j < Tn) {
+      const T* vr = qb + (size_t)j * ldi + 2 * ko + sub * 8;
+      float vv[8];
+      Elem<T>::ld4(vr, vv); Elem<T>::ld4(vr + 4, vv + 4);
+      const float p = sc[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vv[i], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[grp][sub * 8 + i] = acc[i];
+  __syncthreads();
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) t += red[g][tid];       // fixed order
+    Elem<T>::st(o_cls + (size_t)b * ldo + h * HD + tid, t / e);
+  }
+  if (tid == 0) lse_cls[(size_t)b * H + h] = m + logf(e);
+}
+
+extern "C" int gsl_attention_fwd_cls(const void* qkv, void* o_cls, float* lse_cls, int B, int T, int H, float scale, int dtype,
+                                     int qkv_layout, gsl_stream_t s) {
+  GSL_CHECK_ARG(qkv && o_cls && lse_cls && B > 0 && T > 1 && T <= 256 && H > 0, "null/size (T <= 256)");
+  GSL_CHECK_ARG(qkv_layout == 0 || qkv_layout == 1, "qkv_layout: 0 token-major, 1 head-major");
+  const dim3 grid(B * H), blk(256);
+  if (dtype == GSL_BF16)
+    hipLaunchKernelGGL(attn_fwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (bf16_t*)o_cls, lse_cls, T, H, scale, qkv_layout);
+  else if (dtype == GSL_F32)
+    hipLaunchKernelGGL(attn_fwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (float*)o_cls, lse_cls, T, H, scale, qkv_layout);
+  else return fail(GSL_ERR_ARG, "gsl_attention_fwd_cls: bad dtype%s %ld", "", dtype);
+  return check_launch("gsl_attention_fwd_cls");
+}
+
 extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv, int B,
-                                     int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s) {
+                                     int T, int H, float scale, int dtype, int qkv_layout, int cls_compact, gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o && d_o_cls && lse && dqkv && B > 0 && T > 1 && H > 0, "null/size");
   GSL_CHECK_ARG(qkv_layout == 0 || qkv_layout == 1, "qkv_layout: 0 token-major, 1 head-major");
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)o,
-                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale, qkv_layout);
+                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale, qkv_layout, cls_compact);
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)o,
-                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale, qkv_layout);
+                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale, qkv_layout, cls_compact);
   else return fail(GSL_ERR_ARG, "gsl_attention_bwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd_cls");
 }
 
-static inline int attn_persistent() { const char* e = getenv("GSL_ATTN_PERSISTENT"); return e ? atoi(e) : 1; }   // dev: 0 = one item per workgroup
+// Development knobs (libgslora_hip_dev.so only; the product library reads nothing from the environment):
+//   GSL_ATTN_PERSISTENT=0 one item per workgroup; GSL_ATTN_ABL=1 staging only, 2 no staging; GSL_ATTN_BWD_SPLIT=1 the two-kernel backward;
+//   GSL_ATTN_NT key tiles per wave of the dK/dV kernel; GSL_ATTN_STAMPS device address of a cycle-stamp buffer.
+#ifdef GSL_DEV
+static inline int attn_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline unsigned long long* attn_stamps() { const char* sp = getenv("GSL_ATTN_STAMPS"); return sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
+#else
+static inline constexpr int attn_env(const char*, int dflt) { return dflt; }
+static inline constexpr unsigned long long* attn_stamps() { return nullptr; }
+#endif
+static inline int attn_persistent() { return attn_env("GSL_ATTN_PERSISTENT", 1); }
 static inline int attn_num_cus() {
   static int n = 0;
   if (!n) {
@@ -1005,7 +1093,7 @@ static inline int attn_num_cus() {
   }
   return n;
 }
-static inline int attn_abl() { const char* e = getenv("GSL_ATTN_ABL"); return e ? atoi(e) : 0; }   // dev: 1 staging only, 2 no staging
+static inline int attn_abl() { return attn_env("GSL_ATTN_ABL", 0); }
 
 // =====================================================================================
 // C ABI
@@ -1047,17 +1135,16 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     if (T <= 64) {
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
       hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
-    } else if (!getenv("GSL_ATTN_BWD_SPLIT") || atoi(getenv("GSL_ATTN_BWD_SPLIT")) == 0) {
+    } else if (attn_env("GSL_ATTN_BWD_SPLIT", 0) == 0) {
       // (a persistent wave-specialised form like the forward's was measured slower here: 795 vs 736 us at B = 1024 — its four
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
-      const char* sp = getenv("GSL_ATTN_STAMPS");
-      unsigned long long* stp = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr;
+      unsigned long long* stp = attn_stamps();
       if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0));
       else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
-      { const char* nt = getenv("GSL_ATTN_NT");     // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us
-        if (!nt || atoi(nt) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
+      {       // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us
+        if (attn_env("GSL_ATTN_NT", 1) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
         else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 2>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm); }
     }
   } else if (dtype == GSL_F32) {

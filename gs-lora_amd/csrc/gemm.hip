@@ -29,7 +29,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 struct EpiArgs {
   float alpha;
   const float* bias;
-  const float* res;
+  const void* res;     // f32 (BIAS_RES_F32) or the operand dtype (BIAS_RES_BF16)
   const void* aux;
   void* out;
   void* out2;
@@ -70,7 +70,8 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     }
   }
   float bq[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_PATCH) {
+  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_PATCH || EPI == GSL_EPI_BIAS_RES_BF16 ||
+                EPI == GSL_EPI_PATCH_BF16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[i] = bp ? bp[i] : e.bias[n + i];
   }
@@ -81,7 +82,13 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     }
   } else if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
     float r[4], dm[4];
-    Elem<float>::ld4(e.res + off, r);
+    Elem<float>::ld4(reinterpret_cast<const float*>(e.res) + off, r);
+    drop_mul4(e.drop, lin, dm);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
+  } else if constexpr (EPI == GSL_EPI_BIAS_RES_BF16) {      // the residual stream in the operand dtype: f32 arithmetic, one rounding on store
+    float r[4], dm[4];
+    Elem<T>::ld4(reinterpret_cast<const T*>(e.res) + off, r);
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
@@ -103,7 +110,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     Elem<T>::ld4(reinterpret_cast<const T*>(e.aux) + off, a);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= a[i];
-  } else if constexpr (EPI == GSL_EPI_PATCH) {
+  } else if constexpr (EPI == GSL_EPI_PATCH || EPI == GSL_EPI_PATCH_BF16) {
     const int tok = m % e.T;
     float dm[4];
     drop_mul4(e.drop, lin, dm);
@@ -480,7 +487,7 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
     for (int r = 0; r < 8; ++r) {
       const int m = min(mw + q * 32 + r * 4 + crow, e.M - 1);
       if constexpr (EPI == GSL_EPI_PATCH) rs[r] = *reinterpret_cast<const f32x4_t*>(e.pos + (size_t)(m % e.T) * e.N + min(n, e.N - 4));
-      else rs[r] = *reinterpret_cast<const f32x4_t*>(e.res + (size_t)m * e.ldo + min(n, e.N - 4));
+      else rs[r] = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(e.res) + (size_t)m * e.ldo + min(n, e.N - 4));
     }
   };
   f32x4_t rsa[8], rsb[8];      // BIAS_RES_F32: the residual rows; PATCH: the position-embedding rows of the tokens (vit_face.py:531-537)
@@ -517,6 +524,82 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
         for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
       }
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
+    }
+  }
+}
+// BIAS_RES_BF16 / PATCH_BF16 epilogue (bf16 speed mode with the FORWARD residual stream in bf16: out-proj, FFN2 forward, patch
+// embedding): x_out = bf16( dropout(acc + bias) + f32(x_in) ) — f32 arithmetic on the f32 accumulator, ONE rounding on store. Same
+// staging as the f32-stream epilogue above; the residual is loaded and the result stored as full 128-byte rows (8 lanes x 16 B per
+// row, 8 rows per instruction): half the epilogue bytes of the f32 stream. 64 rows per round, the residual rows of round q + 1 are
+// requested before round q is processed. The dropout mask is the one of the f32-stream epilogue (same element index, same hash).
+template <int NI, int EPI>
+__device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+  const int crow = lane >> 3, cch = lane & 7;
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(e.res);
+  bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
+  const int n = nw + cch * 8, ncl = min(n, e.N - 8);
+  float b8[8], c8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { b8[k] = e.bias[ncl + k]; c8[k] = 0.f; }
+  if constexpr (EPI == GSL_EPI_PATCH_BF16) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c8[k] = e.cls[ncl + k];
+  }
+  constexpr int NQ = NI / 4;
+  auto fetch = [&](int q, uint4 (&rs)[8]) {
+    if constexpr (EPI == GSL_EPI_BIAS_RES_BF16) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int m = min(mw + q * 64 + r * 8 + crow, e.M - 1);
+        rs[r] = *reinterpret_cast<const uint4*>(res + (size_t)m * e.ldo + ncl);
+      }
+    }
+  };
+  uint4 rsa[8], rsb[8];
+  fetch(0, rsa);
+  const uint32_t rowstep = e.drop.thr ? (uint32_t)((4u * (uint32_t)e.N) * DROP_PHI) : 0u;      // 8 rows further = 4 N element pairs
+  uint32_t w0 = e.drop.thr ? drop_w0(e.drop.key, ((uint64_t)(mw + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    uint4 (&rs)[8] = (q & 1) ? rsb : rsa;
+    if (q + 1 < NQ) fetch(q + 1, (q & 1) ? rsa : rsb);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t v = acc[q * 4 + ii][j];
+        if (e.alpha != 1.0f) v *= e.alpha;
+        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+      }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = r * 8 + crow;
+      const int m = mw + q * 64 + row;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
+      const float c[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      float dm[8], o[8];
+      drop_mul4_w(e.drop, w0, dm);
+      drop_mul4_w(e.drop, w0 + 2u * DROP_PHI, dm + 4);
+      w0 += rowstep;
+      if constexpr (EPI == GSL_EPI_PATCH_BF16) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout (vit_face.py:531-537)
+        const int tok = min(m, e.M - 1) % e.T;
+        const float* pr = e.pos + (size_t)tok * e.N + ncl;
+        const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pr), p1 = *reinterpret_cast<const f32x4_t*>(pr + 4);
+        const float pp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = ((tok == 0 ? c8[k] : c[k] + b8[k]) + pp[k]) * dm[k];
+      } else {
+        const uint32_t a[4] = {rs[r].x, rs[r].y, rs[r].z, rs[r].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[2 * k] = (c[2 * k] + b8[2 * k]) * dm[2 * k] + __uint_as_float(a[k] << 16);
+          o[2 * k + 1] = (c[2 * k + 1] + b8[2 * k + 1]) * dm[2 * k + 1] + __uint_as_float(a[k] & 0xffff0000u);
+        }
+      }
+      if (m < e.M && n < e.N)
+        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])), e.stmode);
     }
   }
 }
@@ -736,90 +819,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
     }
 }
 
-// ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 2-stage LDS-DMA
-// The per-CU LDS-DMA fill rate measured on this chip (~12-14 B/clk/CU, profiles/r01_*) bounds a tile
-// by its bytes per flop: 256x256x64 moves 64 KB per 8.4 MFLOP (7.6 B/kFLOP) against 15.3 B/kFLOP for
-// 128x128. 8 waves (2 x 4), each 128x64 (acc 8x4 fragments = 128 VGPRs), two 64 KB stages, next tile's DMA
-// in flight during the 64 MFMAs per wave of the current one; raw s_barrier + explicit vmcnt.
+// 256x256 output tile of the 8-phase kernel (and of the development variants in gemm_dev_*.inc)
 constexpr int BM4 = 256, BN4 = 256, ST4 = (BM4 + BN4) * BK;
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_t256_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                             const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                             const bf16_t* __restrict__ A2, int lda2,
-                                                             const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  resolve_drop(e.drop);
-  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4 > CST_BLOCK8) ? 2 * ST4 : CST_BLOCK8];   // stages, then C staging
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nbn = (e.N + BN4 - 1) / BN4;
-  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
-  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
-  const int lrow = lane >> 3, lc = lane & 7;
-
-  auto issue = [&](int kt) {
-    bf16_t* st = smem + (kt & 1) * ST4;
-    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
-    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
-    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rb = wave * 4 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
-      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BM4 * BK + rb * 8 * BK), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fc = lane >> 4;
-
-  issue(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1);
-    const bf16_t* As = smem + (kt & 1) * ST4;
-    const bf16_t* Ws = As + BM4 * BK;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t wf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + fr;
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = wm * 128 + i * 16 + fr;
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-  if constexpr (!epi_out_is_f32<EPI>()) {
-    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
-      __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
-      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
-      return;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4<EPI, bf16_t>(e, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
-    }
-}
+#ifdef GSL_DEV
+#include "gemm_dev_a.inc"
+#endif
 
 struct LoraInk {
   const bf16_t* P; int ldp;
@@ -923,7 +927,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   }
 
   // development: cycle stamps (kernel start, prologue landed, K loop done, epilogue done) of every 64th workgroup
+#ifdef GSL_DEV
   unsigned long long* dbg8 = (e.stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0 && tid == 0) ? e.stamps + (blockIdx.x / 64) * 4 : nullptr;
+#else
+  constexpr unsigned long long* dbg8 = nullptr;
+#endif
   if (dbg8) dbg8[0] = __builtin_readcyclecounter();
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
@@ -1107,6 +1115,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       return;
     }
   }
+  if constexpr (EPI == GSL_EPI_BIAS_RES_BF16 || EPI == GSL_EPI_PATCH_BF16) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0 && e.N >= 8 && (EPI != GSL_EPI_PATCH_BF16 || e.ldo == e.N)) {
+      __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
+      epilogue_staged_res_bf16<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+      if (dbg8) dbg8[3] = __builtin_readcyclecounter();
+      return;
+    }
+  }
   if constexpr (!epi_out_is_f32<EPI>()) {
     if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
@@ -1131,798 +1147,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
 }
 
-// ------------------------------------------------------------------ 256x256 kernel with the LoRA rank-r term computed IN the kernel
-//   out = epilogue( A·Wᵀ + t·Qᵀ ),  t = s·(A·Pᵀ)  [M, r],   P [16, K] (rows >= r zero), Q [N, 32] (cols >= r zero)
-// A workgroup streams the whole K range of its 256 rows anyway, so the down-projection t = s·A·Pᵀ costs 16 extra output
-// columns (2 extra MFMAs per 32 per wave and k-step, P rides along in the W stage) instead of a separate launch that re-reads
-// the [M, K] activation from HBM (413-826 MB per call). After the K loop t goes through LDS (C layout -> operand layout),
-// one more MFMA k-step applies the rank-r update, and the N-tile-0 workgroups store t (bf16, zero padded to 64 columns) for
-// the LoRA-gradient reductions. Replaces loralib.Linear's (x @ Aᵀ @ Bᵀ)·scaling (vit_face.py:330,333) and its autograd.
-
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_t256_lora_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                                  const bf16_t* __restrict__ W1, int ldw1, int K1, LoraInk lk,
-                                                                  EpiArgs e) {
-  resolve_drop(e.drop);
-  __shared__ __attribute__((aligned(16))) bf16_t smem[(2 * ST4L > CST_BLOCK8) ? 2 * ST4L : CST_BLOCK8];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nbn = (e.N + BN4 - 1) / BN4;
-  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
-  const int nk = K1 / BK;
-  const int lrow = lane >> 3, lc = lane & 7;
-
-  auto issue = [&](int kt) {
-    bf16_t* st = smem + (kt & 1) * ST4L;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rb = wave * 4 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
-      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(A1 + (size_t)gm * lda1 + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(W1 + (size_t)gn * ldw1 + k0 + c * 8), (lptr_t)(st + BM4 * BK + rb * 8 * BK), 16, 0, 0);
-    }
-    if (wave < 2) {   // the 16 rows of P (2 KB) ride along: one extra DMA for waves 0 and 1
-      const int row = wave * 8 + lrow, c = lc ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(lk.P + (size_t)row * lk.ldp + k0 + c * 8), (lptr_t)(st + (BM4 + BN4) * BK + wave * 8 * BK), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[8][4], accp[2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  accp[0] = accp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fc = lane >> 4;
-
-  issue(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1);
-    const bf16_t* As = smem + (kt & 1) * ST4L;
-    const bf16_t* Ws = As + BM4 * BK;
-    const bf16_t* Ps = Ws + BN4 * BK;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t wf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + fr;
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
-      }
-      const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(Ps + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = wm * 128 + i * 16 + fr;
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
-        if ((i >> 1) == wn)   // wave-uniform: the 4 waves of a row-half split its 8 row fragments of the 16 extra columns
-          accp[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, af, accp[i & 1], 0, 0, 0);
-      }
-    }
-  }
-  // ---- t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg]  -> LDS [256][32] bf16 (cols 16..31 = 0)
-  __builtin_amdgcn_s_barrier();                      // stages are free
-  bf16_t* tbuf = smem;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    bf16_t* d = tbuf + (wm * 128 + (2 * wn + t) * 16 + fr) * 32 + fc * 4;
-    *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
-    *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
-  }
-  __builtin_amdgcn_s_barrier();
-  if (n0 == 0 && lk.tout) {                          // one N-tile stores t for the gradient reductions: [M, 64], zero padded
-    const int row = tid >> 1, half = tid & 1;
-    if (m0 + row < e.M) {
-      bf16_t* dst = lk.tout + (size_t)(m0 + row) * lk.ldt + half * 32;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint4 v = half ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(tbuf + row * 32 + c * 8);
-        *reinterpret_cast<uint4*>(dst + c * 8) = v;
-      }
-    }
-  }
-  {   // rank-r update: one more k-step (k = 32: r live columns)
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
-      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
-    }
-  }
-  if constexpr (!epi_out_is_f32<EPI>()) {
-    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
-      __builtin_amdgcn_s_barrier();                  // everyone has read tbuf: the C staging may overwrite it
-      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
-      return;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4<EPI, bf16_t>(e, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
-    }
-}
-
-// ------------------------------------------------------------------ 256x128x32 tile, 3-stage ring, TWO workgroups per CU
-// 72 KB of LDS and <= 128 VGPRs: two workgroups (16 waves) share a CU and drift out of phase, so one's epilogue
-// (VALU-heavy for BIAS_GELU) runs under the other's MFMA loop. BK = 32 rows are 64 B in LDS; chunk position =
-// c ^ SWZ[(row >> 2) & 3], SWZ = {0,2,3,1}: every ds_read_b128 lane group hits 16 distinct 16-byte slots (0 conflicts
-// measured). Each wave issues 3 DMA instructions per K tile -> vmcnt(3) per tile in flight. bf16 outputs are staged
-// through the (then idle) ring memory, one output at a time (SEQ) so that the staging also fits in 72 KB.
-constexpr int BK9 = 32, ST9 = (256 + 128) * BK9;
-constexpr int SM9 = (3 * ST9 > 8 * 64 * CLD) ? 3 * ST9 : 8 * 64 * CLD;
-__device__ __forceinline__ int swz9(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // {0,2,3,1}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_k32x2_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                                 const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                                 const bf16_t* __restrict__ A2, int lda2,
-                                                                 const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  resolve_drop(e.drop);
-  __shared__ __attribute__((aligned(16))) bf16_t smem[SM9];
-  __shared__ __attribute__((aligned(16))) float bias_s[128];     // the tile's 128 bias values (read per fragment in the epilogue)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (e.N + 127) / 128;
-  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int m0 = (tile / nbn) * 256, n0 = (tile % nbn) * 128;
-  if (tid < 128) bias_s[tid] = (e.bias && n0 + tid < e.N) ? e.bias[n0 + tid] : 0.f;      // visible after the K loop's barriers
-  const int nk1 = K1 / BK9, nk = nk1 + K2 / BK9;
-  const int lrow = lane >> 2, lc = lane & 3;
-
-  auto issue = [&](int kt) {
-    bf16_t* st = smem + (kt % 3) * ST9;
-    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
-    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK9; }
-    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK9; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rb = wave * 2 + i, row = rb * 16 + lrow, c = lc ^ swz9(row);
-      const int gm = min(m0 + row, e.M - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 16 * BK9), 16, 0, 0);
-    }
-    {
-      const int rb = wave, row = rb * 16 + lrow, c = lc ^ swz9(row);
-      const int gn = min(n0 + row, e.N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + 256 * BK9 + rb * 16 * BK9), 16, 0, 0);
-    }
-  };
-
-  // Two workgroups share a CU. Launched together they would stay in lock step (both in the MFMA loop, then both in the
-  // VALU/store epilogue); delaying the workgroups that fill the SECOND slot of every CU (the dispatcher hands out blocks
-  // 0..255 first) by about half a tile puts the pair out of phase for the rest of the launch: one's epilogue runs under
-  // the other's MFMAs. e.T carries the delay (units of s_sleep 127 = 8128 clocks); placement-independent for correctness.
-  if (e.T > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    for (int d = 0; d < e.T; ++d) __builtin_amdgcn_s_sleep(127);
-  }
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fc = lane >> 4;
-
-  issue(0);
-  if (nk > 1) issue(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(kt + 2);
-    const bf16_t* As = smem + (kt % 3) * ST9;
-    const bf16_t* Ws = As + 256 * BK9;
-    bf16x8_t af[4], wf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wm * 64 + i * 16 + fr;
-      af[i] = *reinterpret_cast<const bf16x8_t*>(As + row * BK9 + ((fc ^ swz9(row)) << 3));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wn * 64 + j * 16 + fr;
-      wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + row * BK9 + ((fc ^ swz9(row)) << 3));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-  }
-  if constexpr (!epi_out_is_f32<EPI>()) {
-    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
-      __builtin_amdgcn_s_barrier();            // every wave is done with the ring: reuse it for C staging
-      epilogue_staged_bf16<EPI, 4, true>(e, acc, smem + wave * (64 * CLD), m0 + wm * 64, n0 + wn * 64, lane, bias_s + wn * 64);
-      return;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
-    }
-}
-
-// ------------------------------------------------------------------ bf16 MFMA kernel, persistent ping-pong schedule
-// One workgroup per CU, two groups of four waves (one wave of each group per SIMD). In every SLOT one group runs the K loop of its
-// 128x256 output tile (wave tile 128x64, 32 MFMAs per 32-deep K slice) while the other group runs the EPILOGUE of the tile it finished
-// in the previous slot (bias / GELU / GELU' / dropout on the VALU, LDS staging, full-row stores); then they swap. The matrix pipe and the
-// VALU are separate pipes of a SIMD, so the epilogue — which the 256x256 kernel above runs after its K loop with nothing to overlap —
-// executes under the other group's MFMAs. Both groups hit the same s_barrier once per K slice ("phase"): the K group needs it for the
-// LDS ring, the epilogue group paces its 32 output fragments over the phases.
-//   * LDS ring: 5 slots of one 32-deep K slice each (A 128 x 32 + W 256 x 32 bf16 = 24 KB; rows of 64 B, 16-byte chunks swizzled with
-//     SWZ = {0,2,3,1}[(row >> 2) & 3] on the DMA source and on the fragment read). In phase p the K group multiplies slice p from
-//     registers, reads slice p+1 from LDS into the other register set, and issues the LDS-DMA of slice p+4 into the slot slice p-1 left;
-//     the counted wait at the end of phase p (vmcnt(12): two younger slices in flight) retires slice p+2 one barrier before it is read.
-//   * the slice stream does not stop at a tile boundary: in the last four phases of a slot the K group has nothing left to fetch, and the
-//     OTHER group (its epilogue is finished by then) issues the first four slices of ITS next tile into the slots that fall free, so a
-//     K loop starts with its pipeline full. A group therefore issues, counts and waits for its own DMAs only; its (older) output stores
-//     can only make a counted wait conservative — loads retire in order, and no store is issued between a DMA and its wait.
-//   * persistent tile order: a workgroup walks the N tiles of one 128-row A panel (half a panel when the N-tile count is even; the two
-//     halves run on workgroups b and b^8, i.e. on one XCD), group 0 / group 1 taking alternate tiles: the A panel is fetched from HBM
-//     once and re-read from L2 by the same CU.
-// Epilogues: STORE (alpha, bias) and BIAS_GELU (two bf16 outputs); bf16 outputs only (N % 8 == 0, ldo % 8 == 0).
-constexpr int PP_TM = 128, PP_TN = 256, PP_BK = 32;
-constexpr int PP_A_B = PP_TM * PP_BK * 2;                      // 8192: A part of a slot (bytes)
-constexpr int PP_SLOT_B = (PP_TM + PP_TN) * PP_BK * 2;         // 24576
-constexpr int PP_NSLOT = 5;
-constexpr int PP_RING_B = PP_NSLOT * PP_SLOT_B;                // 122880
-constexpr int PP_CST_B = 2 * 16 * CLD * 2;                     // 4608 per wave: two outputs x 16 rows x 72 bf16
-constexpr int PP_BIAS_B = 64 * 4;                              // 256 per wave: the wave's 64 bias values
-constexpr int PP_SMEM_B = PP_RING_B + 4 * PP_CST_B + 8 * PP_BIAS_B;   // 143360 of 163840
-
-typedef unsigned int u32x4_pp __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t pp_lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);
-}
-__device__ __forceinline__ void pp_lds_write_b64(uint32_t addr, uint2 v) {
-  const unsigned long long q = ((unsigned long long)v.y << 32) | v.x;
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(q) : "memory");
-}
-__device__ __forceinline__ u32x4_pp pp_lds_read_b128(uint32_t addr) {      // the caller waits (lgkmcnt) before it uses the value
-  u32x4_pp r;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-  return r;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                           const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                           const bf16_t* __restrict__ A2, int lda2,
-                                                           const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  static_assert(EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU, "ping-pong kernel: bf16-output epilogues");
-  resolve_drop(e.drop);
-  __shared__ __attribute__((aligned(16))) char smem[PP_SMEM_B];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
-  const int fr = lane & 15, fc = lane >> 4;
-  const int nk1 = K1 / 64, nk = nk1 + K2 / 64;
-  const int NB = 2 * nk;                                       // phases (barriers) per slot
-  // ---- this workgroup's tile stream
-  const int ntm = (e.M + PP_TM - 1) / PP_TM, ntn = (e.N + PP_TN - 1) / PP_TN;
-  const int up = (ntn % 2 == 0) ? 2 : 1, tpu = ntn / up;
-  const int nunits = ntm * up;
-  const int G = gridDim.x, b = blockIdx.x;
-  const int pb = (up == 2 && (G % 16) == 0) ? ((((b >> 4) * 8 + (b & 7)) << 1) | ((b >> 3) & 1)) : b;
-  const int my_units = (pb < nunits) ? (nunits - pb + G - 1) / G : 0;
-  const int n_tiles = my_units * tpu;
-  // tile t of this workgroup's unit ui: rows of panel u / up, N tile (u % up) * tpu + t   (up is 1 or 2)
-  auto tile_of = [&](int ui, int t, int& m0, int& n0) {
-    const int u = ui * G + pb;
-    m0 = ((up == 2) ? (u >> 1) : u) * PP_TM;
-    n0 = (((up == 2) ? (u & 1) : 0) * tpu + t) * PP_TN;
-  };
-
-  // ---- DMA of one K slice (slice x of the tile at (m0, n0)) into ring position rp: this wave's 2 A + 4 W instructions (16 rows each)
-  const int lrow = lane >> 2, lc = lane & 3;
-  const int csw = (lc ^ swz9(lrow)) * 8;                       // source chunk (elements); (row >> 2) & 3 == (lrow >> 2) & 3 for every 16-row block
-  const int abl = e.T;      // development ablation bits (GSL_PP_ABL): 1 A DMA from 16 hot rows, 2 W DMA from 16 hot rows, 8 no DMA, 16 no epilogue math, 32 no output stores
-  auto dma_slice = [&](int m0, int n0, int x, int rp) {
-    if (abl & 8) return;
-    const int kk = x >> 1, half = x & 1;
-    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
-    if (kk < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kk * 64 + half * 32; }
-    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kk - nk1) * 64 + half * 32; }
-    char* slot = smem + rp * PP_SLOT_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rb = w4 * 2 + i;
-      const int gm = (abl & 1) ? lrow : min(m0 + rb * 16 + lrow, e.M - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + csw), (lptr_t)(slot + rb * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rb = w4 * 4 + i;
-      const int gn = (abl & 2) ? lrow : min(n0 + rb * 16 + lrow, e.N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + ((abl & 2) ? 0 : k0) + csw), (lptr_t)(slot + PP_A_B + rb * 1024), 16, 0, 0);
-    }
-  };
-  // fragment read offsets inside a slot (bytes): A rows i*16 + fr, W rows w4*64 + j*16 + fr; chunk fc ^ swz9(fr)
-  const int fchunk = (fc ^ swz9(fr)) * 16;
-  const int aoff = fr * 64 + fchunk;
-  const int boff = PP_A_B + (w4 * 64 + fr) * 64 + fchunk;
-
-  f32x4_t acc[8][4];
-  bf16x8_t al[4], ah[4], bf0[4], bf1[4];
-  int ring = 0;            // ring position of slice 0 of the tile whose K loop runs in the current slot
-  float* bias_w = reinterpret_cast<float*>(smem + PP_RING_B + 4 * PP_CST_B) + wave * 64;      // wave-private
-  bf16_t* cst = reinterpret_cast<bf16_t*>(smem + PP_RING_B + w4 * PP_CST_B);                  // shared by waves w4 of both groups (never both in the epilogue role)
-
-  // development: cycle stamps of waves 0 and 4 of workgroup 0 after every barrier (GSL_PP_ABL bit 256, buffer = the unused `res` argument)
-  unsigned long long* dbg = ((abl & 256) && e.res && blockIdx.x == 0 && w4 == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(e.res)) + grp * 1024 : nullptr;
-  int stamp_i = 0;
-#define PP_STAMP()                                                                              \
-  if (dbg) { if (stamp_i < 1024) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) dbg[stamp_i] = t_; } ++stamp_i; }
-  // register operands: the W fragments of a slice (4 x 16 columns) are double buffered per phase, the A fragments per HALF phase
-  // (row fragments 0..3 / 4..7): 64 operand registers beside the 128 accumulators
-#define PP_READ_B(BF, RP)                                                                        \
-  if (!(abl & 128)) { const char* sl_ = smem + (RP) * PP_SLOT_B;                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) BF[j] = *reinterpret_cast<const bf16x8_t*>(sl_ + boff + j * 1024); }
-#define PP_READ_A(AF, RP, HALF)                                                                 \
-  if (!(abl & 128)) { const char* sl_ = smem + (RP) * PP_SLOT_B + (HALF) * 4096;                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = *reinterpret_cast<const bf16x8_t*>(sl_ + aoff + i * 1024); }
-#define PP_MFMA(AF, BF, ROW0, ZERO)                                                             \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
-      acc[(ROW0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(ROW0) + i][j], 0, 0, 0);
-  // one K-role phase: slice p is multiplied from registers (al = row fragments 0..3 and BC already loaded); the upper A half of slice p
-  // and the operands of slice p+1 are read meanwhile, the DMA of slice p+4 is issued, then the counted wait and the barrier
-  // One K-role phase. Every variant is straight-line code (DMA: the slice p+4 exists; NEXT: the slice p+1 exists; VM: the counted wait,
-  // -1 = none) and its instruction mix is pinned: the K wave is alone on its SIMD's matrix pipe, so its LDS reads and DMA issues
-  // must sit BETWEEN its MFMAs, not in front of them; the reads end 8 MFMAs before the phase does, so that the lgkmcnt wait is short.
-#define PP_VMWAIT(VM)                                                                           \
-  if ((VM) == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                             \
-  else if ((VM) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                        \
-  else if ((VM) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          \
-  else if ((VM) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define PP_PHASE(P, BC, BN, ZERO, DMA, NEXT, VM)                                                \
-  {                                                                                             \
-    const int p_ = (P);                                                                         \
-    PP_READ_A(ah, (ring + p_) % PP_NSLOT, 1)                                                    \
-    if (DMA) dma_slice(km0, kn0, p_ + 4, (ring + p_ + 4) % PP_NSLOT);                           \
-    PP_MFMA(al, BC, 0, ZERO)                                                                    \
-    if (NEXT) { PP_READ_B(BN, (ring + p_ + 1) % PP_NSLOT) PP_READ_A(al, (ring + p_ + 1) % PP_NSLOT, 0) } \
-    PP_MFMA(ah, BC, 4, ZERO)                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-    if (DMA) { _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } } \
-    else __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                    \
-    if (NEXT) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); }                            \
-    else __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    PP_VMWAIT(VM)                                                                               \
-    __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0), as a builtin: the compiler's own scoreboard starts the next phase clean */ \
-    if (!(abl & 64)) __builtin_amdgcn_s_barrier();                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    PP_STAMP()                                                                                  \
-  }
-
-  // ---- prologue: group 0 fills the pipeline of the first tile
-  if (grp == 0 && n_tiles > 0) {
-    int m0, n0;
-    tile_of(0, 0, m0, n0);
-#pragma unroll 1
-    for (int x = 0; x < 4 && x < NB; ++x) dma_slice(m0, n0, x, x);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  int em0 = 0, en0 = 0;     // tile whose epilogue this group owes
-  int cm0 = 0, cn0 = 0, xm0 = 0, xn0 = 0;      // tile s (K role) and tile s+1 (prefetched by the epilogue group)
-  int xui = 0, xt = 0;                          // stream position of tile s+1
-  if (n_tiles > 0) tile_of(0, 0, cm0, cn0);
-  if (n_tiles > 1) { xt = 1; if (xt == tpu) { xt = 0; xui = 1; } tile_of(xui, xt, xm0, xn0); }
-#pragma unroll 1
-  for (int s = 0; s <= n_tiles; ++s) {
-    const bool k_turn = (grp == (s & 1));
-    if (k_turn) {
-      // =============================================================== K role: tile s
-      if (s < n_tiles) {
-        const int km0 = cm0, kn0 = cn0;
-        __builtin_amdgcn_s_setprio(1);
-        float bval = 0.f;
-        { const int n = kn0 + w4 * 64 + lane; if (e.bias && n < e.N) bval = e.bias[n]; }      // older than slice 4's DMA (see the counted waits)
-        PP_READ_B(bf0, ring)
-        PP_READ_A(al, ring, 0)
-        // first K tile (phases 0, 1): the accumulators start from zero in phase 0
-        PP_PHASE(0, bf0, bf1, true, true, true, 13)
-        PP_PHASE(1, bf1, bf0, false, true, true, 13)
-#pragma unroll 1
-        for (int kt = 1; kt + 2 < nk; ++kt) {          // phases 2 .. NB - 5: steady state
-          PP_PHASE(2 * kt, bf0, bf1, false, true, true, 12)
-          PP_PHASE(2 * kt + 1, bf1, bf0, false, true, true, 12)
-        }
-        // the last four phases: this tile's slice stream has run dry (the other group issues the next tile's slices meanwhile)
-        PP_PHASE(NB - 4, bf0, bf1, false, false, true, 6)
-        PP_PHASE(NB - 3, bf1, bf0, false, false, true, 0)
-        PP_PHASE(NB - 2, bf0, bf1, false, false, true, -1)
-        PP_PHASE(NB - 1, bf1, bf0, false, false, false, -1)
-        bias_w[lane] = bval;
-        __builtin_amdgcn_s_setprio(0);
-        em0 = km0; en0 = kn0;
-      } else {
-#pragma unroll 1
-        for (int p = 0; p < NB; ++p) { if (!(abl & 64)) __builtin_amdgcn_s_barrier(); PP_STAMP() }
-      }
-    } else {
-      // =============================================================== epilogue role: tile s-1; prefetch for tile s+1
-      const bool has_tile = (s >= 1);
-      const bool has_next = (s + 1 < n_tiles);
-      const int nm0 = xm0, nn0 = xn0;
-      int p = 0;
-      const int PE = (NB > 4) ? NB - 4 : 1;
-      int quota = (32 + PE - 1) / PE;             // fragments that must be done before phase p may end: ceil((p + 1) * 32 / PE)
-      auto end_phase = [&]() {
-        if (has_next && p >= NB - 4) dma_slice(nm0, nn0, p - (NB - 4), (ring + p + 4) % PP_NSLOT);
-        if (has_next && p == NB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        if (!(abl & 64)) __builtin_amdgcn_s_barrier();
-        PP_STAMP()
-        ++p;
-        quota = ((p + 1) * 32 + PE - 1) / PE;
-      };
-      if (has_tile) {
-        const int mw = em0, nw = en0 + w4 * 64;
-        const int crow = lane >> 3, cch = lane & 7;
-        float bj[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias_w + j * 16 + fc * 4);
-          bj[j][0] = b4[0]; bj[j][1] = b4[1]; bj[j][2] = b4[2]; bj[j][3] = b4[3];
-        }
-        constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
-        constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
-        uint32_t wrow = 0u, rowstep = 0u;
-        if constexpr (DROPW) {
-          if (e.drop.thr) {
-            wrow = drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1);
-            rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
-          }
-        }
-        const bool full = (mw + PP_TM <= e.M) && (nw + 64 <= e.N);
-        bf16_t* o1 = reinterpret_cast<bf16_t*>(e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
-        bf16_t* o2 = e.out2 ? reinterpret_cast<bf16_t*>(e.out2) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8) : nullptr;
-        const size_t step8 = (size_t)8 * (size_t)e.ldo;
-        const uint32_t cst_a = pp_lds_addr(cst + fr * CLD + fc * 4);             // fragment-layout staging address (column fragment j: + 32 bytes)
-        const uint32_t cst_r = pp_lds_addr(cst + crow * CLD + cch * 8);          // row-layout read-back address
-        int done = 0;
-        // runtime loop over the 8 row fragments (16-row chunks) of the wave tile: the accumulators of chunk i are moved into a fixed
-        // register set first (static register indices everywhere; 16 moves per 1024 outputs)
-#pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
-          f32x4_t t4[4];
-          switch (i) {
-#define PP_CASE(I) case I: t4[0] = acc[I][0]; t4[1] = acc[I][1]; t4[2] = acc[I][2]; t4[3] = acc[I][3]; break;
-            PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) PP_CASE(4) PP_CASE(5) PP_CASE(6) default: t4[0] = acc[7][0]; t4[1] = acc[7][1]; t4[2] = acc[7][2]; t4[3] = acc[7][3]; break;
-#undef PP_CASE
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v[4] = {t4[j][0], t4[j][1], t4[j][2], t4[j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
-            const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
-            if (!(abl & 16) && (full || (m < e.M && n < e.N))) {
-              if constexpr (EPI == GSL_EPI_STORE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * e.alpha + bj[j][r];
-              } else {
-                epi_math<EPI, bf16_t, DROPW>(e, m, n, v, g, bj[j], wrow + (uint32_t)(j * 8) * DROP_PHI);
-              }
-            }
-            // staging through inline asm: the compiler would put s_waitcnt vmcnt(0) in front of every LDS access of a code path that also
-            // issues LDS-DMAs (they may alias for all it knows) — here that would drain this wave's output stores once per fragment
-            pp_lds_write_b64(cst_a + j * 32, make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])));
-            if constexpr (NOUT == 2) pp_lds_write_b64(cst_a + j * 32 + 16 * CLD * 2, make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3])));
-            ++done;
-            // pace: phase p may end once ceil((p + 1) * 32 / PE) fragments are done (the last four phases carry the next tile's DMAs)
-            while (p < PE && p < NB && done >= quota) end_phase();
-          }
-          wrow += rowstep;
-          // copy this 16-row chunk out as full 128-byte rows (the wave's DS operations execute in order: no barrier needed)
-          {
-            u32x4_pp val[2], val2[2];
-            val[0] = pp_lds_read_b128(cst_r);
-            val[1] = pp_lds_read_b128(cst_r + 8 * CLD * 2);
-            if constexpr (NOUT == 2) { val2[0] = pp_lds_read_b128(cst_r + 16 * CLD * 2); val2[1] = pp_lds_read_b128(cst_r + 24 * CLD * 2); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const int mm = mw + i * 16 + r * 8 + crow, nn = nw + cch * 8;
-              if (!(abl & 32) && (full || (mm < e.M && nn < e.N))) {
-                __builtin_nontemporal_store(val[r], reinterpret_cast<u32x4_pp*>(o1 + (size_t)r * step8));
-                if constexpr (NOUT == 2) { if (o2) __builtin_nontemporal_store(val2[r], reinterpret_cast<u32x4_pp*>(o2 + (size_t)r * step8)); }
-              }
-            }
-          }
-          o1 += 2 * step8;
-          if constexpr (NOUT == 2) { if (o2) o2 += 2 * step8; }
-        }
-      }
-      while (p < NB) end_phase();
-    }
-    // next slot: tile s+1 becomes the K tile, the stream advances
-    cm0 = xm0; cn0 = xn0;
-    if (s + 2 < n_tiles) { ++xt; if (xt == tpu) { xt = 0; ++xui; } tile_of(xui, xt, xm0, xn0); }
-    ring = (ring + NB) % PP_NSLOT;
-  }
-#undef PP_READ_A
-#undef PP_READ_B
-#undef PP_MFMA
-#undef PP_PHASE
-#undef PP_STAMP
-#undef PP_VMWAIT
-}
-
-// ------------------------------------------------------------------ bf16 MFMA kernel, in-wave software-pipelined epilogue ("iw")
-// What profiles/r02_pp_pingpong.md taught: for the fused FFN1 the epilogue's VALU work (~35 issue slots per output) equals the tile's
-// matrix-pipe work, a wave issues one instruction per ~4.5 cycles, and a wave that is alone on its SIMD hides nothing. So here EVERY wave
-// carries both streams: it keeps TWO accumulator sets (its 64x64 tile of the current 128x256 workgroup tile and of the previous one),
-// and each 32-deep K slice ("step": 8 fragment reads, 3 LDS-DMA issues, 16 MFMAs) of the current tile carries the epilogue of ONE 16x16
-// fragment of the previous tile (bias / GELU / GELU' / dropout, packed into a wave-private LDS chunk; every fourth step the 16-row chunk
-// is copied out as full 128-byte rows). The two instruction streams are independent, both waves of a SIMD run them, and the step body is
-// straight-line code whose MFMA : VALU mix is pinned with sched_group_barrier. 16 fragments over the 2*NK >= 16 steps of a tile.
-//   * persistent: a workgroup walks the N tiles of (half) a 128-row A panel, the 5-slot slice ring and its DMA stream run across tile
-//     boundaries (steps NB-4 .. NB-1 fetch the next tile's first slices);
-//   * counted waits: vmcnt retires in issue order on gfx9 / CDNA (loads and stores; LLVM's own waitcnt insertion relies on it), so the
-//     wait for slice p+1 at the end of step p is vmcnt(9) — the 9 DMA instructions of slices p+2 .. p+4 may stay in flight; output
-//     stores that are younger than those can only make it wait longer;
-//   * full tiles only (M % 128 == 0, N % 256 == 0, K = NK * 64 with NK in {8, 9}): no bounds tests inside a step. Other shapes run on the
-//     8-phase kernel.
-constexpr int IW_TM = 128, IW_TN = 256;
-constexpr int IW_A_B = IW_TM * 32 * 2;                         // 8192
-constexpr int IW_SLOT_B = (IW_TM + IW_TN) * 32 * 2;            // 24576
-constexpr int IW_NSLOT = 5;
-constexpr int IW_RING_B = IW_NSLOT * IW_SLOT_B;                // 122880
-constexpr int IW_CST_B = 2 * 16 * CLD * 2;                     // 4608 per wave
-constexpr int IW_BIAS_B = 2 * 64 * 4;                          // 512 per wave: bias of the current and of the previous tile
-constexpr int IW_SMEM_B = IW_RING_B + 8 * IW_CST_B + 8 * IW_BIAS_B;   // 163840: all of the CU's LDS
-
-__device__ __forceinline__ void iw_lds_write_b32(uint32_t addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-
-template <int EPI, int NK>
-__global__ __launch_bounds__(512) void gemm_bf16_iw_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                           const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                           const bf16_t* __restrict__ A2, int lda2,
-                                                           const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
-  static_assert(EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU, "iw kernel: bf16-output epilogues");
-  static_assert(NK >= 8, "16 output fragments are spread over the 2 NK steps of a tile");
-  constexpr int NB = 2 * NK;
-  constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
-  resolve_drop(e.drop);
-  __shared__ __attribute__((aligned(16))) char smem[IW_SMEM_B];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 15, fc = lane >> 4;
-  const int nk1 = K1 / 64;
-  // ---- tile stream (as in the ping-pong kernel): unit = (half) an A panel, its N tiles are consecutive
-  const int ntm = e.M / IW_TM, ntn = e.N / IW_TN;
-  const int up = (ntn % 2 == 0) ? 2 : 1, tpu = ntn / up;
-  const int nunits = ntm * up;
-  const int G = gridDim.x, b = blockIdx.x;
-  const int pb = (up == 2 && (G % 16) == 0) ? ((((b >> 4) * 8 + (b & 7)) << 1) | ((b >> 3) & 1)) : b;
-  const int my_units = (pb < nunits) ? (nunits - pb + G - 1) / G : 0;
-  const int n_tiles = my_units * tpu;
-  if (n_tiles == 0) return;
-  auto tile_of = [&](int ui, int t, int& m0, int& n0) {
-    const int u = ui * G + pb;
-    m0 = ((up == 2) ? (u >> 1) : u) * IW_TM;
-    n0 = (((up == 2) ? (u & 1) : 0) * tpu + t) * IW_TN;
-  };
-  // ---- DMA: a slice = 8 A row blocks + 16 W row blocks of 16 rows; wave w issues blocks w, w + 8, w + 16
-  // addresses: wave-uniform 64-bit base (SALU) + one 32-bit per-lane byte offset per operand panel (no per-lane 64-bit pointers)
-  const int lrow = lane >> 2, lc = lane & 3;
-  const int csw = (lc ^ swz9(lrow)) * 8;
-  const uint32_t la1 = (uint32_t)(((wave * 16 + lrow) * lda1 + csw) * 2), la2 = (uint32_t)(((wave * 16 + lrow) * lda2 + csw) * 2);
-  const uint32_t lw1 = (uint32_t)(((wave * 16 + lrow) * ldw1 + csw) * 2), lw2 = (uint32_t)(((wave * 16 + lrow) * ldw2 + csw) * 2);
-  auto dma_slice = [&](int m0, int n0, int x, int rp) {
-    const int kk = x >> 1, half = x & 1;
-    const bool seg1 = kk < nk1;
-    const int k0 = (seg1 ? kk : kk - nk1) * 64 + half * 32;
-    const char* Au = reinterpret_cast<const char*>(seg1 ? A1 : A2) + ((size_t)m0 * (size_t)(seg1 ? lda1 : lda2) + (size_t)k0) * 2;
-    const char* Wu = reinterpret_cast<const char*>(seg1 ? W1 : W2) + ((size_t)n0 * (size_t)(seg1 ? ldw1 : ldw2) + (size_t)k0) * 2;
-    const size_t w8 = (size_t)(seg1 ? ldw1 : ldw2) * 256;          // 128 W rows further (row block + 8)
-    const uint32_t la = seg1 ? la1 : la2, lw = seg1 ? lw1 : lw2;
-    char* slot = smem + rp * IW_SLOT_B;
-    // development ablation (GSL_PP_ABL through e.T): 1 = no A DMA, 2 = no W DMA (wrong results; measures what the DMA stream costs)
-    if (!(e.T & 1)) __builtin_amdgcn_global_load_lds((gptr_t)(Au + la), (lptr_t)(slot + wave * 1024), 16, 0, 0);
-    if (!(e.T & 2)) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wu + lw), (lptr_t)(slot + IW_A_B + wave * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wu + w8 + lw), (lptr_t)(slot + IW_A_B + (wave + 8) * 1024), 16, 0, 0);
-    }
-  };
-  const int fchunk = (fc ^ swz9(fr)) * 16;
-  const int aoff = (wm * 64 + fr) * 64 + fchunk;
-  const int boff = IW_A_B + (wn * 64 + fr) * 64 + fchunk;
-  bf16_t* cst = reinterpret_cast<bf16_t*>(smem + IW_RING_B + wave * IW_CST_B);
-  const uint32_t bias_a = pp_lds_addr(smem + IW_RING_B + 8 * IW_CST_B + wave * IW_BIAS_B);
-  const int crow = lane >> 3, cch = lane & 7;
-  const uint32_t cst_a = pp_lds_addr(cst + fr * CLD + fc * 4);
-  const uint32_t cst_r = pp_lds_addr(cst + crow * CLD + cch * 8);
-
-  f32x4_t accc[4][4], accp[4][4];          // current tile (K loop) / previous tile (epilogue)
-  bf16x8_t af[4], bf[4];
-  u32x4_pp bnx;                             // bias values of the next step's fragment (read from LDS one step ahead)
-  int ring = 0, par = 0;                    // par: LDS bias slot of the CURRENT tile (the previous tile's is par ^ 1)
-  // per-tile epilogue state of the PREVIOUS tile
-  bf16_t* o1 = nullptr; bf16_t* o2 = nullptr;
-  uint32_t wrow = 0u;
-  const uint32_t rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
-  const size_t step8 = (size_t)8 * (size_t)e.ldo;
-
-  using IC0 = std::integral_constant<int, 0>;
-  // development (GSL_P8_STAMPS): workgroup 64 accumulates, per wave row, the cycles of the three parts of a step over all its steps:
-  // [0] the MFMA block, [1] everything else up to the waits in front of the barrier, [2] the barrier itself
-  const bool dbgon = e.stamps && blockIdx.x == 64;
-  unsigned long long dsum0 = 0, dsum1 = 0, dsum2 = 0, dlast = 0;
-  auto mfma_blk = [&](auto zc) {            // the 16 MFMAs of one 32-deep slice on the fragments in af / bf
-    constexpr bool Z = decltype(zc)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], Z ? f32x4_t{0.f, 0.f, 0.f, 0.f} : accc[i][j], 0, 0, 0);
-  };
-  // one step = one 32-deep K slice of the current tile (KON) + one output fragment of the previous tile (EON).
-  // The two waves of a SIMD (wave w and w + 4: wave rows 0 and 1) run in ANTI-PHASE: row 0 does fragment reads, DMA issue and the
-  // epilogue arithmetic first and its 16 MFMAs last; row 1 (R1) starts a step with the MFMAs of the PREVIOUS step (operands kept in
-  // registers across the barrier) and then reads / issues / does its epilogue arithmetic — so in every half of a step one wave
-  // feeds the matrix pipe while the other one owns the VALU port, instead of both waiting on LDS and then queueing on the pipe.
-  // Both rows read slice P between the same two barriers: the ring hazards are those of the unstaggered form.
-  auto step = [&](auto pc, auto konc, auto eonc, auto rowc, int km0, int kn0, int nm0, int nn0) {
-    constexpr int P = decltype(pc)::value;
-    constexpr bool KON = decltype(konc)::value, EON = decltype(eonc)::value, R1 = decltype(rowc)::value;
-    unsigned long long t0 = 0, t1 = 0;
-    if (dbgon) { t0 = __builtin_readcyclecounter(); if (dlast) dsum2 += t0 - dlast; __builtin_amdgcn_sched_barrier(0); }
-    if constexpr (KON && R1 && P > 0) {
-      mfma_blk(std::integral_constant<bool, P == 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      if (dbgon) { t1 = __builtin_readcyclecounter(); dsum0 += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
-    }
-    if constexpr (KON) {
-      const char* sl = smem + ((ring + P) % IW_NSLOT) * IW_SLOT_B;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(sl + boff + j * 1024);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sl + aoff + i * 1024);
-      // slice P + 4: of this tile, or the first slices of the next one (a workgroup without a next tile re-reads its own: no branch)
-      if constexpr (P + 4 < NB) dma_slice(km0, kn0, P + 4, (ring + P + 4) % IW_NSLOT);
-      else dma_slice(nm0, nn0, P + 4 - NB, (ring + P + 4) % IW_NSLOT);
-    }
-    if constexpr (EON && P < 16) {
-      constexpr int I = P >> 2, J = P & 3;
-      float v[4] = {accp[I][J][0], accp[I][J][1], accp[I][J][2], accp[I][J][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
-      const float bq[4] = {__uint_as_float(bnx[0]), __uint_as_float(bnx[1]), __uint_as_float(bnx[2]), __uint_as_float(bnx[3])};
-      if constexpr (EPI == GSL_EPI_STORE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * e.alpha + bq[r];
-      } else {
-        epi_math<EPI, bf16_t, true>(e, 0, 0, v, g, bq, wrow + (uint32_t)(J * 8) * DROP_PHI);
-      }
-      pp_lds_write_b64(cst_a + J * 32, make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])));
-      if constexpr (NOUT == 2) pp_lds_write_b64(cst_a + J * 32 + 16 * CLD * 2, make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3])));
-    }
-    if constexpr (KON && !R1) {
-      __builtin_amdgcn_sched_barrier(0);       // reads, DMA issue and the epilogue arithmetic above; this row's MFMAs close the step
-      if (dbgon) { t1 = __builtin_readcyclecounter(); dsum1 += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
-      mfma_blk(std::integral_constant<bool, P == 0>{});
-      if (dbgon) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_readcyclecounter(); dsum0 += t1 - t0; t0 = t1; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (EON && P < 16 && (P & 3) == 3) {
-      // chunk (P >> 2) complete: copy its 16 rows out as full 128-byte rows (the wave's own DS operations execute in order)
-      u32x4_pp val[2], val2[2];
-      val[0] = pp_lds_read_b128(cst_r);
-      val[1] = pp_lds_read_b128(cst_r + 8 * CLD * 2);
-      if constexpr (NOUT == 2) { val2[0] = pp_lds_read_b128(cst_r + 16 * CLD * 2); val2[1] = pp_lds_read_b128(cst_r + 24 * CLD * 2); }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        __builtin_nontemporal_store(val[r], reinterpret_cast<u32x4_pp*>(o1 + (size_t)r * step8));
-        if constexpr (NOUT == 2) __builtin_nontemporal_store(val2[r], reinterpret_cast<u32x4_pp*>(o2 + (size_t)r * step8));
-      }
-      o1 += 2 * step8;
-      if constexpr (NOUT == 2) o2 += 2 * step8;
-      wrow += rowstep;
-    }
-    // bias of the next step's fragment (column fragment (P + 1) & 3 of the previous tile): covered by the lgkmcnt wait below
-    if constexpr (EON && P + 1 < 16) bnx = pp_lds_read_b128(bias_a + (uint32_t)((par ^ 1) * 256 + (((P + 1) & 3) * 16 + fc * 4) * 4));
-    if constexpr (KON) {
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            // slice P + 1 has landed (slices P + 2 .. P + 4 may still fly)
-      __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0)
-      if (dbgon) { __builtin_amdgcn_sched_barrier(0); dlast = __builtin_readcyclecounter(); dsum1 += dlast - t0; __builtin_amdgcn_sched_barrier(0); }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto tile_rows = [&](auto konc, auto eonc, auto rowc, int km0, int kn0, int nm0, int nn0) {
-    constexpr bool KON = decltype(konc)::value, R1 = decltype(rowc)::value;
-    float bval = 0.f;
-    if constexpr (KON) { if (e.bias) bval = e.bias[kn0 + wn * 64 + lane]; }
-    [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-      (step(std::integral_constant<int, Ps>{}, konc, eonc, rowc, km0, kn0, nm0, nn0), ...);
-    }(std::make_integer_sequence<int, NB>{});
-    if constexpr (KON && R1) {               // row 1 still owes the MFMAs of the tile's last slice (before the accumulators are handed over)
-      mfma_blk(std::false_type{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (KON) iw_lds_write_b32(bias_a + (uint32_t)(par * 256 + lane * 4), bval);      // this tile's bias, for its epilogue during the next tile
-  };
-  const bool row1 = (wm == 1) && !(e.T & 512);      // development ablation (GSL_PP_ABL bit 512): both wave rows in phase
-  auto tile_body = [&](auto konc, auto eonc, int km0, int kn0, int nm0, int nn0) {
-    if (row1) tile_rows(konc, eonc, std::true_type{}, km0, kn0, nm0, nn0);
-    else tile_rows(konc, eonc, std::false_type{}, km0, kn0, nm0, nn0);
-  };
-  // hand the finished tile over to the epilogue side
-  auto hand_over = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) accp[i][j] = accc[i][j];
-    par ^= 1;                                                     // the finished tile's bias slot is now "previous"
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    bnx = pp_lds_read_b128(bias_a + (uint32_t)((par ^ 1) * 256 + (fc * 4) * 4));      // column fragment 0 of step 0
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-    o1 = reinterpret_cast<bf16_t*>(e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
-    o2 = reinterpret_cast<bf16_t*>(NOUT == 2 ? e.out2 : e.out) + (size_t)(mw + crow) * (size_t)e.ldo + (size_t)(nw + cch * 8);
-    wrow = e.drop.thr ? drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1) : 0u;
-  };
-
-  using T_ = std::true_type; using F_ = std::false_type;
-  int cm0, cn0, xm0, xn0, xui = 0, xt = 0;
-  tile_of(0, 0, cm0, cn0);
-  xm0 = cm0; xn0 = cn0;
-  if (n_tiles > 1) { xt = 1; if (xt == tpu) { xt = 0; xui = 1; } tile_of(xui, xt, xm0, xn0); }
-  // prologue: slices 0 .. 3 of the first tile
-#pragma unroll
-  for (int x = 0; x < 4; ++x) dma_slice(cm0, cn0, x, x);
-  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  // first tile: K loop only
-  tile_body(T_{}, F_{}, cm0, cn0, xm0, xn0);
-  ring = (ring + NB) % IW_NSLOT;
-#pragma unroll 1
-  for (int s = 1; s < n_tiles; ++s) {
-    hand_over(cm0, cn0);
-    cm0 = xm0; cn0 = xn0;
-    if (s + 1 < n_tiles) { ++xt; if (xt == tpu) { xt = 0; ++xui; } tile_of(xui, xt, xm0, xn0); }
-    tile_body(T_{}, T_{}, cm0, cn0, xm0, xn0);
-    ring = (ring + NB) % IW_NSLOT;
-  }
-  // drain: the epilogue of the last tile
-  hand_over(cm0, cn0);
-  tile_body(F_{}, T_{}, 0, 0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (dbgon && lane == 0 && (wave == 0 || wave == 4)) {
-    unsigned long long* d = e.stamps + wm * 4;
-    d[0] = dsum0; d[1] = dsum1; d[2] = dsum2; d[3] = (unsigned long long)n_tiles * NB;
-  }
-}
+#ifdef GSL_DEV
+#include "gemm_dev_b.inc"
+#endif
 
 // ------------------------------------------------------------------ f32 kernel (parity mode)
 template <int EPI>
@@ -1969,24 +1196,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   for (int i = 0; i < 4; ++i) epilogue4<EPI, float>(e, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
 }
 
+// Launch knobs. The product library has none: block-id remap on, K rotation off, non-temporal output stores, no stamps, and the
+// tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
+// the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
+static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
+  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr;
+#ifdef GSL_DEV
+  { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
+  { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
+  { const char* sm = getenv("GSL_STORE_MODE"); if (sm) e.stmode = atoi(sm); }
+  { const char* sp = getenv("GSL_P8_STAMPS"); if (sp) e.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)); }
+#else
+  (void)allow_krot;
+#endif
+}
+
 template <int EPI>
 static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e_in, hipStream_t st) {
   const EpiArgs& e = e_in;
   if (dtype == GSL_BF16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
-    // development knob: 1 = 128x128 single stage, 3 = 256x128 three-stage ring, 4 = 256x256 two-stage, 8 = 256x256 8-phase ping-pong,
-    // 9 = 256x128x32 ring with two workgroups per CU. Defaults measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md):
-    // N >= 512 wants the 256x256 8-phase tile (also for the VALU-heavy BIAS_GELU epilogue since its bias values are preloaded and
-    // full tiles skip the bounds tests: 871 us vs 941 us for the two-workgroup tile 9), skinny N the ring.
-    const char* ev = getenv("GSL_GEMM_VARIANT");
-    // fewer than 128 tiles of 256x256 cannot fill the 256 CUs: the 128x128 kernel (4x the workgroups) wins there (measured at M = 1576:
-    // 15-44 us vs 19-58 us per GEMM); from ~150 tiles on the 8-phase kernel is ahead.
+    // Tile choice, measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md): N >= 512 wants the 256x256 8-phase tile (also for the
+    // VALU-heavy BIAS_GELU epilogue), skinny N the 256x128 ring. Fewer than 128 tiles of 256x256 cannot fill the 256 CUs: the 128x128
+    // kernel (4x the workgroups) wins there (measured at M = 1576: 15-44 us vs 19-58 us per GEMM); from ~150 tiles on the 8-phase
+    // kernel is ahead.   1 = 128x128 single stage, 3 = 256x128 three-stage ring, 8 = 256x256 8-phase ping-pong.
     const long tiles256 = (long)((e.M + 255) / 256) * ((e.N + 255) / 256);
-    int variant = ev ? atoi(ev) : ((e.M < 1024 || tiles256 < 128) ? 1 : (e.N >= 512 ? 8 : 3));
-    if (EPI == GSL_EPI_BIAS_GELU && !ev && variant == 8) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
+    int variant = (e.M < 1024 || tiles256 < 128) ? 1 : (e.N >= 512 ? 8 : 3);
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
+#ifdef GSL_DEV
+    // development knobs: GSL_GEMM_VARIANT = 1 / 3 / 8 or the lab kernels 4 (256x256 two-stage), 9 (256x128x32, two workgroups per CU),
+    // 10 (persistent ping-pong), 11 (in-wave pipelined); GSL_GEMM_ABL = main-loop ablation of the ring kernel (tools/bench_gemm_abl.py)
+    const char* ev = getenv("GSL_GEMM_VARIANT");
+    if (ev) variant = atoi(ev);
+    if (EPI == GSL_EPI_BIAS_GELU && !ev && variant == 8) { const char* gv = getenv("GSL_GELU_VARIANT"); if (gv) variant = atoi(gv); }
     if (variant == 10 && (K1 + K2) >= 192 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && e.N >= 8) {
       if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU) {
         EpiArgs e = e_in;
@@ -2016,22 +1260,24 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         return check_launch("gsl_gemm_nt(iw)");
       }
     }
-    if (variant == 9) {
-      EpiArgs e9 = e;
-      if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }
-      hipLaunchKernelGGL(gemm_bf16_k32x2_kernel<EPI>, dim3(((e.M + 255) / 256) * ((e.N + 127) / 128)), dim3(512), 0, st, (const bf16_t*)A1, lda1,
-                         (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e9);
-    } else if (variant == 8) {
-      const EpiArgs& e8 = e;
-      hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e8);
-    } else if (variant == 4) {
-      GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
-    } else if (variant == 3) {
-      const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);
-      const char* ab = getenv("GSL_GEMM_ABL");   // main-loop ablation (tools/bench_gemm_abl.py), STORE epilogue only
-      const int abl = (ab && EPI == GSL_EPI_STORE) ? atoi(ab) : 0;
-      if constexpr (EPI == GSL_EPI_STORE) {
+    if constexpr (EPI != GSL_EPI_BIAS_RES_BF16 && EPI != GSL_EPI_PATCH_BF16) {
+      if (variant == 9) {
+        EpiArgs e9 = e;
+        if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }
+        hipLaunchKernelGGL(gemm_bf16_k32x2_kernel<EPI>, dim3(((e.M + 255) / 256) * ((e.N + 127) / 128)), dim3(512), 0, st, (const bf16_t*)A1, lda1,
+                           (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e9);
+        return check_launch("gsl_gemm_nt(k32x2)");
+      }
+      if (variant == 4) {
+        GSL_LAUNCH(gemm_bf16_t256_kernel<EPI>, ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4), 512);
+        return check_launch("gsl_gemm_nt(t256)");
+      }
+    }
+    if constexpr (EPI == GSL_EPI_STORE) {
+      const char* ab = getenv("GSL_GEMM_ABL");
+      const int abl = ab ? atoi(ab) : 0;
+      if (variant == 3 && abl) {
+        const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);
         switch (abl) {
           case 1: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 1>), nb3, 512); break;
           case 2: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 2>), nb3, 512); break;
@@ -2040,12 +1286,17 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
           case 5: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 5>), nb3, 512); break;
           case 6: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 6>), nb3, 512); break;
           case 9: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 9>), nb3, 512); break;
-          case 11: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 11>), nb3, 512); break;
-          default: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), nb3, 512);
+          default: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 11>), nb3, 512);
         }
-      } else {
-        GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), nb3, 512);
+        return check_launch("gsl_gemm_nt(ring3 ablation)");
       }
+    }
+#endif
+    if (variant == 8) {
+      hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+    } else if (variant == 3) {
+      GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else {
       GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
     }
@@ -2060,7 +1311,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
 
 extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
                            const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
-                           const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                           const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                            const float* pos, const float* cls, int T, float p_drop, uint64_t seed, uint32_t site,
                            gsl_stream_t s) {
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
@@ -2073,11 +1324,8 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   EpiArgs e;
   e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
-  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
-  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
-  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  set_launch_knobs(e, true);
   e.hmT = 0; e.hmH = 0;
-  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   hipStream_t st = as_stream(s);
   switch (epilogue) {
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -2089,6 +1337,12 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
     case GSL_EPI_BIAS_RES_F32:
       GSL_CHECK_ARG(bias && res, "bias/res required");
       return launch_gemm<GSL_EPI_BIAS_RES_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_BIAS_RES_BF16:
+      GSL_CHECK_ARG(bias && res && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/res required, bf16 only");
+      return launch_gemm<GSL_EPI_BIAS_RES_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_PATCH_BF16:
+      GSL_CHECK_ARG(bias && pos && cls && T > 0 && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/pos/cls/T required, bf16 only");
+      return launch_gemm<GSL_EPI_PATCH_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_GELU:
       GSL_CHECK_ARG(bias, "bias required");
       return launch_gemm<GSL_EPI_BIAS_GELU>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -2104,7 +1358,7 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
 
 extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
                                 int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
-                                const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                                const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
   if (dtype != GSL_BF16) return fail(GSL_ERR_UNSUPPORTED, "gsl_gemm_nt_lora: bf16 only (f32 parity mode uses gsl_gemm_nt with a K segment)%s %ld", "", dtype);
   GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && (K % 64) == 0, "M,N>0, N%4==0, K%64==0");
@@ -2115,27 +1369,33 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   EpiArgs e;
   e.alpha = 1.0f; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
-  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
-  { const char* kr = getenv("GSL_KROT"); e.krot = kr ? atoi(kr) : 0; }
-  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  set_launch_knobs(e, true);
   e.hmT = 0; e.hmH = 0;
-  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
   hipStream_t st = as_stream(s);
+#ifdef GSL_DEV
   const char* ev = getenv("GSL_GEMM_VARIANT");      // development knob: 4 = single-phase 256x256 kernel, default = 8-phase schedule
   const bool old_sched = ev && atoi(ev) == 4;
+#endif
+#ifdef GSL_DEV
+#define GSL_LL_DEV(EPIV)                                                                                                          \
+    if (old_sched) { hipLaunchKernelGGL(gemm_bf16_t256_lora_kernel<EPIV>, dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda,       \
+                                        (const bf16_t*)W, ldw, K, lk, e); break; }
+#else
+#define GSL_LL_DEV(EPIV)
+#endif
 #define GSL_LL(EPIV)                                                                                                              \
   do {                                                                                                                            \
-    if (old_sched) hipLaunchKernelGGL(gemm_bf16_t256_lora_kernel<EPIV>, dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda,         \
-                                      (const bf16_t*)W, ldw, K, lk, e);                                                            \
-    else hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPIV, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W, \
-                            ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);                                \
+    GSL_LL_DEV(EPIV)                                                                                                              \
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPIV, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,     \
+                       ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);                                    \
   } while (0)
   switch (epilogue) {
     case GSL_EPI_STORE: GSL_LL(GSL_EPI_STORE); break;
     case GSL_EPI_BIAS_RES_F32: GSL_CHECK_ARG(bias && res, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_F32); break;
+    case GSL_EPI_BIAS_RES_BF16: GSL_CHECK_ARG(bias && res && (ldo % 8) == 0, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_BF16); break;
     case GSL_EPI_BIAS_GELU: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU); break;
     case GSL_EPI_MUL: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL); break;
     default: return fail(GSL_ERR_ARG, "gsl_gemm_nt_lora: unsupported epilogue%s %ld", "", epilogue);
@@ -2195,11 +1455,8 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   EpiArgs e;
   e.alpha = 1.0f; e.bias = nullptr; e.res = nullptr; e.aux = aux; e.out = out; e.out2 = nullptr; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(0.f, 0, 0); e.M = M; e.N = N;
-  { const char* rm = getenv("GSL_XCD_REMAP"); e.remap = rm ? atoi(rm) : 1; }
-  e.krot = 0;   // every N tile must accumulate t = s A P^T in the same K order: G2 contracts the tile-local t, which has to equal tout bit for bit
-  { const char* sm = getenv("GSL_STORE_MODE"); e.stmode = sm ? atoi(sm) : 1; }
+  set_launch_knobs(e, false);   // K rotation stays off: every N tile must accumulate t = s A P^T in the same K order (G2 contracts the tile-local t, which has to equal tout bit for bit)
   e.hmT = 0; e.hmH = 0;
-  { const char* sp = getenv("GSL_P8_STAMPS"); e.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
   const int R = (r <= 8) ? 8 : 16;
   const int ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;
   const size_t NR = (size_t)N * R;

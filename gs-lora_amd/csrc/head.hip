@@ -59,7 +59,9 @@ extern "C" int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_str
 
 constexpr int HEAD_MAXD = 1024;
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ gamma,
+// X: element type of the residual stream x (f32, or bf16 in speed mode)
+template <typename X>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, int T, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, const float* __restrict__ Wn,
                                                        const int64_t* __restrict__ label, float* __restrict__ emb,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
@@ -68,12 +70,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   __shared__ float e[HEAD_MAXD];
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* xr = x + (size_t)b * T * D;
+  const X* xr = x + (size_t)b * T * D;
   float s = 0.f;
   for (int d = tid; d < D; d += 256) {
-    float pv = xr[d];                               // pool = 'cls': token 0 (vit_face.py:540)
+    float pv = Elem<X>::ld(xr + d);                 // pool = 'cls': token 0 (vit_face.py:540)
     if (pool_mean) {                                // pool = 'mean': x.mean(dim=1) over all T tokens, summed in token order
-      for (int t = 1; t < T; ++t) pv += xr[(size_t)t * D + d];
+      for (int t = 1; t < T; ++t) pv += Elem<X>::ld(xr + (size_t)t * D + d);
       pv = pv / (float)T;
     }
     e[d] = pv; s += pv;
@@ -121,24 +123,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
-extern "C" int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps, const float* Wn,
+extern "C" int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamma, const float* beta, float eps, const float* Wn,
                             const int64_t* label, float* emb, float* mean, float* rstd, float* logits, int B, int D, int C,
                             float cos_s, float cos_m, const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s) {
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || x_dtype == GSL_BF16, "x dtype");
   GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
   GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, as_stream(s), x, T, gamma, beta, eps, Wn, label, emb, mean, rstd,
-                     logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
+  if (x_dtype == GSL_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), (const bf16_t*)x, T, gamma, beta, eps, Wn, label, emb,
+                       mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), (const float*)x, T, gamma, beta, eps, Wn, label, emb,
+                       mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
   return check_launch("gsl_head_fwd");
 }
 
-template <typename T, typename S>
+// compact != 0 (pool = 'cls' only): dx / dxb are [B, D] — the gradient of the cls rows alone; the stream gradient of every other token is
+// exactly zero and is neither written here nor read by the consumers (the cls-row-only backward of the last block, gsl_layernorm_bwd's
+// dres_cls_T). The dropout counter of element (b, d) stays that of the dense tensor, (b*Tn)*D + d: same masks in both forms.
+template <typename T, typename S, typename X>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ demb_in,
-                                                       const float* __restrict__ x, int Tn, const float* __restrict__ gamma,
+                                                       const X* __restrict__ x, int Tn, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ emb, const float* __restrict__ Wn,
                                                        S* __restrict__ dx, T* __restrict__ dxb, int D, int C, float cs,
-                                                       DropCfg drop, int linear, int pool_mean) {
+                                                       DropCfg drop, int linear, int pool_mean, int compact) {
   resolve_drop(drop);
   __shared__ float de[HEAD_MAXD];   // d emb
   __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   // pool = 'cls': zero the non-cls token rows of this image (their stream gradient is exactly 0)
-  if (!pool_mean) {
+  if (!pool_mean && !compact) {
     const long n4 = (long)(Tn - 1) * D / 4;
     {
       S* z = dx + ((size_t)b * Tn + 1) * D;
@@ -178,11 +188,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
   const float proj = block_sum(dotp, sm) / (nrm * nrm);   // (e-hat . d e-hat) / ||e||
   const float mu = mean[b], rs = rstd[b];
-  const float* xr = x + (size_t)b * Tn * D;
+  const X* xr = x + (size_t)b * Tn * D;
   for (int d = tid; d < D; d += 256) {          // the pooled row the forward normalised (same summation order)
-    float pv = xr[d];
+    float pv = Elem<X>::ld(xr + d);
     if (pool_mean) {
-      for (int t = 1; t < Tn; ++t) pv += xr[(size_t)t * D + d];
+      for (int t = 1; t < Tn; ++t) pv += Elem<X>::ld(xr + (size_t)t * D + d);
       pv = pv / (float)Tn;
     }
     xp[d] = pv;
@@ -203,9 +213,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const float xh = (xp[d] - mu) * rs;
     const float g = rs * (de[d] - c1 - xh * c2);
     if (!pool_mean) {
-      const size_t o = (size_t)b * Tn * D + d;
-      Elem<S>::st(dx + o, g);
-      if (dxb) Elem<T>::st(dxb + o, g * drop_mul(drop, (uint64_t)o));
+      const size_t o = (size_t)b * Tn * D + d, oc = compact ? (size_t)b * D + d : o;
+      Elem<S>::st(dx + oc, g);
+      if (dxb) Elem<T>::st(dxb + oc, g * drop_mul(drop, (uint64_t)o));
     } else {                                     // every token receives d pooled / T
       const float gt = g / (float)Tn;
       for (int t = 0; t < Tn; ++t) {
@@ -217,25 +227,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
+extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const void* x, int x_dtype, int T, const float* gamma,
                             const float* mean, const float* rstd, const float* emb, const float* Wn, void* dx, void* dxb,
                             int B, int D, int C, float cos_s, int dtype, int stream_dtype, float p_drop, uint64_t seed, uint32_t site,
-                            int linear_head, int pool_mean, gsl_stream_t s) {
-  GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T > 1, "null/size");
+                            int linear_head, int pool_mean, int compact, gsl_stream_t s) {
+  GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T >= 1, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
   GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
+  GSL_CHECK_ARG(!(compact && pool_mean), "compact cls-row gradients need pool = 'cls'");
   const DropCfg drop = make_drop(p_drop, seed, site);
   GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
-  if (dtype == GSL_BF16 && stream_dtype == GSL_BF16)
-    hipLaunchKernelGGL((head_bwd_kernel<bf16_t, bf16_t>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, (bf16_t*)dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
-  else if (dtype == GSL_BF16)
-    hipLaunchKernelGGL((head_bwd_kernel<bf16_t, float>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, (float*)dx, (bf16_t*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
-  else if (dtype == GSL_F32)
-    hipLaunchKernelGGL((head_bwd_kernel<float, float>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, x, T, gamma, mean, rstd, emb,
-                       Wn, (float*)dx, (float*)dxb, D, C, cos_s, drop, linear_head, pool_mean);
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || (x_dtype == GSL_BF16 && dtype == GSL_BF16), "x dtype (bf16 only in bf16 mode)");
+#define GSL_HB(T_, S_, X_)                                                                                                          \
+  hipLaunchKernelGGL((head_bwd_kernel<T_, S_, X_>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, (const X_*)x, T, gamma, mean, \
+                     rstd, emb, Wn, (S_*)dx, (T_*)dxb, D, C, cos_s, drop, linear_head, pool_mean, compact)
+  if (dtype == GSL_BF16 && stream_dtype == GSL_BF16 && x_dtype == GSL_BF16) GSL_HB(bf16_t, bf16_t, bf16_t);
+  else if (dtype == GSL_BF16 && stream_dtype == GSL_BF16) GSL_HB(bf16_t, bf16_t, float);
+  else if (dtype == GSL_BF16 && x_dtype == GSL_BF16) GSL_HB(bf16_t, float, bf16_t);
+  else if (dtype == GSL_BF16) GSL_HB(bf16_t, float, float);
+  else if (dtype == GSL_F32) GSL_HB(float, float, float);
   else return fail(GSL_ERR_ARG, "gsl_head_bwd: bad dtype%s %ld", "", dtype);
+#undef GSL_HB
   return check_launch("gsl_head_bwd");
 }
 

@@ -328,8 +328,13 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
   hipStream_t st = as_stream(s);
   const int R = (r <= 8) ? 8 : 16;
   int CG, bx, nsplit, rps;
-  { const char* ev = getenv("GSL_LORA_GRAD_MFMA");      // development knob: 0 forces the VALU kernel
+  {
+#ifdef GSL_DEV
+    const char* ev = getenv("GSL_LORA_GRAD_MFMA");      // development knob (dev library only): 0 forces the VALU kernel
     const bool want = !ev || atoi(ev) != 0;
+#else
+    const bool want = true;
+#endif
     if (want && lgm_usable(M, N, ldu, dtype) && (reinterpret_cast<uintptr_t>(U) % 16) == 0 && (reinterpret_cast<uintptr_t>(Y) % 16) == 0 &&
         ((size_t)ldu * 2) % 16 == 0 && ((size_t)ldy * 2) % 16 == 0) {
       lgm_plan(M, N, bx, nsplit, rps);

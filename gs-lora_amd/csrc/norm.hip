@@ -34,8 +34,9 @@ struct RowIO {
   }
 };
 
-template <int NPL, typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long xs, const float* __restrict__ gamma,
+// X: element type of the residual stream (f32; bf16 when the speed mode carries the forward stream in bf16)
+template <int NPL, typename T, typename X>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const X* __restrict__ x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M) {
   constexpr int D = NPL * 64;
@@ -65,12 +66,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // S: element type of the residual-GRADIENT stream (dres in, dx out): f32, or bf16 in speed mode (the stream is re-read and re-written by
 // every LayerNorm backward of the chain: 2 x 413 MB per call at M = 201 728 in f32)
-template <int NPL, typename T, typename S>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, long xs,
+// X: element type of the saved forward residual stream x. cls_T > 0: dres holds only the rows of the cls tokens ([M / cls_T] rows, ios
+// apart); row m receives dres[m / cls_T] when m % cls_T == 0 and nothing otherwise (the stream gradient that leaves the cls-row-only
+// backward of the last block is exactly zero on every other row: no zero-filled dense tensor is written or read).
+template <int NPL, typename T, typename S, typename X>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const X* __restrict__ x, long xs,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const S* dres,
                                                      S* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
-                                                     long drop_row_stride) {
+                                                     long drop_row_stride, int cls_T) {
   resolve_drop(drop);
   constexpr int D = NPL * 64;
   using IO = RowIO<NPL>;
@@ -94,13 +98,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const float c1 = wave_sum(s1) * (1.0f / D), c2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
     for (int i = 0; i < NPL; ++i) gy[i] = rs * (gy[i] - c1 - xv[i] * c2);
-    if (dres) {
+    if (dres && (cls_T == 0 || (row % cls_T) == 0)) {
       float r[NPL];
-      IO::load(dres + (size_t)row * ios, lane, r);
+      IO::load(dres + (size_t)(cls_T ? row / cls_T : row) * ios, lane, r);
 #pragma unroll
       for (int i = 0; i < NPL; ++i) gy[i] += r[i];
     }
-    IO::store(dx + (size_t)row * ios, lane, gy);
+    IO::store(dx + (size_t)row * (cls_T ? (long)D : ios), lane, gy);
     if (dxb) {
       if (drop.thr) {
 #pragma unroll
@@ -121,30 +125,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 template <int NPL>
-static int ln_fwd_launch(const float* x, long xs, const float* gamma, const float* beta, float eps, void* y, float* mean,
-                         float* rstd, int M, int dtype, hipStream_t st) {
+static int ln_fwd_launch(const void* x, long xs, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                         float* rstd, int M, int dtype, int xdtype, hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
-  if (dtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t>), dim3(grid), dim3(256), 0, st, x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
+  if (dtype == GSL_BF16 && xdtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
+  else if (dtype == GSL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t, float>), dim3(grid), dim3(256), 0, st, (const float*)x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, float>), dim3(grid), dim3(256), 0, st, x, xs, gamma, beta, eps, (float*)y, mean, rstd, M);
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, xs, gamma, beta, eps, (float*)y, mean, rstd, M);
   return check_launch("gsl_layernorm_fwd");
 }
 
 template <int NPL>
-static int ln_bwd_launch(const void* dy, const float* x, long xs, const float* gamma, const float* mean, const float* rstd,
-                         const void* dres, void* dx, long ios, void* dxb, int M, int dtype, int sdtype, DropCfg drop, long drs,
-                         hipStream_t st) {
+static int ln_bwd_launch(const void* dy, const void* x, long xs, const float* gamma, const float* mean, const float* rstd,
+                         const void* dres, void* dx, long ios, void* dxb, int M, int dtype, int sdtype, int xdtype, DropCfg drop, long drs,
+                         int cls_T, hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
-  if (dtype == GSL_BF16 && sdtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
-                       (const bf16_t*)dres, (bf16_t*)dx, ios, (bf16_t*)dxb, M, drop, drs);
-  else if (dtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, x, xs, gamma, mean, rstd,
-                       (const float*)dres, (float*)dx, ios, (bf16_t*)dxb, M, drop, drs);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, float, float>), dim3(grid), dim3(256), 0, st, (const float*)dy, x, xs, gamma, mean, rstd,
-                       (const float*)dres, (float*)dx, ios, (float*)dxb, M, drop, drs);
+#define GSL_LNB(T, S, X)                                                                                                            \
+  hipLaunchKernelGGL((ln_bwd_kernel<NPL, T, S, X>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const X*)x, xs, gamma, mean, rstd, \
+                     (const S*)dres, (S*)dx, ios, (T*)dxb, M, drop, drs, cls_T)
+  if (dtype == GSL_BF16 && sdtype == GSL_BF16 && xdtype == GSL_BF16) GSL_LNB(bf16_t, bf16_t, bf16_t);
+  else if (dtype == GSL_BF16 && sdtype == GSL_BF16) GSL_LNB(bf16_t, bf16_t, float);
+  else if (dtype == GSL_BF16 && xdtype == GSL_BF16) GSL_LNB(bf16_t, float, bf16_t);
+  else if (dtype == GSL_BF16) GSL_LNB(bf16_t, float, float);
+  else GSL_LNB(float, float, float);
+#undef GSL_LNB
   return check_launch("gsl_layernorm_bwd");
 }
 
@@ -159,28 +165,31 @@ static int ln_bwd_launch(const void* dy, const float* x, long xs, const float* g
     default: return fail(GSL_ERR_UNSUPPORTED, "%s: unsupported LayerNorm width %ld", __func__, (long)(D)); \
   }
 
-extern "C" int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
-                                 void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s) {
+extern "C" int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
+                                 void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0, "null/size");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || (x_dtype == GSL_BF16 && dtype == GSL_BF16), "x dtype (bf16 only in bf16 mode)");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
-#define CALL(N) ln_fwd_launch<N>(x, x_row_stride, gamma, beta, eps, y, mean, rstd, M, dtype, as_stream(s))
+#define CALL(N) ln_fwd_launch<N>(x, x_row_stride, gamma, beta, eps, y, mean, rstd, M, dtype, x_dtype, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
 }
 
-extern "C" int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma, const float* mean,
+extern "C" int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_stride, const float* gamma, const float* mean,
                                  const float* rstd, const void* dres, void* dx, long io_row_stride, void* dxb, int M, int D,
-                                 int dtype, int stream_dtype, float p_drop, uint64_t seed, uint32_t site, long drop_row_stride,
-                                 gsl_stream_t s) {
+                                 int dtype, int stream_dtype, int x_dtype, float p_drop, uint64_t seed, uint32_t site,
+                                 long drop_row_stride, int dres_cls_T, gsl_stream_t s) {
   GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
   GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || (x_dtype == GSL_BF16 && dtype == GSL_BF16), "x dtype (bf16 only in bf16 mode)");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
+  GSL_CHECK_ARG(dres_cls_T >= 0 && (dres_cls_T == 0 || (dres && dres != dx)), "dres_cls_T: compact dres, out of place");
   const DropCfg drop = make_drop(p_drop, seed, site);
   const long ios = io_row_stride > 0 ? io_row_stride : D, drs = drop_row_stride > 0 ? drop_row_stride : D;
   GSL_CHECK_ARG((ios % 4) == 0, "io row stride alignment");
-#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, drop, drs, as_stream(s))
+#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, x_dtype, drop, drs, dres_cls_T, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
 }

@@ -7,12 +7,17 @@ There is NO fallback: if the shared library is missing or a call fails, a Runtim
 import ctypes as C
 import os
 
+import contextlib
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSLORA_HIP_LIB: development override (A/B of kernel build variants, tools/probes/); the default is the in-tree build
+# GSLORA_HIP_LIB: development override (A/B of kernel build variants, tools/probes/); the default is the in-tree PRODUCT build.
+# libgslora_hip_dev.so (python -m gslora_hip.build --dev) is the same ABI compiled with -DGSL_DEV: it additionally holds the GEMM
+# variants that lost their A/Bs and reads the GSL_* ablation / variant knobs from the environment. The product library reads nothing.
 LIB_PATH = os.environ.get("GSLORA_HIP_LIB") or os.path.join(_HERE, "libgslora_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libgslora_hip_dev.so")
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM, EPI_BIAS_RES_BF16, EPI_PATCH_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 NORM_SPLIT = 8
 SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 
@@ -30,16 +35,17 @@ SIGNATURES = {
     "gsl_gemm_mulgrad_ws_elems": [_i, _i, _i],
     "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
                                  _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _vp],
-    "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _u64, _u32, _l, _vp],
+    "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
-    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
+    "gsl_attention_fwd_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
+    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp],
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
-    "gsl_head_fwd": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
-    "gsl_head_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _vp],
+    "gsl_head_fwd": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp],
     "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -61,28 +67,49 @@ _RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long, "
 _lib = None
 
 
-def load():
-    """Load the shared library (once). Raises RuntimeError — never falls back to a CPU path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _bind(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"libgslora_hip.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{os.path.basename(path)} not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The GS-LoRA step has no CPU fallback.")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:  # missing libamdhip64 etc.
-        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        raise RuntimeError(f"cannot load {path}: {e}") from e
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+            raise RuntimeError(f"{path} does not export {name}; rebuild the extension") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    _lib = lib
     return lib
+
+
+def load():
+    """Load the shared library (once). Raises RuntimeError — never falls back to a CPU path."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+_dev = None
+
+
+@contextlib.contextmanager
+def use_dev():
+    """Route the calls made inside the block to the development build (tests that compare the product kernels with the
+    variants / ablations only the dev build contains, tools/probes/). Raises RuntimeError if it has not been built."""
+    global _lib, _dev
+    if _dev is None:
+        _dev = _bind(DEV_LIB_PATH)
+    prev = _lib
+    _lib = _dev
+    try:
+        yield _dev
+    finally:
+        _lib = prev
 
 
 def check(rc, what):

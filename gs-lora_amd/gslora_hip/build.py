@@ -1,4 +1,13 @@
-"""Build libgslora_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libgslora_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Two libraries from the same sources:
+  libgslora_hip.so      the PRODUCT: the default kernels only, -fvisibility=hidden (exactly the entry points of include/gslora_hip.h
+                        are exported), no getenv() on any launch path.
+  libgslora_hip_dev.so  the LAB (-DGSL_DEV): additionally the GEMM variants that lost their A/Bs (csrc/gemm_dev_*.inc), the ablation /
+                        variant knobs and the cycle-stamp buffers that tools/bench_gemm*.py and tools/probes/ drive through the
+                        environment. Built on demand (`python -m gslora_hip.build --dev`), selected with GSLORA_HIP_LIB; never loaded
+                        by default.
+"""
 import os
 import subprocess
 import sys
@@ -6,29 +15,48 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 SOURCES = ["gemm.hip", "norm.hip", "lora.hip", "head.hip", "attention.hip"]
+HEADERS = ["gsl_common.h", "exports.map"]
+DEV_ONLY = ["gemm_dev_a.inc", "gemm_dev_b.inc"]
 OUT = os.path.join(HERE, "libgslora_hip.so")
+OUT_DEV = os.path.join(HERE, "libgslora_hip_dev.so")
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def needs_build(dev=False):
+    out = OUT_DEV if dev else OUT
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "gsl_common.h"),
-                                                       os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "gslora_hip.h")]
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + (DEV_ONLY if dev else [])]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "gslora_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return OUT
+def build(force=False, verbose=True, dev=False):
+    out = OUT_DEV if dev else OUT
+    if not force and not needs_build(dev):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(HERE, "build", "dev" if dev else "prod")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + (["-DGSL_DEV"] if dev else [])
+    procs = []
+    objs = []
+    for src in SOURCES:      # one hipcc per translation unit, in parallel (gemm.hip dominates)
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[gslora_hip.build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + objs
     if verbose:
         print("[gslora_hip.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -125,19 +125,21 @@ def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2
 
 
 def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
+    """x: the residual stream, f32 or (bf16 mode) bf16 — its dtype is handed to the kernel."""
     _need(x, gamma, beta)
     y = torch.empty(M, D, device=x.device, dtype=dtype)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
     L.check(L.load().gsl_layernorm_fwd(_p(x), row_stride, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), M, D,
-                                       code(dtype), _stream()), "gsl_layernorm_fwd")
+                                       code(dtype), code(x.dtype), _stream()), "gsl_layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
-                  io_row_stride=0, drop_row_stride=0):
+                  io_row_stride=0, drop_row_stride=0, dres_cls_T=0):
     """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the
-    residual-gradient stream (dres / dx: f32, or bf16 in bf16 mode) is taken from dres / dx."""
+    residual-gradient stream (dres / dx: f32, or bf16 in bf16 mode) is taken from dres / dx, the dtype of the saved forward stream from x.
+    dres_cls_T > 0: dres holds the cls rows only ([M / T, D]); the other rows of the incoming stream gradient are zero."""
     _need(dy, x, gamma, mean, rstd)
     M, D = dy.shape
     sdt = dx.dtype if dx is not None else (dres.dtype if dres is not None else torch.float32)
@@ -148,8 +150,8 @@ def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_
         raise RuntimeError("layernorm_bwd: dres and dx must share one dtype")
     dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if want_copy else None
     L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-                                       int(io_row_stride), _p(dxb), M, D, code(dy.dtype), code(sdt), float(p_drop), int(seed), int(site),
-                                       int(drop_row_stride), _stream()), "gsl_layernorm_bwd")
+                                       int(io_row_stride), _p(dxb), M, D, code(dy.dtype), code(sdt), code(x.dtype), float(p_drop),
+                                       int(seed), int(site), int(drop_row_stride), int(dres_cls_T), _stream()), "gsl_layernorm_bwd")
     return dx, dxb
 
 
@@ -173,11 +175,23 @@ def attention_bwd(qkv, o, d_o, lse, B, T, H, scale, layout=0):
     return dqkv
 
 
+def attention_fwd_cls(qkv, B, T, H, scale, layout=0):
+    """Attention output of the cls query alone (the last block under pool='cls'): o_cls [B, H*64], lse_cls [B, H]."""
+    _need(qkv)
+    o = torch.empty(B, H * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, H, device=qkv.device, dtype=torch.float32)
+    L.check(L.load().gsl_attention_fwd_cls(_p(qkv), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), int(layout), _stream()),
+            "gsl_attention_fwd_cls")
+    return o, lse
+
+
 def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale, layout=0):
+    """o / lse: either the full forward tensors ([B*T, H*64] / [B, H, T]) or the compact ones of attention_fwd_cls ([B, H*64] / [B, H])."""
     _need(qkv, o, d_o_cls, lse)
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(B * T, 3 * H * 64, device=qkv.device, dtype=qkv.dtype)
+    compact = o.shape[0] == B and lse.dim() == 2
     L.check(L.load().gsl_attention_bwd_cls(_p(qkv), _p(o), _p(d_o_cls), _p(lse), _p(dqkv), B, T, H, float(scale),
-                                           code(qkv.dtype), int(layout), _stream()), "gsl_attention_bwd_cls")
+                                           code(qkv.dtype), int(layout), 1 if compact else 0, _stream()), "gsl_attention_bwd_cls")
     return dqkv
 
 
@@ -241,21 +255,23 @@ def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=No
     rstd = torch.empty(B, device=dev, dtype=torch.float32)
     C = Wn.shape[0] if Wn is not None else 0
     logits = torch.empty(B, C, device=dev, dtype=torch.float32) if (label is not None or linear) else None
-    L.check(L.load().gsl_head_fwd(_p(x), T, _p(gamma), _p(beta), float(eps), _p(Wn), _p(label), _p(emb), _p(mean), _p(rstd),
+    L.check(L.load().gsl_head_fwd(_p(x), code(x.dtype), T, _p(gamma), _p(beta), float(eps), _p(Wn), _p(label), _p(emb), _p(mean), _p(rstd),
                                   _p(logits), B, D, C, float(cos_s), float(cos_m), _p(head_bias), 1 if linear else 0,
                                   1 if pool_mean else 0, _stream()), "gsl_head_fwd")
     return logits, emb, mean, rstd
 
 
 def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False,
-             pool_mean=False, stream_dtype=torch.float32):
+             pool_mean=False, stream_dtype=torch.float32, compact=False):
+    """compact (pool='cls' only): dx / dxb are [B, D] — the cls rows alone, nothing zero-filled."""
     _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn)
-    dx = torch.empty(B * T, D, device=x.device, dtype=stream_dtype)
-    dxb = torch.empty(B * T, D, device=x.device, dtype=dtype)
+    rows = B if compact else B * T
+    dx = torch.empty(rows, D, device=x.device, dtype=stream_dtype)
+    dxb = torch.empty(rows, D, device=x.device, dtype=dtype)
     C = Wn.shape[0] if Wn is not None else 0
-    L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
+    L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), code(x.dtype), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
                                   _p(dxb), B, D, C, float(cos_s), code(dtype), code(stream_dtype), float(p_drop), int(seed), int(site),
-                                  1 if linear else 0, 1 if pool_mean else 0, _stream()), "gsl_head_bwd")
+                                  1 if linear else 0, 1 if pool_mean else 0, 1 if compact else 0, _stream()), "gsl_head_bwd")
     return dx, dxb
 
 

@@ -22,6 +22,15 @@ FUSE_LORA_GRAD = os.environ.get("GSL_FUSE_LORA_GRAD", "1") != "0"
 # bf16 speed mode carries the residual-GRADIENT stream (the f32 [M, dim] tensor every LayerNorm backward re-reads and re-writes) in bf16:
 # -25 % of the bytes of each LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32 (the parity mode always does).
 GRAD_STREAM_BF16 = os.environ.get("GSLORA_GRAD_STREAM", "bf16").lower() != "f32"
+# bf16 speed mode also carries the FORWARD residual stream x (read by every LayerNorm forward, read + written by the out-proj / FFN2
+# epilogues, re-read by every LayerNorm backward) in bf16: f32 accumulate in the producing epilogue, one rounding on store.
+# GSLORA_FWD_STREAM=f32 keeps it in f32 (the parity mode always does).
+FWD_STREAM_BF16 = os.environ.get("GSLORA_FWD_STREAM", "bf16").lower() != "f32"
+# pool='cls' (vit_face.py:540): the head reads token 0 only and everything after a block's attention is token-wise, so in the LAST block
+# only the cls query's attention output, its out-proj / LayerNorm / FFN rows are ever consumed — forward and backward of that block's
+# tail run on B rows instead of B*T (exact: the skipped rows influence no output of the model). GSLORA_TAIL_CLS=0 keeps the dense forward
+# (the backward then still runs on the cls rows).
+TAIL_CLS = os.environ.get("GSLORA_TAIL_CLS", "1") != "0"
 # layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
 # read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
 QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
@@ -324,9 +333,12 @@ class ViTRunner:
         eps = sp.ln_eps
 
         patches = ops.patchify(parts, sp.patch_size, dt)
-        x = torch.empty(M, D, device=img.device, dtype=torch.float32)
+        xbf = dt == torch.bfloat16 and FWD_STREAM_BF16
+        xdt = torch.bfloat16 if xbf else torch.float32            # dtype of the residual stream
+        epi_res = L.EPI_BIAS_RES_BF16 if xbf else L.EPI_BIAS_RES_F32
+        x = torch.empty(M, D, device=img.device, dtype=xdt)
         pw = self.w_conv("pe", sp.patch_w, dt) if sp.patch_is_conv else self.w("pe", sp.patch_w, dt)
-        ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH, bias=sp.patch_b.detach(),
+        ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH_BF16 if xbf else L.EPI_PATCH, bias=sp.patch_b.detach(),
                     pos=sp.pos.detach()[0, :T].contiguous(), cls=sp.cls.detach().reshape(-1), T=T,
                     p_drop=p_emb, seed=seed, site=SITE_EMB | sflag)
         del patches
@@ -349,11 +361,18 @@ class ViTRunner:
                             bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             xn_keep = xn if (attn_site and save) else None
             del xn
-            o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale, layout=hm)
-            x1 = torch.empty(M, D, device=img.device, dtype=torch.float32)
-            ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=L.EPI_BIAS_RES_F32,
-                        bias=blk.out.bias.detach(), res=x, p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
-            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, M, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
+            tail = TAIL_CLS and i == len(sp.blocks) - 1 and sp.pool == "cls"
+            if tail:      # only the cls query of the last block is ever consumed: B rows from here on
+                o, lse = ops.attention_fwd_cls(qkv, B, T, H, sp.attn_scale, layout=hm)
+                xres, Mr = x.view(B, T, D)[:, 0].contiguous(), B
+            else:
+                o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale, layout=hm)
+                xres, Mr = x, M
+            x1 = torch.empty(Mr, D, device=img.device, dtype=xdt)
+            ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=epi_res,
+                        bias=blk.out.bias.detach(), res=xres, p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
+            del xres
+            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, Mr, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
             l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
             lora_on = r > 0 and not attn_site and not l1.merged
@@ -361,45 +380,46 @@ class ViTRunner:
                 raise NotImplementedError("gs-lora_amd: the fused LoRA path uses scaling = 1 / r (lora_alpha = 1, the only value GS-LoRA "
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
             u1 = u2 = None
-            h = torch.empty(M, mlp, device=img.device, dtype=dt)
-            gp = torch.empty(M, mlp, device=img.device, dtype=dt) if save else None
+            h = torch.empty(Mr, mlp, device=img.device, dtype=dt)
+            gp = torch.empty(Mr, mlp, device=img.device, dtype=dt) if save else None
             if lora_on:
-                u1 = torch.empty(M, PADK, device=img.device, dtype=dt)
+                u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
                 ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, A2=u1,
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                             p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
-                u2 = torch.empty(M, PADK, device=img.device, dtype=dt)
-                if not self.lora_in_kernel(dt, M):
+                u2 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
+                if not self.lora_in_kernel(dt, Mr):
                     ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, bias=l1.bias.detach(),
                             out2=gp, p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag)
-            x2 = torch.empty(M, D, device=img.device, dtype=torch.float32)
-            if lora_on and self.lora_in_kernel(dt, M):
+            x2 = torch.empty(Mr, D, device=img.device, dtype=xdt)
+            if lora_on and self.lora_in_kernel(dt, Mr):
                 ops.gemm_nt_lora(h, self.w(f"w2_{i}", l2.weight, dt), self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows16", dt),
-                                 self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols32", dt), s_lora, u2, x2, epilogue=L.EPI_BIAS_RES_F32,
+                                 self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols32", dt), s_lora, u2, x2, epilogue=epi_res,
                                  bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             else:
-                ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=L.EPI_BIAS_RES_F32, A2=u2,
+                ops.gemm_nt(h, self.w(f"w2_{i}", l2.weight, dt), x2, epilogue=epi_res, A2=u2,
                             W2=self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols", dt) if lora_on else None,
                             bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, qkv_hm=hm, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
-                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq))
+                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq, tail=tail))
             x = x2
         hn = sp.final_ln
+        Th = x.shape[0] // B      # rows per image of the stream that reaches the head: T, or 1 after a cls-row-only last block
         if linear_head:      # plain classifier: logits for every call, no normalisation, no margin
             Wn = sp.head_w.detach().contiguous()
-            logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, None, 1.0, 0.0,
+            logits, emb, meanh, rstdh = ops.head_fwd(x, B, Th, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, None, 1.0, 0.0,
                                                      head_bias=sp.head_b.detach(), linear=True)
         else:
             Wn = ops.cosface_prep(sp.head_w.detach().contiguous()) if label is not None else None
-            logits, emb, meanh, rstdh = ops.head_fwd(x, B, T, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, label,
+            logits, emb, meanh, rstdh = ops.head_fwd(x, B, Th, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, label,
                                                      sp.cos_s, sp.cos_m, pool_mean=(sp.pool == "mean"))
         saved = None
         if save:
-            saved = dict(layers=stash, x_last=x, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, sflag=sflag, p_drop=p_drop,
+            saved = dict(layers=stash, x_last=x, Th=Th, meanh=meanh, rstdh=rstdh, emb=emb, Wn=Wn, B=B, seed=seed, sflag=sflag, p_drop=p_drop,
                          dt=dt, spec=sp)
         return logits, emb, saved
 
@@ -427,10 +447,11 @@ class ViTRunner:
             demb = demb.contiguous().float()
         if dlogits is not None and saved["Wn"] is None:
             raise RuntimeError("backward through logits requires a forward with labels")
-        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
+        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
-                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32)
+                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32,
+                               compact=(sp.pool == "cls"))      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -446,8 +467,9 @@ class ViTRunner:
             # outside the B cls rows, so its FFN backward, LoRA-gradient reductions, LN2 backward, out-proj dX and the
             # attention backward (a rank-1 cls-query form) run on B rows instead of B*T. Exact, not an approximation.
             sparse = (i == nl - 1) and sp.pool == "cls"      # (with pool='mean' every token carries gradient: dense last block)
-            if sparse:
-                dyb, xn2, h, gp, u1, u2 = (cls_rows(dxb, D), cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), cls_rows(st["gp"], mlp),
+            tail = st["tail"]      # the forward of this block already ran on the cls rows: every saved tensor behind the attention is [B, .]
+            if sparse and not tail:      # dx / dxb arrive compact ([B, D]) from the head backward
+                dyb, xn2, h, gp, u1, u2 = (dxb, cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), cls_rows(st["gp"], mlp),
                                            cls_rows(st["u1"], PADK), cls_rows(st["u2"], PADK))
             else:
                 dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
@@ -494,9 +516,9 @@ class ViTRunner:
                             W2=self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols", dt))
             del da, v1, v2
             n2 = blk.ln2
-            if sparse:   # update the cls rows of the dense stream gradient in place; dx1b is the compact masked copy
+            if sparse and not tail:   # compact in, compact out: the cls rows of x1 are T*D apart, the dropout counters are those of the dense tensor
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
-                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
+                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx,
                                               p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
             else:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
@@ -514,7 +536,8 @@ class ViTRunner:
             del d_o, dqkv, dx1b
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
-                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag)
+                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag,
+                                        dres_cls_T=T if sparse else 0)      # after the cls-row-only block dx1 is compact [B, D]
             saved["layers"][i] = None   # free this layer's activations
         if not torch.cuda.is_current_stream_capturing():
             self.build_pack_tables(dt)    # every pack of the step is registered now: the next forward refreshes them in one launch
@@ -538,10 +561,11 @@ class ViTRunner:
             demb = demb.contiguous().float()
         if dlogits is not None and saved["Wn"] is None:
             raise RuntimeError("backward through logits requires a forward with labels")
-        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, T, D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
+        dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
-                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32)
+                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32,
+                               compact=(sp.pool == "cls"))      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
@@ -553,8 +577,9 @@ class ViTRunner:
                 raise RuntimeError("backward with merged LoRA weights is undefined (model.train() un-merges)")
             mlp = l1.weight.shape[0]
             sparse = (i == nl - 1) and sp.pool == "cls"      # only the cls rows of the last block carry gradient (see the FFN-site path)
-            if sparse:
-                dyb, gp = cls_rows(dxb, D), cls_rows(st["gp"], mlp)
+            tail = st["tail"]
+            if sparse and not tail:
+                dyb, gp = dxb, cls_rows(st["gp"], mlp)
             else:
                 dyb, gp = dxb, st["gp"]
             Mrows = dyb.shape[0]
@@ -565,9 +590,9 @@ class ViTRunner:
             ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2)
             del da
             n2 = blk.ln2
-            if sparse:
+            if sparse and not tail:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
-                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx, dx=dx, io_row_stride=T * D,
+                                              cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx,
                                               p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
             else:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
@@ -598,5 +623,6 @@ class ViTRunner:
             del dqkv, v
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
-                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag)
+                                        p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag,
+                                        dres_cls_T=T if sparse else 0)      # after the cls-row-only block dx1 is compact [B, D]
             saved["layers"][i] = None

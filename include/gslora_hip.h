@@ -8,8 +8,9 @@
  *  - return 0 on success, negative gsl_status on error; message via gsl_last_error()
  *    (thread-local). Never aborts.
  *  - dtype selects the operand/activation element type: GSL_F32 (parity mode, exact-f32 kernels)
- *    or GSL_BF16 (speed mode: bf16 operands, f32 accumulate on MFMA). Residual stream, LayerNorm
- *    statistics, biases, LoRA master weights, losses and optimizer state are always f32.
+ *    or GSL_BF16 (speed mode: bf16 operands, f32 accumulate on MFMA). LayerNorm statistics, biases,
+ *    LoRA master weights, losses and optimizer state are always f32; the residual stream and its
+ *    gradient are f32 or — in speed mode, per call (x_dtype / stream_dtype) — bf16.
  *
  * Each entry point names the reference code it replaces (paths relative to bjzhb666/GS-LoRA).
  * The reference has no FFI of its own (it is pure PyTorch); the "binding a maintainer would add"
@@ -23,6 +24,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#define GSL_API __attribute__((visibility("default")))
 
 typedef void* gsl_stream_t;
 
@@ -43,30 +47,33 @@ enum gsl_epilogue {
   GSL_EPI_MUL = 3,          /* out[dtype]  = acc * aux[dtype]                                   */
   GSL_EPI_PATCH = 4,        /* outf32      = dropout((tok==0 ? cls : acc + bias) + pos[tok]),  tok = m % T */
   GSL_EPI_STORE_F32 = 5,    /* outf32      = acc (+ bias)                                       */
-  GSL_EPI_STORE_QKV_HM = 6  /* bf16 only: STORE of a QKV projection (N = 3*H*64, rows m = b*T + t, T = tokens per image) into the
+  GSL_EPI_STORE_QKV_HM = 6, /* bf16 only: STORE of a QKV projection (N = 3*H*64, rows m = b*T + t, T = tokens per image) into the
                                head-major layout [B][H][3][T][64] that the attention entry points read with qkv_layout = 1 */
+  GSL_EPI_BIAS_RES_BF16 = 7,/* bf16 only, the forward residual stream carried in bf16: out[bf16] = bf16(dropout(acc + bias) + f32(res[bf16]))
+                               — f32 arithmetic on the f32 accumulator, one rounding on store; same dropout mask as BIAS_RES_F32 */
+  GSL_EPI_PATCH_BF16 = 8    /* bf16 only: PATCH with a bf16 output */
 };
 
-int gsl_version(void);
-const char* gsl_last_error(void);
+GSL_API int gsl_version(void);
+GSL_API const char* gsl_last_error(void);
 
 /* ---- K1 patch gather: einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (vit_face.py:530).
  * img f32 [B,C,H,W] -> out[dtype] [B*T, p*p*C], T = 1 + (H/p)*(W/p); row b*T (cls slot) is zero. */
-int gsl_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype, gsl_stream_t s);
+GSL_API int gsl_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype, gsl_stream_t s);
 
 /* ---- K3/K5/K6/K7/K8 dense NT GEMM with an optional second K segment (the LoRA rank-r term)
  * and a fused epilogue. Replaces F.linear + loralib.Linear.forward (vit_face.py:330-334,349-356)
  * and their autograd dX.
  *   A1 [M,K1] (lda1), W1 [N,K1] (ldw1); A2 [M,K2] (lda2), W2 [N,K2] (ldw2)  — all `dtype`;
- *   K1 % 64 == 0, K2 % 64 == 0 (K2 may be 0). bias/res/pos/cls f32. out/out2/aux per epilogue.
+ *   K1 % 64 == 0, K2 % 64 == 0 (K2 may be 0). bias/pos/cls f32; res f32 (bf16 for GSL_EPI_BIAS_RES_BF16). out/out2/aux per epilogue.
  *   dropout: p_drop in [0,1); mask = hash(seed, site, m*N+n) (see gsl_dropout_keep in DESIGN.md).
  *   Every (seed, site) pair of this ABI: when bit 31 of `site` (GSL_SEED_ON_DEVICE) is set, `seed` is not the value but a device
  *   pointer to a uint64 holding it — the kernels load it, so a captured HIP graph replays with the value current at replay time. */
 #define GSL_SEED_ON_DEVICE 0x80000000u
-int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
+GSL_API int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
                 const void* A2, int lda2, const void* W2, int ldw2, int K2,
                 int M, int N, int dtype, int epilogue, float alpha,
-                const float* bias, const float* res, const void* aux,
+                const float* bias, const void* res, const void* aux,
                 void* out, void* out2, int ldo,
                 const float* pos, const float* cls, int T,
                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
@@ -76,11 +83,11 @@ int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1,
  *   out = epilogue(A*W^T + t*Q^T),  t = lora_scale * (A*P^T)
  *   A [M,K] (lda), W [N,K] (ldw), P [16,K] (ldp; rows >= r zero), Q [N,32] (ldq >= 32; cols >= r zero), K % 64 == 0.
  *   tout (nullable) [M, ldt >= 64] receives t in bf16, zero padded to 64 columns (input of gsl_lora_grad).
- * Epilogues: STORE, BIAS_RES_F32, BIAS_GELU, MUL. */
-int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
+ * Epilogues: STORE, BIAS_RES_F32, BIAS_RES_BF16, BIAS_GELU, MUL. */
+GSL_API int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
                      const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
                      int M, int N, int dtype, int epilogue,
-                     const float* bias, const float* res, const void* aux, void* out, void* out2, int ldo,
+                     const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                      float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
 
 /* The MUL form of gsl_gemm_nt_lora (FFN2-dX: out = (A W^T + t Q^T) * aux, bf16) with the two LoRA-gradient reductions that consume
@@ -89,79 +96,89 @@ int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
  *   G2[n*g2sn + j*g2sj] (+)= sum_m Y2[m,n] * t[m,j]        (dA of the down-projection adapter; Y2 = the saved FFN hidden activation)
  * U1 [M, ldu1 >= 16] bf16 (columns r..15 zero or discarded), Y2 / aux / out [M,N] bf16 with row stride ldo, N % 8 == 0.
  * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible). */
-long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
-int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
+GSL_API long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
+GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
                              const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
                              int M, int N, const void* aux, void* out, int ldo,
                              const void* U1, int ldu1, float* G1, long g1sn, long g1sj,
                              const void* Y2, float* G2, long g2sn, long g2sj,
                              int r, int accumulate, float* ws, gsl_stream_t s);
 
-/* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x f32 rows of length D at
- * stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M]. D in {64,128,256,512,768,1024}. */
-int gsl_layernorm_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, float eps,
-                      void* y, float* mean, float* rstd, int M, int D, int dtype, gsl_stream_t s);
+/* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x — the residual stream — is `x_dtype` (f32; bf16 when the bf16
+ * speed mode carries the forward stream in bf16), rows of length D at stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M].
+ * D in {64,128,256,512,768,1024}. */
+GSL_API int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
+                      void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s);
 /* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D] (dense). dres / dx — the residual-GRADIENT
  * stream — are `stream_dtype`: f32, or bf16 when dtype is bf16 (speed mode: the stream is re-read and re-written by every LayerNorm
- * backward of the chain).
- * dres/dx rows are io_row_stride elements apart (0 -> D; dres may alias dx: in-place update of strided rows,
- * used for the cls-row-only backward of the last block); the dropout counter of element (row, d) is
- * row*drop_row_stride + d (0 -> D). dxb is always dense [M,D]. */
-int gsl_layernorm_bwd(const void* dy, const float* x, long x_row_stride, const float* gamma,
+ * backward of the chain). x (the saved forward stream) is `x_dtype`.
+ * dres/dx rows are io_row_stride elements apart (0 -> D; dres may alias dx: in-place update); the dropout counter of element (row, d) is
+ * row*drop_row_stride + d (0 -> D). dxb is always dense [M,D].
+ * dres_cls_T > 0: dres is COMPACT — it holds only the rows of the cls tokens ([M / dres_cls_T] rows, io_row_stride apart); row m
+ * receives dres[m / dres_cls_T] when m % dres_cls_T == 0 and nothing otherwise, and dx is written dense [M,D]. (The stream gradient
+ * leaving the cls-row-only backward of the last block is exactly zero off the cls rows: no zero-filled tensor is written or read.) */
+GSL_API int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_stride, const float* gamma,
                       const float* mean, const float* rstd, const void* dres,
-                      void* dx, long io_row_stride, void* dxb, int M, int D, int dtype, int stream_dtype,
-                      float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, gsl_stream_t s);
+                      void* dx, long io_row_stride, void* dxb, int M, int D, int dtype, int stream_dtype, int x_dtype,
+                      float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, int dres_cls_T, gsl_stream_t s);
 
 /* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
  * qkv_layout (the INPUT qkv): 0 = token-major qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)', as the reference's to_qkv output),
  * 1 = head-major [B][H][3][T][64] (bf16 kernels only; written by gsl_gemm_nt's GSL_EPI_STORE_QKV_HM): every panel row is a full
  * 128-byte line next to its neighbours. Outputs are token-major in both cases: o[dtype] [B*T, H*64], lse f32 [B,H,T]. */
-int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
+GSL_API int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
 /* dqkv[dtype] [B*T,3*H*64] (token-major, always); delta_ws f32 [B,H,T] scratch. */
-int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+GSL_API int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
                       float* delta_ws, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
-/* Backward when only the cls query (token 0 of every image) carries an output gradient — the last
- * transformer block, because ViT_face pools x[:,0] (vit_face.py:540). d_o_cls[dtype] [B, H*64] is dO of the cls rows;
- * o and lse are the forward's full tensors. Writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens = 0). */
-int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
-                          int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
+/* The last transformer block when the head pools the cls token (vit_face.py:540): everything after its attention is token-wise, so
+ * only the cls query's attention output is ever consumed. Forward of that one query row per (image, head) against the full K / V
+ * panels: o_cls[dtype] [B, H*64], lse_cls f32 [B, H]. */
+GSL_API int gsl_attention_fwd_cls(const void* qkv, void* o_cls, float* lse_cls, int B, int T, int H, float scale, int dtype,
+                                  int qkv_layout, gsl_stream_t s);
+/* Its backward: only the cls query carries an output gradient. d_o_cls[dtype] [B, H*64] is dO of the cls rows;
+ * cls_compact != 0: o / lse are the [B, H*64] / [B, H] outputs of gsl_attention_fwd_cls, 0: the full tensors of gsl_attention_fwd
+ * ([B*T, H*64] / [B, H, T]; the cls rows are read). Writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens = 0). */
+GSL_API int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
+                                  int B, int T, int H, float scale, int dtype, int qkv_layout, int cls_compact, gsl_stream_t s);
 
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
  * Y[dtype] [M,N] with row stride ldy >= N elements (a column block of a wider tensor is allowed), U[dtype] [M,ldu] (first r columns
  * used, r <= 16; columns r..15 must be readable zeros or belong to other adapters whose products are discarded).
  * ws f32 >= gsl_lora_grad_ws_elems(). */
-long gsl_lora_grad_ws_elems(int M, int N, int r);
-int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj,
+GSL_API long gsl_lora_grad_ws_elems(int M, int N, int r);
+GSL_API int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj,
                   int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
 
 /* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35).
  * linear_head != 0 selects the ViT-B/16 path instead (modified_VIT.py:32-38): logits = emb * W^T + head_bias, with Wn = W
  * un-normalised and cos_s = 1 on the backward side. */
-int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s);   /* Wn = F.normalize(W) */
-int gsl_head_fwd(const float* x, int T, const float* gamma, const float* beta, float eps,
+GSL_API int gsl_cosface_prep(const float* W, float* Wn, int C, int D, gsl_stream_t s);   /* Wn = F.normalize(W) */
+GSL_API int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamma, const float* beta, float eps,
                  const float* Wn, const int64_t* label, float* emb, float* mean, float* rstd,
                  float* logits, int B, int D, int C, float cos_s, float cos_m,
                  const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s);
 /* pool_mean = 0: the head pools token 0 (pool='cls'); 1: the mean over the T tokens (pool='mean', vit_face.py:540).
- * dlogits [B,C] / demb [B,D] nullable. dx f32 [B*T,D]: with pool='cls' the cls rows get the gradient and the others are zeroed,
+ * x is `x_dtype` (the residual stream, see gsl_layernorm_fwd).
+ * dlogits [B,C] / demb [B,D] nullable. dx [B*T,D]: with pool='cls' the cls rows get the gradient and the others are zeroed,
  * with pool='mean' every token row gets d pooled / T. dxb[dtype] = dx * dropmask(site) (nullable). dx is `stream_dtype` (see
- * gsl_layernorm_bwd). */
-int gsl_head_bwd(const float* dlogits, const float* demb, const float* x, int T, const float* gamma,
+ * gsl_layernorm_bwd). compact != 0 (pool='cls' only): dx / dxb are [B,D], the cls rows alone — nothing is zero-filled; the dropout
+ * counters stay those of the dense tensor. */
+GSL_API int gsl_head_bwd(const float* dlogits, const float* demb, const void* x, int x_dtype, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
                  void* dx, void* dxb, int B, int D, int C, float cos_s, int dtype, int stream_dtype,
-                 float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, gsl_stream_t s);
+                 float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, int compact, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
  * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */
-int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, float* row_ws, int B, int C, gsl_stream_t s);
+GSL_API int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out2, float* row_ws, int B, int C, gsl_stream_t s);
 /* dlogits (+)= coef[0] * scale * (softmax - onehot) ; coef is a DEVICE scalar (no host sync). */
-int gsl_ce_bwd(const float* logits, const int64_t* labels, const float* coef, float scale,
+GSL_API int gsl_ce_bwd(const float* logits, const int64_t* labels, const float* coef, float scale,
                float* dlogits, int B, int C, int accumulate, gsl_stream_t s);
 
 /* ---- K13 prototype KL (engine_cl.py:571-603): out1[0] = sum_i KL(softmax(proto[y_i]) || softmax(emb_i)). */
-int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, float* row_ws /*[B]*/,
+GSL_API int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const float* proto, float* out1, float* row_ws /*[B]*/,
                      int B, int D, int C, gsl_stream_t s);
-int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef,
+GSL_API int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto, const float* coef,
                      float scale, float* demb, int B, int D, int C, int accumulate, gsl_stream_t s);
 
 /* ---- scalar tail of the step (engine_cl.py:65-125, single process): from the batch SUMS of the kernels above
@@ -169,7 +186,7 @@ int gsl_proto_kl_bwd(const float* emb, const int64_t* labels, const float* proto
  * meters8 = [beta*loss_forget, loss_remain, total, alpha*structure, top1_forget %, top1_remain %, proto_f, proto_r],
  * coefs5 = d total / d {ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure} (relu'(0) = 0). kl_* / structure nullable (term absent).
  * All inputs and outputs are device scalars / small device arrays: no host sync. */
-int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* kl_f_sum, const float* kl_r_sum,
+GSL_API int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* kl_f_sum, const float* kl_r_sum,
                      const float* structure, const float* hit_r, const float* hit_f, float n_r, float n_f,
                      float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
                      float* total, float* meters8, float* coefs5, gsl_stream_t s);
@@ -177,7 +194,7 @@ int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const float* 
 /* Data-parallel form of the scalar tail (SURVEY 8(e) collective C2; reference semantics train_own_forget_cl.py:494-497, engine_cl.py:78,99):
  * pack8 = the sum-all-reduced [ce_r_sum, ce_f_sum, hit_r, hit_f, n_r, n_f, kl_f_sum, kl_r_sum] — global batch sums and sizes, all on the
  * device. Same outputs as gsl_loss_combine; coefs5 are the derivatives with respect to THIS rank's local sums (= those of the global sums). */
-int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_proto, float beta, float BND, float alpha, float w_f,
+GSL_API int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_proto, float beta, float BND, float alpha, float w_f,
                           float w_r, float BND_pro, float* total, float* meters8, float* coefs5, gsl_stream_t s);
 
 
@@ -187,39 +204,39 @@ int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_pr
  * cal_norm[ngroups] = sum sqrt(sumsq) (cal_norm.py 'L2'), loss[1] = sum_g group_norm,
  * mask u8[ngroups] = group_norm > tau.  partial_ws f32 [ntensors*GSL_NORM_SPLIT]. */
 #define GSL_NORM_SPLIT 8
-int gsl_group_norms_fwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+GSL_API int gsl_group_norms_fwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
                         int ntensors, int ngroups, float tau, float* partial_ws, float* tensor_sumsq,
                         float* group_norm, float* cal_norm, float* loss, uint8_t* mask, gsl_stream_t s);
 /* gradflat[i] += coef[0]*scale * flat[i] / group_norm[g(i)]  (0 where group_norm == 0). */
-int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
+GSL_API int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,
                         int ntensors, const float* group_norm, const float* coef, float scale,
                         float* gradflat, gsl_stream_t s);
 
 /* ---- K14 fused AdamW over a flat buffer (torch.optim.AdamW as timm.create_optimizer builds it,
  * train_own_forget_cl.py:811-813): decoupled wd, bias correction, step >= 1. */
-int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n,
+GSL_API int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n,
                    float lr, float beta1, float beta2, float eps, float wd, int step, gsl_stream_t s);
 /* HIP-graph form of the same update: the step count t (>= 1, int64) and the learning rate (f32) are read from device memory,
  * so a captured graph of the whole forgetting step replays with fresh values (bias corrections 1 - beta^t in f64 in-kernel). */
-int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
+GSL_API int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
                        float eps, float wd, const int64_t* step_dev, gsl_stream_t s);
 
 /* ---- helpers: f32 -> dtype casts for the frozen-weight caches and padded LoRA operands. */
-int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s);
+GSL_API int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s);
 /* out[dtype] [C,R] = in[R,C]^T */
-int gsl_transpose_cast(const float* in, void* out, int R, int C, int dtype, gsl_stream_t s);
+GSL_API int gsl_transpose_cast(const float* in, void* out, int R, int C, int dtype, gsl_stream_t s);
 /* out[dtype] [rows_out, ld_out] zero-padded copy: out[i, j] = scale * in[i*si + j*sj] for i<rows, j<cols. */
-int gsl_pack_pad(const float* in, long si, long sj, int rows, int cols, float scale,
+GSL_API int gsl_pack_pad(const float* in, long si, long sj, int rows, int cols, float scale,
                  void* out, int rows_out, int ld_out, int dtype, gsl_stream_t s);
 /* The same for n packs in one launch. descs_dev: device array of n descriptors (all outputs share `dtype`); max_elems =
  * max over descriptors of rows_out * ld_out. The table is built once by the host and reused every step (HIP-graph friendly). */
 typedef struct gsl_pack_desc {
   const float* in; long si, sj; int rows, cols; float scale; int pad_; void* out; int rows_out, ld_out;
 } gsl_pack_desc;
-int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long max_elems, int dtype, gsl_stream_t s);
+GSL_API int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long max_elems, int dtype, gsl_stream_t s);
 
 /* dropout keep-mask as the kernels compute it (for tests): keep[i] = 1/0 for element index i. */
-int gsl_dropout_mask(uint8_t* keep, long n, float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
+GSL_API int gsl_dropout_mask(uint8_t* keep, long n, float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -19,3 +19,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def dev_lib():
+    """`dev_lib(L)` routes the rest of the test through libgslora_hip_dev.so (the -DGSL_DEV build with the lab kernels and the GSL_* knobs);
+    the product library is restored at teardown."""
+    import contextlib
+    with contextlib.ExitStack() as stack:
+        yield lambda L: stack.enter_context(L.use_dev())

@@ -176,7 +176,9 @@ def test_full_model_bf16_vs_f32_batch64():
     top1_same = float((a[0].argmax(1) == b[0].argmax(1)).float().mean())
     print(f"[bf16 vs f32, B=64+64] logits {d_logit:.4f} emb {d_emb:.4f} loss {a[3]:.5f}/{b[3]:.5f} grad rel {rel:.4f} cos {cos:.6f} "
           f"top-1 agreement {top1_same:.4f}")
-    assert d_logit < 0.05 and d_emb < 0.02
+    # round 3 (forward residual stream in bf16, twelve more roundings of the [M, dim] stream per forward): measured logits 0.060, emb 0.049,
+    # gradient relative error 0.55 %, cosine 0.999985, top-1 agreement 1.0 (round 2, f32 stream: 0.016 / 0.0056 / 0.32 % / 0.999995)
+    assert d_logit < 0.09 and d_emb < 0.075
     assert abs(a[3] - b[3]) < 5e-3 * max(1.0, abs(a[3]))
     assert rel < 0.015 and cos > 0.9999
     assert top1_same >= 0.99

@@ -309,6 +309,15 @@ def test_dropout_grads_match_autograd_with_same_masks():
     # oracle with identical masks
     B, T, D, mlp = 3, m.num_tokens, cfg["dim"], cfg["mlp_dim"]
     keep = lambda n, site: ops.dropout_mask(n, p, seed, site, "cuda").cpu().float() / (1 - p)
+
+    def keep_rows(i, width, site):
+        """Mask of a [B, T, width] activation behind the attention of block i. The last block runs on the cls rows only (pool='cls':
+        nothing else is consumed), so its dropout counters index a compact [B, width] tensor; the other rows never reach the output."""
+        if i < cfg["depth"] - 1:
+            return keep(B * T * width, site).reshape(B, T, width)
+        full = torch.ones(B, T, width)
+        full[:, 0] = keep(B * width, site).reshape(B, width)
+        return full
     st = O.to_torch(st_np, requires_grad_lora=True)
     import torch.nn.functional as F
     x = O.patchify(xr.cpu(), cfg["patch_size"])
@@ -322,12 +331,12 @@ def test_dropout_grads_match_autograd_with_same_masks():
         q, k, v = [t.reshape(B, T, cfg["heads"], 64).permute(0, 2, 1, 3) for t in F.linear(xn, st[f"{a}.fn.to_qkv.weight"]).chunk(3, -1)]
         att = (torch.einsum("bhid,bhjd->bhij", q, k) * D ** -0.5).softmax(-1)
         o = torch.einsum("bhij,bhjd->bhid", att, v).permute(0, 2, 1, 3).reshape(B, T, -1)
-        x = F.linear(o, st[f"{a}.fn.to_out.0.weight"], st[f"{a}.fn.to_out.0.bias"]) * keep(B * T * D, 4 * i).reshape(B, T, D) + x
+        x = F.linear(o, st[f"{a}.fn.to_out.0.weight"], st[f"{a}.fn.to_out.0.bias"]) * keep_rows(i, D, 4 * i) + x
         xn = F.layer_norm(x, (D,), st[f"{f}.norm.weight"], st[f"{f}.norm.bias"], 1e-5)
         h = O.lora_linear(xn, st[f"{f}.fn.net.0.weight"], st[f"{f}.fn.net.0.bias"], st[f"{f}.fn.net.0.lora_A"], st[f"{f}.fn.net.0.lora_B"], rr, False)
-        h = F.gelu(h) * keep(B * T * mlp, 4 * i + 1).reshape(B, T, mlp)
+        h = F.gelu(h) * keep_rows(i, mlp, 4 * i + 1)
         y = O.lora_linear(h, st[f"{f}.fn.net.3.weight"], st[f"{f}.fn.net.3.bias"], st[f"{f}.fn.net.3.lora_A"], st[f"{f}.fn.net.3.lora_B"], rr, False)
-        x = y * keep(B * T * D, 4 * i + 2).reshape(B, T, D) + x
+        x = y * keep_rows(i, D, 4 * i + 2) + x
     emb = F.layer_norm(x[:, 0], (D,), st["mlp_head.0.weight"], st["mlp_head.0.bias"], 1e-5)
     logits = O.cosface(emb, st["loss.weight"], yr.cpu())
     assert (lo.detach().cpu() - logits.detach()).abs().max() < 1e-4

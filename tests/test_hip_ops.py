@@ -323,8 +323,10 @@ def test_attention_fwd_persistent_bit_identical_to_per_item_kernel(ops, B, T, H,
     qkv = rnd(B * T, 3 * H * 64, seed=31, scale=1.3).cuda().to(dt)
     o1, lse1 = ops.attention_fwd(qkv, B, T, H, scale)
     o1b, lse1b = ops.attention_fwd(qkv, B, T, H, scale)
-    monkeypatch.setenv("GSL_ATTN_PERSISTENT", "0")
-    o0, lse0 = ops.attention_fwd(qkv, B, T, H, scale)
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_ATTN_PERSISTENT", "0")      # a knob of the development build only
+    with L.use_dev():
+        o0, lse0 = ops.attention_fwd(qkv, B, T, H, scale)
     assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
     assert torch.equal(o1, o1b) and torch.equal(lse1, lse1b)
 
@@ -338,8 +340,10 @@ def test_attention_bwd_fused_bit_identical_to_two_kernel_form(ops, B, T, H, monk
     o, lse = ops.attention_fwd(qkv, B, T, H, scale)
     d_o = rnd(B * T, H * 64, seed=22).cuda().to(dt)
     fused = ops.attention_bwd(qkv, o, d_o, lse, B, T, H, scale)
-    monkeypatch.setenv("GSL_ATTN_BWD_SPLIT", "1")
-    split = ops.attention_bwd(qkv, o, d_o, lse, B, T, H, scale)
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_ATTN_BWD_SPLIT", "1")       # a knob of the development build only
+    with L.use_dev():
+        split = ops.attention_bwd(qkv, o, d_o, lse, B, T, H, scale)
     assert torch.equal(fused, split)
 
 
@@ -417,9 +421,7 @@ def test_gemm_nt_lora_mulgrad_fused_reductions(ops, M, N, K, r, monkeypatch):
     U1 = c(U1)
     s = 1.0 / r
     tout0 = torch.empty(M, 64, device="cuda", dtype=dt); out0 = torch.empty(M, N, device="cuda", dtype=dt)
-    monkeypatch.setenv("GSL_KROT", "0")
     ops.gemm_nt_lora(A, W, P, Q, s, tout0, out0, epilogue=L.EPI_MUL, aux=aux)
-    monkeypatch.delenv("GSL_KROT")
     G1r = torch.zeros(N, r, device="cuda"); G2r = torch.zeros(r, N, device="cuda")
     ops.lora_grad(out0, U1, G1r, r, 1, r, accumulate=False)
     ops.lora_grad(Y2, tout0, G2r, 1, N, r, accumulate=False)
@@ -526,11 +528,14 @@ def test_lora_grad_mfma_matches_valu_kernel(ops, M, N, r, monkeypatch):
     U[:, :r] = rnd(M, r, seed=22).cuda().bfloat16()
     ref = Y.float().cpu().t() @ U[:, :r].float().cpu()
     got = {}
-    for mode in ("1", "0"):
+    from gslora_hip import _lib as L
+    import contextlib
+    for mode in ("1", "0"):      # "1": the product library's matrix-core kernel; "0": the VALU kernel, forced through the development build
         monkeypatch.setenv("GSL_LORA_GRAD_MFMA", mode)
         G = torch.zeros(N, r, device="cuda")
-        ops.lora_grad(Y, U, G, r, 1, r, accumulate=False)
-        ops.lora_grad(Y, U, G, r, 1, r, accumulate=True)
+        with (L.use_dev() if mode == "0" else contextlib.nullcontext()):
+            ops.lora_grad(Y, U, G, r, 1, r, accumulate=False)
+            ops.lora_grad(Y, U, G, r, 1, r, accumulate=True)
         got[mode] = G.cpu() / 2
         assert relerr(got[mode], ref) < 2e-5, mode
     assert relerr(got["1"], got["0"]) < 2e-6
@@ -562,11 +567,12 @@ def test_data_prefetcher_ring_delivers_batches_in_order(ops):
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(5713, 2048, 512, 64), (1031, 1536, 512, 0), (2600, 512, 2048, 0), (640, 256, 192, 0)])
-def test_gemm_pingpong_variant(ops, monkeypatch, M, N, K1, K2):
+def test_gemm_pingpong_variant(ops, monkeypatch, dev_lib, M, N, K1, K2):
     """The persistent ping-pong kernel (GSL_GEMM_VARIANT=10; measured, not the default — profiles/r02_pp_pingpong.md): STORE and
     BIAS_GELU (+ dropout) results against fp32 torch on the bf16-rounded operands, ragged M and N-tile counts of 8 / 6 / 2 / 1."""
     from gslora_hip import _lib as L
-    monkeypatch.setenv("GSL_GEMM_VARIANT", "10")
+    monkeypatch.setenv("GSL_GEMM_VARIANT", "10")      # the kernel lives in the development build only
+    dev_lib(L)
     dt = torch.bfloat16
     A1, W1 = rnd(M, K1, seed=11), rnd(N, K1, seed=12, scale=K1 ** -0.5)
     A2 = W2 = None
@@ -595,11 +601,12 @@ def test_gemm_pingpong_variant(ops, monkeypatch, M, N, K1, K2):
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(2560, 2048, 512, 64), (1536, 1536, 512, 0), (1280, 256, 512, 0)])
-def test_gemm_inwave_pipelined_variant(ops, monkeypatch, M, N, K1, K2):
+def test_gemm_inwave_pipelined_variant(ops, monkeypatch, dev_lib, M, N, K1, K2):
     """The in-wave software-pipelined kernel (GSL_GEMM_VARIANT=11; measured, not the default — profiles/r02_pp_pingpong.md): full tiles
     only (M % 128 == 0, N % 256 == 0, K in {512, 576}); N-tile counts 8 / 6 / 1, workgroups with one and with several tiles."""
     from gslora_hip import _lib as L
-    monkeypatch.setenv("GSL_GEMM_VARIANT", "11")
+    monkeypatch.setenv("GSL_GEMM_VARIANT", "11")      # the kernel lives in the development build only
+    dev_lib(L)
     dt = torch.bfloat16
     A1, W1 = rnd(M, K1, seed=21), rnd(N, K1, seed=22, scale=K1 ** -0.5)
     A2 = W2 = None
@@ -687,3 +694,136 @@ def test_attention_head_major_input_bit_identical_to_token_major(ops, B, T, H):
     c0 = ops.attention_bwd_cls(qkv, o0, d_cls, l0, B, T, H, scale)
     c1 = ops.attention_bwd_cls(hm, o0, d_cls, l0, B, T, H, scale, layout=1)
     assert torch.equal(c0, c1)
+
+
+# ---------------------------------------------------------------------------------------------------------------- bf16 forward stream
+@pytest.mark.parametrize("M,N,K1,K2,T", [(591, 192, 128, 64, 197), (257, 512, 512, 0, 257), (788, 512, 2048, 64, 197),
+                                         (33490, 512, 512, 0, 197), (33490, 512, 192, 0, 197)])
+def test_gemm_bf16_stream_epilogues_equal_the_rounded_f32_stream_epilogues(ops, M, N, K1, K2, T):
+    """BIAS_RES_BF16 / PATCH_BF16 (bf16 speed mode, forward residual stream in bf16): with a residual that is exactly representable in
+    bf16 both epilogues compute the same f32 value — the bf16-stream output must be its one-time rounding, bit for bit, and the dropout
+    mask the same. Small shapes run the 128x128 kernel's fragment path, the 33 490-row shapes the 8-phase kernel's staged full-row
+    epilogue (ragged last M tile)."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    c = lambda t: None if t is None else t.cuda().to(dt)
+    A1, W1 = c(rnd(M, K1, seed=1)), c(rnd(N, K1, seed=2, scale=K1 ** -0.5))
+    A2 = W2 = None
+    if K2:
+        a2 = rnd(M, K2, seed=3); a2[:, 8:] = 0
+        A2, W2 = c(a2), c(rnd(N, K2, seed=4, scale=0.1))
+    bias, res = rnd(N, seed=5).cuda(), c(rnd(M, N, seed=6))
+    for p in (0.0, 0.1):
+        o32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        o16 = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+        ops.gemm_nt(A1, W1, o32, epilogue=L.EPI_BIAS_RES_F32, A2=A2, W2=W2, bias=bias, res=res.float(), p_drop=p, seed=11, site=3)
+        ops.gemm_nt(A1, W1, o16, epilogue=L.EPI_BIAS_RES_BF16, A2=A2, W2=W2, bias=bias, res=res, p_drop=p, seed=11, site=3)
+        assert torch.equal(o16, o32.to(dt)), p
+        pos, cls = rnd(T, N, seed=8).cuda(), rnd(N, seed=9).cuda()
+        if M % T == 0:
+            ops.gemm_nt(A1, W1, o32, epilogue=L.EPI_PATCH, A2=A2, W2=W2, bias=bias, pos=pos, cls=cls, T=T, p_drop=p, seed=12, site=1_000_000)
+            ops.gemm_nt(A1, W1, o16, epilogue=L.EPI_PATCH_BF16, A2=A2, W2=W2, bias=bias, pos=pos, cls=cls, T=T, p_drop=p, seed=12, site=1_000_000)
+            assert torch.equal(o16, o32.to(dt)), p
+
+
+def test_gemm_nt_lora_bf16_stream_epilogue(ops):
+    """The in-kernel-LoRA GEMM (FFN2 forward) with the bf16 residual stream == its f32-stream result, rounded once."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    M, N, K, r = 2100, 512, 2048, 8
+    c = lambda t: t.cuda().to(dt)
+    A, W = c(rnd(M, K, seed=1)), c(rnd(N, K, seed=2, scale=K ** -0.5))
+    P = torch.zeros(16, K); P[:r] = rnd(r, K, seed=3, scale=K ** -0.5)
+    Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
+    bias, res = rnd(N, seed=5).cuda(), c(rnd(M, N, seed=6))
+    t32 = torch.empty(M, 64, device="cuda", dtype=dt); t16 = torch.empty(M, 64, device="cuda", dtype=dt)
+    o32 = torch.empty(M, N, device="cuda", dtype=torch.float32); o16 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t32, o32, epilogue=L.EPI_BIAS_RES_F32, bias=bias, res=res.float(), p_drop=0.1, seed=5, site=2)
+    ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t16, o16, epilogue=L.EPI_BIAS_RES_BF16, bias=bias, res=res, p_drop=0.1, seed=5, site=2)
+    assert torch.equal(o16, o32.to(dt)) and torch.equal(t16, t32)
+
+
+@pytest.mark.parametrize("D", [128, 512, 768])
+def test_layernorm_with_a_bf16_residual_stream(ops, D):
+    """LayerNorm forward / backward reading the residual stream x in bf16 == the same kernels on the widened f32 copy of that tensor."""
+    dt = torch.bfloat16
+    M = 301
+    x = (rnd(M, D, seed=41, scale=2.0) + 0.5).cuda().to(dt)
+    g, b = (1 + 0.1 * rnd(D, seed=42)).cuda(), (0.1 * rnd(D, seed=43)).cuda()
+    y16, m16, r16 = ops.layernorm_fwd(x, D, M, D, g, b, 1e-5, dt)
+    y32, m32, r32 = ops.layernorm_fwd(x.float(), D, M, D, g, b, 1e-5, dt)
+    assert torch.equal(y16, y32) and torch.equal(m16, m32) and torch.equal(r16, r32)
+    dy, dres = rnd(M, D, seed=44).cuda().to(dt), rnd(M, D, seed=45).cuda().to(dt)
+    a = ops.layernorm_bwd(dy, x, D, g, m16, r16, dres, p_drop=0.1, seed=5, site=3)
+    bq = ops.layernorm_bwd(dy, x.float(), D, g, m16, r16, dres, p_drop=0.1, seed=5, site=3)
+    for u, v in zip(a, bq):      # same arithmetic; the two template instantiations may contract multiply-adds differently: within one bf16 ulp
+        assert (u.float() - v.float()).abs().max() <= 2.0 ** -7 * max(1.0, v.float().abs().max().item())
+        assert (u != v).float().mean() < 0.01
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layernorm_bwd_compact_cls_residual_gradient(ops, dt):
+    """dres_cls_T: the incoming stream gradient is given as its cls rows only ([B, D]); the result must equal the dense call on the
+    zero-filled [B*T, D] tensor, bit for bit."""
+    B, T, D = 5, 7, 128
+    M = B * T
+    sdt = dt
+    x = rnd(M, D, seed=1, scale=2.0).cuda().to(sdt)
+    g = (1 + 0.1 * rnd(D, seed=2)).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, torch.zeros(D).cuda(), 1e-5, dt)
+    dy = rnd(M, D, seed=3).cuda().to(dt)
+    compact = rnd(B, D, seed=4).cuda().to(sdt)
+    dense = torch.zeros(M, D, device="cuda", dtype=sdt)
+    dense.view(B, T, D)[:, 0] = compact
+    a = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dense, p_drop=0.2, seed=9, site=4)
+    b = ops.layernorm_bwd(dy, x, D, g, mean, rstd, compact, p_drop=0.2, seed=9, site=4, dres_cls_T=T)
+    assert b[0].shape == (M, D) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_head_bwd_compact_equals_the_cls_rows_of_the_dense_form(ops, dt):
+    B, T, D, C = 6, 9, 128, 10
+    sdt = dt
+    x = rnd(B * T, D, seed=1, scale=1.5).cuda().to(sdt)
+    g, b = (1 + 0.1 * rnd(D, seed=2)).cuda(), (0.1 * rnd(D, seed=3)).cuda()
+    Wn = ops.cosface_prep(rnd(C, D, seed=4).cuda())
+    label = (torch.arange(B) % C).cuda()
+    logits, emb, mean, rstd = ops.head_fwd(x, B, T, D, g, b, 1e-5, Wn, label, 64.0, 0.35)
+    if dt == torch.bfloat16:      # the bf16 stream is read as the widened values
+        l32, e32, _, _ = ops.head_fwd(x.float(), B, T, D, g, b, 1e-5, Wn, label, 64.0, 0.35)
+        assert torch.equal(logits, l32) and torch.equal(emb, e32)
+    dl, de = rnd(B, C, seed=5).cuda(), rnd(B, D, seed=6).cuda()
+    kw = dict(p_drop=0.3, seed=21, site=6, stream_dtype=sdt)
+    dx, dxb = ops.head_bwd(dl, de, x, B, T, D, g, mean, rstd, emb, Wn, 64.0, dt, **kw)
+    cx, cxb = ops.head_bwd(dl, de, x, B, T, D, g, mean, rstd, emb, Wn, 64.0, dt, compact=True, **kw)
+    assert cx.shape == (B, D) and cxb.shape == (B, D)
+    assert torch.equal(cx, dx.view(B, T, D)[:, 0]) and torch.equal(cxb, dxb.view(B, T, D)[:, 0])
+    assert (dx.view(B, T, D)[:, 1:] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,T,H,hm", [(3, 197, 2, 0), (2, 26, 1, 0), (5, 197, 8, 1), (2, 224, 2, 1), (130, 197, 8, 1)])
+def test_attention_fwd_cls_equals_the_cls_rows_of_the_dense_forward(ops, dt, B, T, H, hm):
+    """The last block's attention for the cls query alone: o / lse of token 0 of every (image, head), against fp32 torch and against the
+    dense kernel; the cls backward accepts its compact o / lse and returns what it returns for the dense forward's tensors."""
+    if hm and dt != torch.bfloat16:
+        pytest.skip("head-major qkv is a bf16-mode layout")
+    scale = 64 ** -0.5
+    qkv = rnd(B * T, 3 * H * 64, seed=61, scale=1.2).cuda().to(dt)
+    qin = _to_head_major(qkv, B, T, H) if hm else qkv
+    o_d, lse_d = ops.attention_fwd(qin, B, T, H, scale, layout=hm)
+    o_c, lse_c = ops.attention_fwd_cls(qin, B, T, H, scale, layout=hm)
+    assert o_c.shape == (B, H * 64) and lse_c.shape == (B, H)
+    q, k, v = [t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.float().cpu().chunk(3, -1)]
+    s0 = torch.einsum("bhd,bhjd->bhj", q[:, :, 0], k) * scale
+    ref_o = torch.einsum("bhj,bhjd->bhd", s0.softmax(-1), v).reshape(B, H * 64)
+    assert (o_c.float().cpu() - ref_o).abs().max() < tol(dt, 2e-5, 2e-2)
+    assert (lse_c.cpu() - s0.logsumexp(-1)).abs().max() < 2e-4
+    assert (o_c.float() - o_d.view(B, T, -1)[:, 0].float()).abs().max() < tol(dt, 2e-5, 3e-2)
+    assert (lse_c - lse_d[:, :, 0]).abs().max() < tol(dt, 2e-5, 2e-3)
+    d_o = rnd(B, H * 64, seed=62).cuda().to(dt)
+    a = ops.attention_bwd_cls(qin, o_c, d_o, lse_c, B, T, H, scale, layout=hm)
+    dense_o = torch.zeros(B * T, H * 64, device="cuda", dtype=dt); dense_o.view(B, T, -1)[:, 0] = o_c
+    dense_l = torch.zeros(B, H, T, device="cuda"); dense_l[:, :, 0] = lse_c
+    b = ops.attention_bwd_cls(qin, dense_o, d_o, dense_l, B, T, H, scale, layout=hm)
+    assert torch.equal(a, b)
