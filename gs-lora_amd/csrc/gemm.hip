@@ -51,6 +51,34 @@ struct EpiArgs {
   unsigned long long* stamps;     // development (GSL_P8_STAMPS = device address of 256 x 4 u64): cycle stamps of every 64th workgroup of the 8-phase kernel
 };
 
+// ---- 8-bit GELU' (bf16 speed mode). The second output of the fused FFN1 epilogue, g' = GELU'(a) * keep / (1 - p), is read once, by the
+// FFN2-dX epilogue, as a multiplier; GELU' lives in [-0.129, 1.129], so the tensor is stored as an unsigned fixed-point code
+//   q = rne(GELU'(a) * keep * 200 + 26)  in [0, 252]   (v_cvt_pk_u8_f32 rounds to nearest; step 0.005; keep = 0 -> q = 26 -> decodes to exactly 0)
+//   g' = (q - 26) * 0.005 / (1 - p)
+// i.e. an absolute error <= 0.0025 / (1 - p) where bf16 has a relative one of 2^-9: half the bytes of the [M, mlp] tensor that the
+// FFN1 forward writes and the HBM-bound FFN2-dX epilogue reads (profiles/r03_*). GSL_EPI_BIAS_GELU_G8 writes it, GSL_EPI_MUL_G8 /
+// gsl_gemm_nt_lora_mulgrad(aux_u8) read it; both take the dropout rate of the forward for the 1 / (1 - p).
+constexpr float G8_K = 200.0f, G8_O = 26.0f;
+template <int EPI> constexpr bool epi_is_mul() { return EPI == GSL_EPI_MUL || EPI == GSL_EPI_MUL_G8; }
+template <int EPI> constexpr bool epi_is_gelu() { return EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_BIAS_GELU_G8; }
+// kq = 200 * (1 - p): g (already scaled by keep / (1 - p)) -> code
+__device__ __forceinline__ uint32_t g8_pack4(const float g[4], float kq) {
+  uint32_t w = 0u;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[0], kq, G8_O), 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[1], kq, G8_O), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[2], kq, G8_O), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[3], kq, G8_O), 3, w);
+  return w;
+}
+// sq = 0.005 / (1 - p): code -> g'
+__device__ __forceinline__ void g8_unpack4(uint32_t w, float sq, float g[4]) {
+  const float o = -G8_O * sq;
+  g[0] = fmaf((float)(w & 0xffu), sq, o);
+  g[1] = fmaf((float)((w >> 8) & 0xffu), sq, o);
+  g[2] = fmaf((float)((w >> 16) & 0xffu), sq, o);
+  g[3] = fmaf((float)(w >> 24), sq, o);
+}
+
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
 // N % 4 == 0 is enforced by the host wrapper. v = primary output, g = second output (GELU' of BIAS_GELU).
 // bp: the 4 bias values of columns n..n+3 already in registers (the staged epilogues load them once per wave: a per-fragment
@@ -63,14 +91,14 @@ template <int EPI, typename T, bool HASW = false>
 __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4], const float* bp = nullptr, uint32_t w0 = 0u) {
   const size_t off = (size_t)m * e.ldo + n;
   const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
-  if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32 || EPI == GSL_EPI_MUL) {
+  if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32 || epi_is_mul<EPI>()) {
     if (e.alpha != 1.0f) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= e.alpha;
     }
   }
   float bq[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_PATCH || EPI == GSL_EPI_BIAS_RES_BF16 ||
+  if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || epi_is_gelu<EPI>() || EPI == GSL_EPI_PATCH || EPI == GSL_EPI_BIAS_RES_BF16 ||
                 EPI == GSL_EPI_PATCH_BF16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[i] = bp ? bp[i] : e.bias[n + i];
@@ -92,7 +120,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
-  } else if constexpr (EPI == GSL_EPI_BIAS_GELU) {
+  } else if constexpr (epi_is_gelu<EPI>()) {
     float dm[4];
     if constexpr (HASW) drop_mul4_w(e.drop, w0, dm);
     else drop_mul4(e.drop, lin, dm);
@@ -108,6 +136,11 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
   } else if constexpr (EPI == GSL_EPI_MUL) {
     float a[4];
     Elem<T>::ld4(reinterpret_cast<const T*>(e.aux) + off, a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= a[i];
+  } else if constexpr (EPI == GSL_EPI_MUL_G8) {
+    float a[4];
+    g8_unpack4(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(e.aux) + off), 1.0f / (G8_K) * e.drop.scale, a);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= a[i];
   } else if constexpr (EPI == GSL_EPI_PATCH || EPI == GSL_EPI_PATCH_BF16) {
@@ -141,6 +174,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   } else {
     Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
     if constexpr (EPI == GSL_EPI_BIAS_GELU) { if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g); }
+    if constexpr (EPI == GSL_EPI_BIAS_GELU_G8) { if (e.out2) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(e.out2) + off) = g8_pack4(g, G8_K / e.drop.scale); }
   }
 }
 
@@ -167,7 +201,11 @@ constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-
 template <int EPI, int NI, bool SEQ, bool FULL>
 __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
                                                           const float* bias_lds) {
-  constexpr int NOUT = (EPI == GSL_EPI_BIAS_GELU) ? 2 : 1;
+  constexpr int NOUT = epi_is_gelu<EPI>() ? 2 : 1;
+  constexpr bool G8 = (EPI == GSL_EPI_BIAS_GELU_G8);      // second output as the 8-bit GELU' code: staged as bytes (80-byte rows: conflict-free
+  static_assert(!(G8 && SEQ), "the 8-bit GELU' output is staged beside the first one");      // dword writes), copied out as 64-byte row segments
+  uint8_t* c8 = reinterpret_cast<uint8_t*>(cst + 64 * CLD);
+  const float kq8 = G8_K / e.drop.scale;
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
   float bj[4][4];        // this lane's bias values for its 4 column fragments
@@ -196,7 +234,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
       hwrap = img - (size_t)e.hmT * 64;
     }
   }
-  constexpr bool DROPW = (EPI == GSL_EPI_BIAS_GELU);
+  constexpr bool DROPW = epi_is_gelu<EPI>();
   uint32_t wbase = 0u, rowstep = 0u;
   if constexpr (DROPW) {
     if (e.drop.thr) {
@@ -226,7 +264,9 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
         *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        if constexpr (NOUT == 2) {
+        if constexpr (G8) {
+          *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) = g8_pack4(g, kq8);
+        } else if constexpr (NOUT == 2) {
           const uint2 pg = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
           if constexpr (SEQ) held[ii][j] = pg; else *reinterpret_cast<uint2*>(d + 64 * CLD) = pg;
         }
@@ -253,7 +293,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
             if (e.hmT) off = hrow;
           }
           if (dst) store_stream16(dst + off, val, e.stmode);
-          if constexpr (NOUT == 2 && !SEQ) {
+          if constexpr (NOUT == 2 && !SEQ && !G8) {
             if (e.out2) {
               const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
               store_stream16(reinterpret_cast<bf16_t*>(e.out2) + off, val2, e.stmode);
@@ -262,6 +302,19 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         }
         if constexpr (EPI == GSL_EPI_STORE) {
           if (e.hmT) { ht += 8; hrow += 8 * 64; while (ht >= e.hmT) { ht -= e.hmT; hrow += hwrap; } }
+        }
+      }
+    }
+    if constexpr (G8) {      // 64 rows x 64 code bytes: 4 lanes x 16 B per row, 16 rows per instruction
+      if (e.out2) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = rr * 16 + (lane >> 2), c16 = lane & 3;
+          const int m = mw + ib * 16 + row, n = nw + c16 * 16;
+          if (FULL || (m < e.M && n < e.N)) {
+            const uint4 val = *reinterpret_cast<const uint4*>(c8 + row * 80 + c16 * 16);
+            store_stream16(reinterpret_cast<uint8_t*>(e.out2) + (size_t)m * (size_t)e.ldo + (size_t)n, val, e.stmode);
+          }
         }
       }
     }
@@ -283,11 +336,14 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
 // row-contiguous, and aux is loaded / the result stored as full 128-byte rows (16 B per lane). Same arithmetic as epi_math<MUL>:
 // bf16( alpha * acc * f32(aux) ), one rounding — bit-identical to the fragment-layout path.
 constexpr int CLF = 68;    // floats per staged row (272 B: 16-byte aligned)
-template <int NI>
+template <int NI, int EPI = GSL_EPI_MUL>
 __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  constexpr bool G8 = (EPI == GSL_EPI_MUL_G8);      // aux = the 8-bit GELU' code: 8 bytes per lane and row instead of 16
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
+  const uint8_t* aux8 = reinterpret_cast<const uint8_t*>(e.aux);
+  const float sq8 = e.drop.scale / G8_K;
   bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
@@ -295,7 +351,8 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
 #pragma unroll
     for (int r = 0; r < 8; ++r) {      // aux rows of this 64-row chunk: issued first, consumed after the LDS round trip
       const int m = min(mw + ib * 16 + r * 8 + crow, e.M - 1), n = min(nw + cch * 8, e.N - 8);
-      ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + n);
+      if constexpr (G8) { const uint2 t = *reinterpret_cast<const uint2*>(aux8 + (size_t)m * e.ldo + n); ax[r].x = t.x; ax[r].y = t.y; }
+      else ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + n);
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -311,12 +368,20 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
       const int m = mw + ib * 16 + row, n = nw + cch * 8;
       const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
       const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
-      const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
       uint32_t o[4];
+      if constexpr (G8) {
+        float ga[4], gb[4];
+        g8_unpack4(ax[r].x, sq8, ga);
+        g8_unpack4(ax[r].y, sq8, gb);
+        o[0] = pack2bf(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2bf(lo[2] * ga[2], lo[3] * ga[3]);
+        o[2] = pack2bf(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2bf(hi[2] * gb[2], hi[3] * gb[3]);
+      } else {
+        const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
-        o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+        for (int k = 0; k < 4; ++k) {
+          const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
+          o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+        }
       }
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), e.stmode);
     }
@@ -341,6 +406,7 @@ typedef __attribute__((address_space(3))) gf_v4s_t* gf_lds_v4s_p;
 union GfFrag { gf_v4s_t h[2]; bf16x8_t v; };
 // global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
 struct GfOperands { uint4 ax[4], hx[4], u1a, u1b; };
+template <bool G8>
 __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int mw, int nw, int ic, int lane) {
   const int crow = lane >> 3, cch = lane & 7;
   const int ncl = min(nw + cch * 8, e.N - 8);
@@ -348,7 +414,12 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
-    g.ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + ncl);
+    if constexpr (G8) {      // 8-bit GELU' codes: 8 bytes per lane and row (only .x / .y of the slot are live)
+      const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(e.aux) + (size_t)m * e.ldo + ncl);
+      g.ax[r].x = t.x; g.ax[r].y = t.y;
+    } else {
+      g.ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + ncl);
+    }
     g.hx[r] = *reinterpret_cast<const uint4*>(e.gy2 + (size_t)m * e.ldo + ncl);
   }
   const bf16_t* up = e.gu1 + (size_t)min(mw + ic * 32 + (lane & 31), e.M - 1) * e.ldgu1;
@@ -356,7 +427,7 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
   g.u1b = *reinterpret_cast<const uint4*>(up + 8);
 }
 // go: the operands of round 0, requested by the caller (right after the K loop, in front of the rank-r tail)
-template <int NI>
+template <int NI, bool G8>
 __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_t (&acc)[NI][4], char* wreg, char* partner,
                                                         const bf16_t* t16w, int mw, int nw, int lane, int wm, int mtile, GfOperands& go) {
   float* cst = reinterpret_cast<float*>(wreg);
@@ -378,7 +449,8 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   uint4 (&ax)[4] = go.ax;
   uint4 (&hx)[4] = go.hx;
   uint4 &u1a = go.u1a, &u1b = go.u1b;
-  auto request = [&](int ic) { gf_request(e, go, mw, nw, ic, lane); };
+  auto request = [&](int ic) { gf_request<G8>(e, go, mw, nw, ic, lane); };
+  const float sq8 = e.drop.scale / G8_K;
 #pragma unroll
   for (int ic = 0; ic < NI / 2; ++ic) {
 #pragma unroll
@@ -396,12 +468,20 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       const int m = mw + ic * 32 + row, n = nw + cch * 8;
       const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
       const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
-      const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
       uint32_t o[4];
+      if constexpr (G8) {
+        float ga[4], gb[4];
+        g8_unpack4(ax[r].x, sq8, ga);
+        g8_unpack4(ax[r].y, sq8, gb);
+        o[0] = pack2bf(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2bf(lo[2] * ga[2], lo[3] * ga[3]);
+        o[2] = pack2bf(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2bf(hi[2] * gb[2], hi[3] * gb[3]);
+      } else {
+        const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
-        o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+        for (int k = 0; k < 4; ++k) {
+          const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
+          o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+        }
       }
       const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, e.stmode);
@@ -804,7 +884,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
   }
   if constexpr (!epi_out_is_f32<EPI>()) {
     static_assert(3 * ST3 >= CST_BLOCK8, "C staging must fit in the stage ring");
-    if (ABL == 0 && (e.N % 8) == 0 && (e.ldo % 8) == 0) {
+    if (ABL == 0 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && (EPI != GSL_EPI_BIAS_GELU_G8 || ((e.N % 16) == 0 && (e.ldo % 16) == 0))) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stage ring: reuse it for C staging
       epilogue_staged_bf16<EPI, 4>(e, acc, smem + wave * CST_WAVE, m0 + wm * 64, n0 + wn * 64, lane);
       return;
@@ -858,7 +938,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
   resolve_drop(e.drop);
   constexpr int STG = LORA ? ST4L : ST4;
-  static_assert(!GRAD || (LORA && EPI == GSL_EPI_MUL), "GRAD is the gradient-fused form of the in-kernel-LoRA MUL GEMM");
+  static_assert(!GRAD || (LORA && epi_is_mul<EPI>()), "GRAD is the gradient-fused form of the in-kernel-LoRA MUL GEMM");
   static_assert(!GRAD || 2 * STG * 2 <= 8 * GF_WAVE_B, "t16 must lie behind the K-loop stages");
   constexpr int SMEM_E = GRAD ? GF_BLOCK_B / 2 : ((2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8);
   __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_E];   // stages, then C staging
@@ -1057,7 +1137,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     // first LDS store) and behind the Q fragments (vmcnt retires in order: the MFMAs below must not wait for these ten loads).
     asm volatile("" ::: "memory");
     GfOperands go;
-    gf_request(e, go, m0 + wm * 128, n0 + wn * 64, 0, lane);
+    gf_request<EPI == GSL_EPI_MUL_G8>(e, go, m0 + wm * 128, n0 + wn * 64, 0, lane);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(t16 + (wm * 128 + i * 16 + fr) * 16 + (fc & 1) * 8);
@@ -1067,7 +1147,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
     __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
-    epilogue_staged_mulgrad<8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
+    epilogue_staged_mulgrad<8, EPI == GSL_EPI_MUL_G8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
                                t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4, go);
     if (dbg8) dbg8[3] = __builtin_readcyclecounter();
     return;
@@ -1124,11 +1204,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
   }
   if constexpr (!epi_out_is_f32<EPI>()) {
-    if ((e.N % 8) == 0 && (e.ldo % 8) == 0) {
+    if ((e.N % 8) == 0 && (e.ldo % 8) == 0 && (EPI != GSL_EPI_BIAS_GELU_G8 || ((e.N % 16) == 0 && (e.ldo % 16) == 0))) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages: reuse them for C staging
-      if constexpr (EPI == GSL_EPI_MUL) {
+      if constexpr (epi_is_mul<EPI>()) {
         if (e.N >= 8) {
-          epilogue_staged_mul<8>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+          epilogue_staged_mul<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
           if (dbg8) dbg8[3] = __builtin_readcyclecounter();
           return;
         }
@@ -1260,7 +1340,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         return check_launch("gsl_gemm_nt(iw)");
       }
     }
-    if constexpr (EPI != GSL_EPI_BIAS_RES_BF16 && EPI != GSL_EPI_PATCH_BF16) {
+    if constexpr (EPI != GSL_EPI_BIAS_RES_BF16 && EPI != GSL_EPI_PATCH_BF16 && EPI != GSL_EPI_MUL_G8 && EPI != GSL_EPI_BIAS_GELU_G8) {
       if (variant == 9) {
         EpiArgs e9 = e;
         if (EPI != GSL_EPI_PATCH) { const char* sg = getenv("GSL_STAGGER"); e9.T = sg ? atoi(sg) : 0; }
@@ -1349,6 +1429,12 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
     case GSL_EPI_MUL:
       GSL_CHECK_ARG(aux, "aux required");
       return launch_gemm<GSL_EPI_MUL>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_BIAS_GELU_G8:
+      GSL_CHECK_ARG(bias && dtype == GSL_BF16, "bias required, bf16 only");
+      return launch_gemm<GSL_EPI_BIAS_GELU_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_MUL_G8:      // aux = 8-bit GELU' codes [M, ldo bytes]; p_drop = the dropout rate of the forward that wrote them (no mask is applied here)
+      GSL_CHECK_ARG(aux && dtype == GSL_BF16, "aux required, bf16 only");
+      return launch_gemm<GSL_EPI_MUL_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_PATCH:
       GSL_CHECK_ARG(bias && pos && cls && T > 0, "bias/pos/cls/T required");
       return launch_gemm<GSL_EPI_PATCH>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -1398,6 +1484,8 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
     case GSL_EPI_BIAS_RES_BF16: GSL_CHECK_ARG(bias && res && (ldo % 8) == 0, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_BF16); break;
     case GSL_EPI_BIAS_GELU: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU); break;
     case GSL_EPI_MUL: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL); break;
+    case GSL_EPI_BIAS_GELU_G8: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU_G8); break;
+    case GSL_EPI_MUL_G8: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL_G8); break;
     default: return fail(GSL_ERR_ARG, "gsl_gemm_nt_lora: unsupported epilogue%s %ld", "", epilogue);
   }
 #undef GSL_LL
@@ -1445,7 +1533,8 @@ extern "C" long gsl_gemm_mulgrad_ws_elems(int M, int N, int r) {
 extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
                                         int ldq, float lora_scale, void* tout, int ldt, int M, int N, const void* aux, void* out,
                                         int ldo, const void* U1, int ldu1, float* G1, long g1sn, long g1sj, const void* Y2, float* G2,
-                                        long g2sn, long g2sj, int r, int accumulate, float* ws, gsl_stream_t s) {
+                                        long g2sn, long g2sj, int r, int accumulate, float* ws, int aux_u8, float p_drop, gsl_stream_t s) {
+  GSL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "p_drop");
   GSL_CHECK_ARG(M > 0 && N >= 8 && (N % 8) == 0 && K > 0 && (K % 64) == 0, "M>0, N%8==0, K%64==0");
   GSL_CHECK_ARG(A && W && P && Q && out && aux && U1 && G1 && Y2 && G2 && ws, "null operand");
   GSL_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (ldp % 8) == 0 && (ldq % 8) == 0 && ldq >= 32 && (ldo % 8) == 0 && ldo >= N &&
@@ -1455,6 +1544,7 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   EpiArgs e;
   e.alpha = 1.0f; e.bias = nullptr; e.res = nullptr; e.aux = aux; e.out = out; e.out2 = nullptr; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(0.f, 0, 0); e.M = M; e.N = N;
+  e.drop.scale = 1.0f / (1.0f - p_drop);      // only the decode of the 8-bit GELU' codes reads it: no mask is applied in this kernel
   set_launch_knobs(e, false);   // K rotation stays off: every N tile must accumulate t = s A P^T in the same K order (G2 contracts the tile-local t, which has to equal tout bit for bit)
   e.hmT = 0; e.hmH = 0;
   const int R = (r <= 8) ? 8 : 16;
@@ -1467,8 +1557,12 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ntile * ((N + BN4 - 1) / BN4);
   hipStream_t st = as_stream(s);
-  hipLaunchKernelGGL((gemm_bf16_p8_kernel<GSL_EPI_MUL, true, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,
-                     ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);
+  if (aux_u8)
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<GSL_EPI_MUL_G8, true, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,
+                       ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);
+  else
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<GSL_EPI_MUL, true, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,
+                       ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);
   int rc = check_launch("gsl_gemm_nt_lora_mulgrad");
   if (rc) return rc;
   const int NR4 = (int)(NR / 4);

@@ -18,6 +18,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "libgslora_hip_dev.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM, EPI_BIAS_RES_BF16, EPI_PATCH_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+EPI_MUL_G8, EPI_BIAS_GELU_G8 = 9, 10
 NORM_SPLIT = 8
 SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 
@@ -34,7 +35,7 @@ SIGNATURES = {
                          _f, _u64, _u32, _vp],
     "gsl_gemm_mulgrad_ws_elems": [_i, _i, _i],
     "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
-                                 _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _vp],
+                                 _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _i, _f, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],

@@ -93,16 +93,17 @@ def gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, *, epilogue=L.EPI_STORE, bia
     return out
 
 
-def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True, tag=None):
+def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True, tag=None, p_drop=0.0):
     """out = (A W^T + t Q^T) * aux with t = lora_scale * A P^T (as gemm_nt_lora, epilogue MUL) and, from the same tiles,
-    G1[n*g1s[0] + j*g1s[1]] (+)= sum_m out[m,n] U1[m,j] and G2[n*g2s[0] + j*g2s[1]] (+)= sum_m Y2[m,n] t[m,j]."""
+    G1[n*g1s[0] + j*g1s[1]] (+)= sum_m out[m,n] U1[m,j] and G2[n*g2s[0] + j*g2s[1]] (+)= sum_m Y2[m,n] t[m,j].
+    A uint8 aux is the 8-bit GELU' code of EPI_BIAS_GELU_G8; p_drop is then the dropout rate of the forward that wrote it."""
     _need(A, W, P, Q, tout, out, aux, U1, Y2)
     M, K = A.shape
     N = W.shape[0]
     if PROFILE is not None and tag in PROFILE:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate)
+        gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate, p_drop=p_drop)
         ev[1].record()
         PROFILE[tag].append((ev[0], ev[1], M, N, K, 0))
         return out
@@ -120,7 +121,8 @@ def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2
     L.check(lib.gsl_gemm_nt_lora_mulgrad(_p(A), A.stride(0), _p(W), W.stride(0), K, _p(P), P.stride(0), _p(Q), Q.stride(0),
                                          float(lora_scale), _p(tout), 0 if tout is None else tout.stride(0), M, N, _p(aux), _p(out),
                                          out.stride(0), _p(U1), U1.stride(0), G1.data_ptr(), g1s[0], g1s[1], _p(Y2), G2.data_ptr(),
-                                         g2s[0], g2s[1], r, 1 if accumulate else 0, _p(ws), _stream()), "gsl_gemm_nt_lora_mulgrad")
+                                         g2s[0], g2s[1], r, 1 if accumulate else 0, _p(ws), 1 if aux.dtype == torch.uint8 else 0,
+                                         float(p_drop), _stream()), "gsl_gemm_nt_lora_mulgrad")
     return out
 
 

@@ -31,6 +31,10 @@ FWD_STREAM_BF16 = os.environ.get("GSLORA_FWD_STREAM", "bf16").lower() != "f32"
 # tail run on B rows instead of B*T (exact: the skipped rows influence no output of the model). GSLORA_TAIL_CLS=0 keeps the dense forward
 # (the backward then still runs on the cls rows).
 TAIL_CLS = os.environ.get("GSLORA_TAIL_CLS", "1") != "0"
+# bf16 speed mode stores g' = GELU'(.) * dropmask / (1 - p) — written by the fused FFN1 epilogue, read once by the FFN2-dX epilogue — as an
+# 8-bit fixed-point code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN.
+# GSLORA_GP8=0 keeps it in bf16 (the parity mode always keeps it in f32).
+GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
 # layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
 # read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
 QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
@@ -381,18 +385,20 @@ class ViTRunner:
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
             u1 = u2 = None
             h = torch.empty(Mr, mlp, device=img.device, dtype=dt)
-            gp = torch.empty(Mr, mlp, device=img.device, dtype=dt) if save else None
+            gp8 = GP8 and dt == torch.bfloat16 and save
+            epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
+            gp = torch.empty(Mr, mlp, device=img.device, dtype=torch.uint8 if gp8 else dt) if save else None
             if lora_on:
                 u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
                 ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
-                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, A2=u1,
+                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, A2=u1,
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                             p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
                 u2 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
                 if not self.lora_in_kernel(dt, Mr):
                     ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
-                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=L.EPI_BIAS_GELU, bias=l1.bias.detach(),
+                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, bias=l1.bias.detach(),
                             out2=gp, p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag)
             x2 = torch.empty(Mr, D, device=img.device, dtype=xdt)
             if lora_on and self.lora_in_kernel(dt, Mr):
@@ -476,6 +482,7 @@ class ViTRunner:
             Mrows = dyb.shape[0]
             # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
             ink = self.lora_in_kernel(dt, Mrows)
+            epi_mul = L.EPI_MUL_G8 if gp.dtype == torch.uint8 else L.EPI_MUL      # g' as the 8-bit code of the forward (decode scale from p_drop)
             v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
             fused_grads = ink and FUSE_LORA_GRAD
@@ -484,14 +491,14 @@ class ViTRunner:
                 # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
                 ops.gemm_nt_lora_mulgrad(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                          self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, gp,
-                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx")
+                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx", p_drop=p_drop)
             elif ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
                 ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
-                                 self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=L.EPI_MUL, aux=gp)
+                                 self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=epi_mul, aux=gp, p_drop=p_drop)
             else:
                 ops.gemm_nt(dyb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
-                ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, A2=v2,
-                            W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp)
+                ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=epi_mul, A2=v2,
+                            W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp, p_drop=p_drop)
             ops.lora_grad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                # dB2[c, j]
             if not fused_grads:
                 ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)            # dA2[j, hid]
@@ -585,7 +592,8 @@ class ViTRunner:
             Mrows = dyb.shape[0]
             # ---- frozen FFN sub-layer: dX only
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
-            ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL, aux=gp)
+            ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=L.EPI_MUL_G8 if gp.dtype == torch.uint8 else L.EPI_MUL, aux=gp,
+                        p_drop=p_drop)
             dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
             ops.gemm_nt(da, self.wT(f"w1_{i}", l1.weight, dt), dxn2)
             del da

@@ -51,7 +51,12 @@ enum gsl_epilogue {
                                head-major layout [B][H][3][T][64] that the attention entry points read with qkv_layout = 1 */
   GSL_EPI_BIAS_RES_BF16 = 7,/* bf16 only, the forward residual stream carried in bf16: out[bf16] = bf16(dropout(acc + bias) + f32(res[bf16]))
                                — f32 arithmetic on the f32 accumulator, one rounding on store; same dropout mask as BIAS_RES_F32 */
-  GSL_EPI_PATCH_BF16 = 8    /* bf16 only: PATCH with a bf16 output */
+  GSL_EPI_PATCH_BF16 = 8,   /* bf16 only: PATCH with a bf16 output */
+  GSL_EPI_MUL_G8 = 9,       /* bf16 only: MUL with aux = the 8-bit GELU' code u8 [M, ldo bytes] written by BIAS_GELU_G8;
+                               p_drop = the dropout rate of the forward that wrote it (decode scale 1/(1-p); no mask is applied here) */
+  GSL_EPI_BIAS_GELU_G8 = 10 /* bf16 only: BIAS_GELU whose second output is the 8-bit fixed-point code of gelu'(acc+bias)*dropmask:
+                               out2 u8 [M, ldo bytes], q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p).
+                               gelu' lies in [-0.129, 1.129]: absolute error <= 0.0025/(1-p), a dropped element decodes to exactly 0 */
 };
 
 GSL_API int gsl_version(void);
@@ -83,7 +88,7 @@ GSL_API int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int 
  *   out = epilogue(A*W^T + t*Q^T),  t = lora_scale * (A*P^T)
  *   A [M,K] (lda), W [N,K] (ldw), P [16,K] (ldp; rows >= r zero), Q [N,32] (ldq >= 32; cols >= r zero), K % 64 == 0.
  *   tout (nullable) [M, ldt >= 64] receives t in bf16, zero padded to 64 columns (input of gsl_lora_grad).
- * Epilogues: STORE, BIAS_RES_F32, BIAS_RES_BF16, BIAS_GELU, MUL. */
+ * Epilogues: STORE, BIAS_RES_F32, BIAS_RES_BF16, BIAS_GELU, BIAS_GELU_G8, MUL, MUL_G8. */
 GSL_API int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K,
                      const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
                      int M, int N, int dtype, int epilogue,
@@ -95,14 +100,15 @@ GSL_API int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int
  *   G1[n*g1sn + j*g1sj] (+)= sum_m out[m,n] * U1[m,j]      (dB of the up-projection adapter: loralib autograd of vit_face.py:330)
  *   G2[n*g2sn + j*g2sj] (+)= sum_m Y2[m,n] * t[m,j]        (dA of the down-projection adapter; Y2 = the saved FFN hidden activation)
  * U1 [M, ldu1 >= 16] bf16 (columns r..15 zero or discarded), Y2 / aux / out [M,N] bf16 with row stride ldo, N % 8 == 0.
- * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible). */
+ * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible).
+ * aux_u8 != 0: aux is the 8-bit GELU' code of GSL_EPI_BIAS_GELU_G8 (u8 [M, ldo bytes]) and p_drop the dropout rate of that forward. */
 GSL_API long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
 GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
                              const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
                              int M, int N, const void* aux, void* out, int ldo,
                              const void* U1, int ldu1, float* G1, long g1sn, long g1sj,
                              const void* Y2, float* G2, long g2sn, long g2sj,
-                             int r, int accumulate, float* ws, gsl_stream_t s);
+                             int r, int accumulate, float* ws, int aux_u8, float p_drop, gsl_stream_t s);
 
 /* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x — the residual stream — is `x_dtype` (f32; bf16 when the bf16
  * speed mode carries the forward stream in bf16), rows of length D at stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M].

@@ -10,6 +10,12 @@
   tests/golden/chain2.npz           two tasks chained the way train_own_forget_cl.py does it: train -> eval() -> save merged state ->
                                     load_state_dict -> reinitialize_lora_parameters -> train.
 
+  tests/golden/engine_cl_acc.npz     the trajectory's model evaluated by the real eval_data on 1 000 + 1 000 held-out samples before / after
+                                    the 24 steps: accuracies at 0.1 pp resolution + per-sample predictions and decision margins.
+
+  tests/golden/chain4.npz            BASELINE config 3 as written: four tasks with the shipped per-task beta / prototype-weight lists, the
+                                    alpha warm-up switch and the EMA model (its un-merged-into-merged quirk included).
+
 Inputs come from oracle/scenarios.py (shared with tests/test_hip_engines.py); fixtures hold OUTPUTS only.
 Usage: python oracle/make_golden_engines.py [traj] [single] [chain]
 """
@@ -168,6 +174,61 @@ def gen_traj(out):
                                        if not k.startswith("eval_logits") and not k.startswith("eval_emb") and "::" not in k and "row7" not in k})
 
 
+def gen_acc(out):
+    """tests/golden/engine_cl_acc.npz: the trajectory scenario (same model, head, loaders, 24 steps of the real engine_cl.train_one_epoch)
+    evaluated with the REAL eval_data on 1 000 + 1 000 held-out samples before and after training: accuracies at 0.1 pp resolution and
+    the per-sample predictions (argmax of the margin logits, as eval_data takes it, engine_cl.py:336-339)."""
+    import engine_cl
+    from util import utils as rutil
+    cfg, T, A = recipe.cfg_full(), S.TRAJ, S.ACC
+    rem, forg, _, _ = S.class_loaders(cfg, T["n_remain"], T["n_forget"], T["batch"])
+    big_rem, big_forg = S.class_eval_loaders(cfg, A["n_per_split"], A["batch"])
+    g = np.load(os.path.join(out, "engine_cl_traj.npz"))
+    state = recipe.make_state(cfg)
+    state["mlp_head.0.bias"], state["loss.weight"] = g["head_bias"], g["loss_weight"]
+    model = build_reference_model(cfg, state)
+    proto = S.prototypes(cfg)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=T["lr"], weight_decay=T["wd"], eps=1e-8)
+    crit = torch.nn.CrossEntropyLoss()
+    dev = torch.device("cpu")
+    res = {}
+
+    def snapshot(tag):
+        t0 = time.time()
+        with torch.no_grad():
+            res[f"acc_forget_{tag}"] = np.float64(engine_cl.eval_data(model, big_forg, dev, "forget", 0))
+            res[f"acc_remain_{tag}"] = np.float64(engine_cl.eval_data(model, big_rem, dev, "remain", 0))
+            model.eval()
+            for kind, ld in (("forget", big_forg), ("remain", big_rem)):
+                lo = torch.cat([model(x, y)[0] for x, y in ld.batches])
+                res[f"pred_{kind}_{tag}"] = lo.argmax(1).numpy().astype(np.int16)
+                top2 = lo.topk(2, dim=1).values
+                res[f"margin_{kind}_{tag}"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)     # how close each decision is
+        model.train()
+        print(f"[golden] acc snapshot {tag}: forget {res[f'acc_forget_{tag}']:.2f} remain {res[f'acc_remain_{tag}']:.2f} ({time.time() - t0:.0f} s)", flush=True)
+
+    snapshot("before")
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": T["BND_pro"], "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+    meters = fresh_meters(rutil)
+    batch_ctr = 0
+    with UpdateLog(rutil) as log:
+        for epoch in range(T["epochs"]):
+            for gq in opt.param_groups:
+                gq["lr"] = S.cosine_lr(epoch, T["epochs"], T["lr"], T["lr_min"])
+            ret = engine_cl.train_one_epoch(
+                model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=epoch,
+                beta=T["beta"], alpha=T["alpha"], BND=T["BND"], batch=batch_ctr, testloader_forget=None, testloader_remain=None,
+                forget_acc_before=T["forget_acc_before"], highest_H_mean=0.0, cfg=cfgd, task_i="0", use_prototype=True,
+                prototype_dict=proto, prototype_weight_forget=T["pro_f_weight"], prototype_weight_remain=T["pro_r_weight"], **meters)
+            batch_ctr = ret[0]
+            meters = dict(losses_forget=ret[2], losses_remain=ret[3], top1_forget=ret[4], top1_remain=ret[5], losses_total=ret[6],
+                          losses_structure=ret[7], losses_prototype_forget=ret[8], losses_prototype_remain=ret[9])
+    assert np.abs(log.steps() - g["step_updates"]).max() == 0.0, "the trajectory must be the one of engine_cl_traj.npz"
+    snapshot("after")
+    np.savez_compressed(os.path.join(out, "engine_cl_acc.npz"), **res)
+    print("[golden] engine_cl_acc:", {k: float(v) for k, v in res.items() if k.startswith("acc_")})
+
+
 def gen_single(out):
     import engine as eng
     from util import utils as rutil
@@ -268,6 +329,123 @@ def gen_chain(out):
           float(np.abs(res["logits_after_reload_reinit"] - res["task0::eval_logits"]).max()))
 
 
+def gen_chain4(out):
+    """tests/golden/chain4.npz — BASELINE config 3 as the reference runs it: four tasks with per-task cl_beta_list / cl_prof_list, the
+    alpha warm-up switch and the EMA model, issued by hand in the order of train/train_own_forget_cl.py (:502-507 EMA copy in eval(),
+    :515-536 reload + re-init, :803-834 per-task counters and meters, :999-1011 per-task / per-epoch hyper-parameters, :1013 scheduler
+    step, :1015-1056 train_one_epoch, :1058-1098 EMA update + eval, :1100-1106 norms, :1696-1705 merged save). The statements between
+    the `# ref` marks restate those lines on an argparse-like namespace; everything they call is the REAL reference code."""
+    import copy
+    import types
+    import engine_cl
+    from util import utils as rutil
+    from util.cal_norm import get_norm_of_lora
+    cfg, C = recipe.cfg_small6(), S.CHAIN4
+    args = types.SimpleNamespace(cl_beta_list=list(C["cl_beta_list"]), cl_prof_list=list(C["cl_prof_list"]), warmup_alpha=C["warmup_alpha"],
+                                 alpha_epoch=C["alpha_epoch"], big_alpha=C["big_alpha"], alpha=C["alpha"], pro_f_weight=C["pro_f_weight"],
+                                 pro_r_weight=C["pro_r_weight"], average_weight=True, ema_epoch=C["ema_epoch"], ema_decay=C["ema_decay"],
+                                 BND=C["BND"], num_tasks=C["num_tasks"], prototype=True)
+    BACKBONE = build_reference_model(cfg, recipe.make_state(cfg))
+    DEVICE = torch.device("cpu")
+    LOSS = torch.nn.CrossEntropyLoss()
+    prototype = S.prototypes(cfg, C["proto_scale"])
+    res = {}
+    work = tempfile.mkdtemp(prefix="gsl_golden_")
+    os.makedirs(os.path.join(work, "task-level"))
+    cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": C["BND_pro"], "MULTI_GPU": False, "WORK_PATH": work, "BACKBONE_NAME": "VIT"}
+    x_ev = torch.tensor(recipe.make_images(cfg, 4, seed=902, tag="xev"))
+    y_ev = torch.tensor(recipe.make_labels(cfg, 4, seed=902, tag="yev"))
+    # ref :502-509
+    BACKBONE.eval()
+    ema_model = copy.deepcopy(BACKBONE)
+    BACKBONE.train()
+    for task_i in range(args.num_tasks):
+        if task_i > 0:      # ref :524-536
+            BACKBONE.load_state_dict(torch.load(os.path.join(work, "task-level", "Backbone_task_{}.pth".format(task_i - 1))))
+            rutil.reinitialize_lora_parameters(BACKBONE)
+            with torch.no_grad():      # seeded adapter matrices (the kaiming draws come from the device RNG)
+                for k, v in S.chain_lora_A(cfg, task_i).items():
+                    BACKBONE.get_parameter(k).copy_(v)
+        train_loader_remain, train_loader_forget, testloader_remain, testloader_forget = S.chain4_task(cfg, task_i)
+        highest_H_mean = 0.0      # ref :803
+        OPTIMIZER = torch.optim.AdamW([p for p in BACKBONE.parameters() if p.requires_grad], lr=C["lr"], weight_decay=C["wd"], eps=1e-8)
+        batch = 0                 # ref :824
+        meters = fresh_meters(rutil)      # ref :827-834
+        with torch.no_grad():
+            forget_acc_before = engine_cl.eval_data(BACKBONE, testloader_forget, DEVICE, "forget-{}".format(task_i), batch)
+            remain_acc_before = engine_cl.eval_data(BACKBONE, testloader_remain, DEVICE, "remain-{}".format(task_i), batch)
+        res[f"task{task_i}::acc_before"] = np.array([forget_acc_before, remain_acc_before])
+        # ref :999-1004
+        cl_beta = args.cl_beta_list[task_i]
+        if len(args.cl_prof_list) != 0:
+            args.pro_f_weight = args.cl_prof_list[task_i]
+        BACKBONE.train()
+        hyper, ema_accs = [], []
+        with UpdateLog(rutil) as log:
+            for epoch in range(C["epochs"]):
+                if args.warmup_alpha:      # ref :1007-1011
+                    if epoch < args.alpha_epoch:
+                        args.alpha = 0
+                    else:
+                        args.alpha = args.big_alpha
+                for g in OPTIMIZER.param_groups:      # ref :1013 lr_scheduler.step(epoch) (timm cosine, restated in scenarios.cosine_lr)
+                    g["lr"] = S.cosine_lr(epoch, C["epochs"], C["lr"], C["lr_min"])
+                hyper.append([cl_beta, args.pro_f_weight, args.alpha, OPTIMIZER.param_groups[0]["lr"]])
+                ret = engine_cl.train_one_epoch(      # ref :1015-1056
+                    model=BACKBONE, dataloader_forget=train_loader_forget, dataloader_remain=train_loader_remain,
+                    testloader_forget=testloader_forget, testloader_remain=testloader_remain, device=DEVICE, criterion=LOSS,
+                    optimizer=OPTIMIZER, epoch=epoch, batch=batch, beta=cl_beta, BND=args.BND, forget_acc_before=forget_acc_before,
+                    highest_H_mean=highest_H_mean, cfg=cfgd, alpha=args.alpha, task_i=task_i, use_prototype=args.prototype,
+                    prototype_dict=prototype, prototype_weight_forget=args.pro_f_weight, prototype_weight_remain=args.pro_r_weight,
+                    **meters)
+                batch, highest_H_mean = ret[0], ret[1]
+                meters = dict(losses_forget=ret[2], losses_remain=ret[3], top1_forget=ret[4], top1_remain=ret[5], losses_total=ret[6],
+                              losses_structure=ret[7], losses_prototype_forget=ret[8], losses_prototype_remain=ret[9])
+                if args.average_weight:      # ref :1058-1098
+                    if epoch == args.ema_epoch:
+                        with torch.no_grad():
+                            BACKBONE_COPY = copy.deepcopy(BACKBONE)
+                            ema_model.eval()
+                            for param, ema_param in zip(BACKBONE_COPY.parameters(), ema_model.parameters()):
+                                ema_param.data = param.data.detach()
+                    elif epoch > args.ema_epoch:
+                        with torch.no_grad():
+                            BACKBONE_COPY = copy.deepcopy(BACKBONE)
+                            ema_model.eval()
+                            for param, ema_param in zip(BACKBONE_COPY.parameters(), ema_model.parameters()):
+                                ema_param.data = ema_param.data.detach() * args.ema_decay + param.data.detach() * (1 - args.ema_decay)
+                    if epoch < args.ema_epoch:
+                        pass
+                    else:
+                        with torch.no_grad():
+                            fa = engine_cl.eval_data(ema_model, testloader_forget, DEVICE, "forget-ema-{}".format(task_i), batch)
+                            ra = engine_cl.eval_data(ema_model, testloader_remain, DEVICE, "remain-ema-{}".format(task_i), batch)
+                        ema_accs.append([fa, ra])
+        res[f"task{task_i}::step_updates"] = log.steps()
+        res[f"task{task_i}::hyper"] = np.array(hyper, dtype=np.float64)
+        res[f"task{task_i}::ema_accs"] = np.array(ema_accs, dtype=np.float64)
+        res[f"task{task_i}::batch_ctr"] = np.int64(batch)
+        res[f"task{task_i}::norm_list"] = np.array([float(v) for v in get_norm_of_lora(BACKBONE, type="L2", group_num=cfg["depth"])])
+        with torch.no_grad():
+            ema_model.eval()
+            res[f"task{task_i}::ema_eval_logits"] = ema_model(x_ev, y_ev)[0].numpy().copy()
+            res[f"task{task_i}::ema_lora_B_l1_net0"] = dict(ema_model.named_parameters())["transformer.layers.1.1.fn.fn.net.0.lora_B"].numpy().copy()
+            res[f"task{task_i}::acc_after"] = np.array([engine_cl.eval_data(BACKBONE, testloader_forget, DEVICE, "forget", batch),
+                                                        engine_cl.eval_data(BACKBONE, testloader_remain, DEVICE, "remain", batch)])
+        BACKBONE.eval()      # ref :1696-1705
+        torch.save(BACKBONE.state_dict(), os.path.join(work, "task-level", "Backbone_task_{}.pth".format(task_i)))
+        with torch.no_grad():
+            res[f"task{task_i}::eval_logits"] = BACKBONE(x_ev, y_ev)[0].numpy().copy()
+        sd = BACKBONE.state_dict()
+        res[f"task{task_i}::saved_w_l4_net3_row5"] = sd["transformer.layers.4.1.fn.fn.net.3.weight"][5].numpy().copy()
+        BACKBONE.train()
+    shutil.rmtree(work)
+    np.savez_compressed(os.path.join(out, "chain4.npz"), **res)
+    for t in range(args.num_tasks):
+        print(f"[golden] chain4 task {t}: steps {res[f'task{t}::step_updates'].shape[0]} hyper {res[f'task{t}::hyper'].tolist()} "
+              f"ema accs {res[f'task{t}::ema_accs'].tolist()} acc before/after {res[f'task{t}::acc_before']} {res[f'task{t}::acc_after']}")
+
+
 def gen_poolmean(out):
     """ViT_face(pool='mean') (vit_face.py:540): forward, eval forward and the LoRA gradients of the three-term loss on the 3-layer model."""
     import engine as eng
@@ -335,6 +513,10 @@ def main():
         gen_chain(out)
     if not only or "traj" in only:
         gen_traj(out)
+    if not only or "acc" in only:
+        gen_acc(out)
+    if not only or "chain4" in only:
+        gen_chain4(out)
     if not only or "poolmean" in only:
         gen_poolmean(out)
     if not only or "protoaug" in only:

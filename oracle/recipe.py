@@ -70,6 +70,14 @@ def cfg_small2(lora_rank=8, num_class=12):
                 mlp_dim=256, num_class=num_class, lora_rank=lora_rank, channels=3)
 
 
+def cfg_small6(lora_rank=8, num_class=12):
+    """cfg_small2 with SIX layers: the reference's engine_cl.get_structure_loss hard-codes six per-block groups (engine_cl.py:390-396),
+    so every scenario that runs the real continual engine needs depth 6."""
+    c = cfg_small2(lora_rank, num_class)
+    c["depth"] = 6
+    return c
+
+
 def param_shapes(cfg):
     """Ordered {name: shape} exactly as the reference module tree names them
     (probe of vit_pytorch_face/vit_face.py:449-521)."""

@@ -74,6 +74,23 @@ def class_loaders(cfg, n_remain, n_forget, batch, seed=0):
             mk(n_remain, 300 + 1000 * seed, "r", 3), mk(n_forget, 400 + 1000 * seed, "f", 4))
 
 
+def class_eval_loaders(cfg, n_per_split=1000, batch=40, seed=0):
+    """Large held-out evaluation sets of the class-structured scenario (eval only): `n_per_split` remain and `n_per_split` forget samples,
+    other noise draws than every training / small test image. At 1 000 samples per split one flipped prediction is 0.1 pp of accuracy —
+    the resolution north_star's "accuracy deltas < 0.1 pp" asks for. Returns (test_remain, test_forget)."""
+    assert n_per_split % batch == 0
+    nf = max(2, cfg["num_class"] // 5)
+
+    def mk(kind, img_seed):
+        lo, hi = (0, cfg["num_class"] - nf) if kind == "r" else (cfg["num_class"] - nf, cfg["num_class"])
+        b = []
+        for i in range(n_per_split // batch):
+            y = torch.tensor(recipe.make_labels(cfg, batch, seed=7000 + 1000 * seed + i, tag="yE" + kind, lo=lo, hi=hi))
+            b.append((class_images(cfg, y, img_seed * 100000 + i), y))
+        return ListLoader(b)
+    return mk("r", 5), mk("f", 6)
+
+
 def discriminative_head(emb_fn, state, cfg, loaders_, common=1.17):
     """Frozen head that makes the randomly initialised backbone discriminative on the scenario's classes (a stand-in for a pre-trained
     checkpoint, which cannot be shipped): the final LayerNorm's bias cancels the data-set mean of its output, so the embedding is the
@@ -111,6 +128,9 @@ def cosine_lr(epoch, n_epochs, lr0, lr_min):
 # ---- continual engine (engine_cl.train_one_epoch, reference engine_cl.py:12-244): a 24-step trajectory on the FULL ViT-P8S8 ----------
 TRAJ = dict(batch=4, n_remain=6, n_forget=3, epochs=4, lr=1e-2, lr_min=1e-5, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, BND_pro=2.0,
             pro_f_weight=0.05, pro_r_weight=0.1, forget_acc_before=100.0)
+# accuracy evidence at 0.1 pp resolution (tests/golden/engine_cl_acc.npz): the same 24 steps, evaluated before / after on
+# class_eval_loaders(n_per_split, batch) with the reference's eval_data; per-sample predictions are kept so that flips can be counted
+ACC = dict(n_per_split=1000, batch=40)
 # second part, continued from the trajectory's end state: one more epoch starting at batch counter 97, so that engine_cl.evaluate runs
 # inside train_one_epoch at batch 99 (VER_FREQ 100): eval accuracies, H-mean, checkpoint save + prune (engine_cl.py:247-315)
 EVAL = dict(batch0=97, forget_acc_before=100.0)
@@ -133,6 +153,24 @@ SINGLE_HYPER = dict(lr=1e-2, wd=0.05, beta=0.15, alpha=1e-2, BND=105.0, pro_f_we
 # ---- two-task chain (train -> eval() -> save merged -> reload -> reinitialize -> train; train_own_forget_cl.py:515-536,1696-1705) -------
 CHAIN = dict(batch=2, n_remain=3, n_forget=2, lr=1e-2, wd=0.05, betas=(0.15, 0.2), alpha=1e-2, BND=105.0, BND_pro=2.0, pro_f_weight=0.05,
              pro_r_weight=0.1)
+
+
+# ---- config 3 as written: FOUR tasks with the shipped per-task lists (scripts/run_cl_forget.sh:217-218, 231-233), alpha warm-up
+# (train_own_forget_cl.py:1007-1011: 0 before alpha_epoch, big_alpha from then on) and the EMA model (:502-507, 1058-1098), on the
+# small 6-layer model (recipe.cfg_small6: the reference's engine_cl.get_structure_loss hard-codes six groups). Two epochs per task so that the warm-up switch, the cosine step and both EMA branches (copy at ema_epoch, average
+# after it) are exercised in every task; the EMA model lives across tasks, as in the reference.
+CHAIN4 = dict(num_tasks=4, batch=3, n_remain=3, n_forget=2, n_test=2, epochs=2, lr=1e-2, lr_min=1e-5, wd=0.05,
+              cl_beta_list=(0.2, 0.25, 0.25, 0.2), cl_prof_list=(0.015, 0.06, 0.025, 0.012), warmup_alpha=True, alpha_epoch=1,
+              big_alpha=1e-2, alpha=1e-4, BND=105.0, BND_pro=2.0, pro_f_weight=0.017, pro_r_weight=0.1, ema_epoch=0, ema_decay=0.9,
+              proto_scale=1.0)
+
+
+def chain4_task(cfg, task):
+    """(train remain, train forget, test remain, test forget) ListLoaders of one task of the four-task chain."""
+    C = CHAIN4
+    rem, forg = loaders(cfg, C["n_remain"], C["n_forget"], C["batch"], seed=20 + task)
+    te_r, te_f = loaders(cfg, C["n_test"], C["n_test"], C["batch"], seed=40 + task)
+    return rem, forg, te_r, te_f
 
 
 def chain_lora_A(cfg, task):

@@ -352,6 +352,75 @@ def test_two_task_chain_f32_matches_reference(golden_dir):
         shutil.rmtree(work)
 
 
+def test_four_task_chain_through_the_driver_f32_matches_reference(golden_dir, tmp_path):
+    """BASELINE config 3 as the reference runs it, through the build's own driver (driver_cl.run_tasks): FOUR tasks with the shipped
+    per-task lists (--cl_beta_list / --cl_prof_list, scripts/run_cl_forget.sh:217-218,231-233), the alpha warm-up switch (0 before
+    alpha_epoch, big_alpha after; train_own_forget_cl.py:1007-1011), per-task optimizer / cosine schedule / counters / meters, and
+    the EMA model with the reference's quirk (:502-507, 1058-1098), against tests/golden/chain4.npz from the real reference code."""
+    import copy
+    import driver_cl
+    g = np.load(os.path.join(golden_dir, "chain4.npz"))
+    cfg, C = recipe.cfg_small6(), S.CHAIN4
+    model = build_model(cfg, "fp32", recipe.make_state(cfg))
+    f = lambda seq: [repr(float(v)) for v in seq]
+    args = driver_cl.get_args(["--num_tasks", str(C["num_tasks"]), "--epochs", str(C["epochs"]), "--lr", repr(C["lr"]), "--min_lr", repr(C["lr_min"]),
+                               "--weight_decay", repr(C["wd"]), "--cl_beta_list", *f(C["cl_beta_list"]), "--cl_prof_list", *f(C["cl_prof_list"]),
+                               "--warmup_alpha", "--alpha_epoch", str(C["alpha_epoch"]), "--big_alpha", repr(C["big_alpha"]), "--alpha", repr(C["alpha"]),
+                               "--BND", repr(C["BND"]), "--BND_pro", repr(C["BND_pro"]), "--pro_f_weight", repr(C["pro_f_weight"]),
+                               "--pro_r_weight", repr(C["pro_r_weight"]), "--average_weight", "--ema_epoch", str(C["ema_epoch"]),
+                               "--ema_decay", repr(C["ema_decay"])])
+    protos = S.prototypes(cfg, C["proto_scale"])
+    dev = torch.device("cuda")
+    x_ev = torch.tensor(recipe.make_images(cfg, 4, seed=902, tag="xev")).cuda()
+    y_ev = torch.tensor(recipe.make_labels(cfg, 4, seed=902, tag="yev")).cuda()
+    got = {}
+
+    def task_data(t, m):
+        rem, forg, te_r, te_f = S.chain4_task(cfg, t)
+        return dict(loader_f=forg, loader_r=rem, te_f=te_f, te_r=te_r, protos=protos)
+
+    def after_reinit(m, t):
+        st = {n: p.detach().cpu().numpy() for n, p in m.named_parameters() if p.requires_grad}
+        assert all(np.all(v == 0) for k, v in st.items() if k.endswith("lora_B"))
+        with torch.no_grad():
+            for k, v in S.chain_lora_A(cfg, t).items():
+                m.get_parameter(k).copy_(v.cuda())
+
+    def after_task(t, m, ema, rec):
+        with torch.no_grad():
+            ema.eval()
+            got[f"task{t}::ema_eval_logits"] = ema(x_ev, y_ev)[0].cpu().numpy()
+            got[f"task{t}::ema_lora_B_l1_net0"] = dict(ema.named_parameters())["transformer.layers.1.1.fn.fn.net.0.lora_B"].detach().cpu().numpy()
+            assert all(blk.l1.merged and blk.l2.merged for blk in ema.hip_spec().blocks)      # the quirk: flagged merged, never re-merged
+            m2 = copy.deepcopy(m).eval()
+            got[f"task{t}::eval_logits"] = m2(x_ev, y_ev)[0].cpu().numpy()
+        sd = torch.load(os.path.join(str(tmp_path), "task-level", f"Backbone_task_{t}.pth"), map_location="cpu")
+        got[f"task{t}::saved_w_l4_net3_row5"] = sd["transformer.layers.4.1.fn.fn.net.3.weight"][5].numpy()
+
+    with UpdateLog() as log:
+        report, ema = driver_cl.run_tasks(model, args, task_data, dev, str(tmp_path), cfg["depth"], after_reinit=after_reinit, after_task=after_task)
+    steps = log.steps_in_reference_order()
+    at = 0
+    for t, rec in enumerate(report):
+        n = int(g[f"task{t}::batch_ctr"])
+        assert rec["steps"] == n
+        assert relmax(steps[at:at + n], g[f"task{t}::step_updates"]) < 1e-3, t
+        at += n
+        hy = g[f"task{t}::hyper"]
+        assert np.abs(np.array(rec["hypers"]) - hy[:, :3]).max() < 1e-12 and np.abs(np.array(rec["lrs"]) - hy[:, 3]).max() < 1e-12
+        assert np.abs(np.array(rec["ema_accs"]) - g[f"task{t}::ema_accs"]).max() < 1e-9, (t, rec["ema_accs"])
+        assert np.abs(np.array([rec["forget_before"], rec["remain_before"]]) - g[f"task{t}::acc_before"]).max() < 1e-9
+        assert np.abs(np.array([rec["forget_after"], rec["remain_after"]]) - g[f"task{t}::acc_after"]).max() < 1e-9
+        assert np.abs(np.array(rec["norms"]) - g[f"task{t}::norm_list"]).max() < 1e-3
+        for k in ("ema_eval_logits", "eval_logits"):
+            assert np.abs(got[f"task{t}::{k}"] - g[f"task{t}::{k}"]).max() < 2e-3, (t, k)
+        assert np.abs(got[f"task{t}::saved_w_l4_net3_row5"] - g[f"task{t}::saved_w_l4_net3_row5"]).max() < 1e-4
+        rb = g[f"task{t}::ema_lora_B_l1_net0"]      # AdamW normalises: where |g| ~ eps, f32 summation-order noise moves a weight by a visible fraction of lr
+        assert np.abs(got[f"task{t}::ema_lora_B_l1_net0"] - rb).max() < 3e-3 * max(1.0, np.abs(rb).max())
+        assert np.abs(got[f"task{t}::ema_lora_B_l1_net0"] - rb).mean() < 1e-4
+    assert at == steps.shape[0]
+
+
 def test_pool_mean_f32_matches_reference(golden_dir):
     """ViT_face(pool='mean') (reference vit_face.py:540; no GS-LoRA script uses it, the constructor contract lists it): forward, eval
     forward and the LoRA gradients of the three-term loss against the golden of the real reference; the last block runs DENSE (every

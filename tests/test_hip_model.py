@@ -436,7 +436,7 @@ def test_own_cl_driver_ema_model_reproduces_reference_quirk(tmp_path):
     import driver_cl
     rep, out, (model, ema) = driver_cl.main(["--small", "--num_class", "20", "--num_tasks", "1", "--per_forget_cls", "4", "--epochs", "2",
                                              "--batch_size", "16", "--samples_per_class", "4", "--dtype", "fp32", "--dropout", "0.0",
-                                             "--average_weight", "--ema_epoch", "1", "--outdir", str(tmp_path)])
+                                             "--average_weight", "--ema_epoch", "1", "--ema_decay", "0.9", "--outdir", str(tmp_path)])
     assert rep[0]["ema_acc"] is not None and all(0.0 <= a <= 100.0 for a in rep[0]["ema_acc"])
     assert all(blk.l1.merged and blk.l2.merged for blk in ema.hip_spec().blocks)
     x = torch.rand(3, 3, 48, 48).cuda(); y = torch.tensor([1, 2, 3]).cuda()

@@ -827,3 +827,77 @@ def test_attention_fwd_cls_equals_the_cls_rows_of_the_dense_forward(ops, dt, B, 
     dense_l = torch.zeros(B, H, T, device="cuda"); dense_l[:, :, 0] = lse_c
     b = ops.attention_bwd_cls(qin, dense_o, d_o, dense_l, B, T, H, scale, layout=hm)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------- 8-bit GELU'
+@pytest.mark.parametrize("M,N,K1,K2,p", [(130, 128, 64, 0, 0.1), (591, 256, 128, 64, 0.0), (788, 2048, 512, 64, 0.1), (33490, 2048, 512, 64, 0.1),
+                                         (33490, 2056, 512, 0, 0.25)])
+def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
+    """GSL_EPI_BIAS_GELU_G8: the first output h is bit-identical to BIAS_GELU's; the second is the 8-bit fixed-point code of
+    gelu'(a) * keep — q = round(gelu' keep 200 + 26), decoded (q - 26) 0.005 / (1 - p): within half a step (0.0025 / (1 - p)) of the
+    bf16 kernel's own f32 value (compared through BIAS_GELU's bf16 output: + its rounding), a dropped element decodes to exactly 0,
+    and the code error has no bias. Fragment path (small M, and N % 16 != 0) and the 8-phase kernel's staged byte path."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    c = lambda t: None if t is None else t.cuda().to(dt)
+    A1, W1 = c(rnd(M, K1, seed=1)), c(rnd(N, K1, seed=2, scale=K1 ** -0.5))
+    A2 = W2 = None
+    if K2:
+        a2 = rnd(M, K2, seed=3); a2[:, 8:] = 0
+        A2, W2 = c(a2), c(rnd(N, K2, seed=4, scale=0.1))
+    bias = rnd(N, seed=5).cuda()
+    h0 = torch.empty(M, N, device="cuda", dtype=dt); g0 = torch.empty(M, N, device="cuda", dtype=dt)
+    h1 = torch.empty(M, N, device="cuda", dtype=dt); q = torch.full((M, N), 255, device="cuda", dtype=torch.uint8)
+    ops.gemm_nt(A1, W1, h0, epilogue=L.EPI_BIAS_GELU, A2=A2, W2=W2, bias=bias, out2=g0, p_drop=p, seed=7, site=5)
+    ops.gemm_nt(A1, W1, h1, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q, p_drop=p, seed=7, site=5)
+    assert torch.equal(h0, h1)
+    assert int(q.max()) <= 252
+    dec = (q.float() - 26.0) * (0.005 / (1 - p))
+    keep = ops.dropout_mask(M * N, p, 7, 5, "cuda").reshape(M, N).bool() if p > 0 else torch.ones(M, N, device="cuda", dtype=torch.bool)
+    assert (q[~keep] == 26).all() and (dec[~keep] == 0).all()
+    err = dec - g0.float()
+    half = 0.0025 / (1 - p)
+    assert (err.abs() - 2.0 ** -8 * g0.float().abs()).max() <= half * 1.02
+    assert abs(err[keep].mean().item()) < 0.1 * half                       # round-to-nearest: no bias beyond the saturated tails (gelu' -> 0-, 1-)
+    # MUL_G8 decodes it: (A W^T) * decode(q) in f32, one bf16 rounding
+    acc = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(A1, W1, acc, epilogue=L.EPI_STORE_F32, A2=A2, W2=W2)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A1, W1, out, epilogue=L.EPI_MUL_G8, A2=A2, W2=W2, aux=q, p_drop=p)
+    want = acc * dec
+    assert ((out.float() - want).abs() - 2.0 ** -8 * want.abs()).max() < 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,r,p", [(1000, 512, 256, 8, 0.1), (4099, 2048, 512, 8, 0.1), (1300, 640, 192, 5, 0.0)])
+def test_gemm_nt_lora_mulgrad_with_the_8bit_gelu_derivative(ops, M, N, K, r, p):
+    """gsl_gemm_nt_lora_mulgrad(aux_u8): `out` / `tout` bit-identical to the unfused in-kernel-LoRA GEMM with GSL_EPI_MUL_G8, gradients
+    equal to gsl_lora_grad on the same tensors — the fused reductions see the decoded multiplier."""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    c = lambda t: t.cuda().to(dt)
+    A, W = c(rnd(M, K, seed=1)), c(rnd(N, K, seed=2, scale=K ** -0.5))
+    P = torch.zeros(16, K); P[:r] = rnd(r, K, seed=3, scale=K ** -0.5)
+    Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
+    P, Q = c(P), c(Q)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randint(0, 253, (M, N), generator=g, dtype=torch.uint8).cuda()
+    Y2 = c(rnd(M, N, seed=8))
+    U1 = torch.zeros(M, 64); U1[:, :r] = rnd(M, r, seed=9)
+    U1 = c(U1)
+    s = 1.0 / r
+    tout0 = torch.empty(M, 64, device="cuda", dtype=dt); out0 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt_lora(A, W, P, Q, s, tout0, out0, epilogue=L.EPI_MUL_G8, aux=q, p_drop=p)
+    G1r = torch.zeros(N, r, device="cuda"); G2r = torch.zeros(r, N, device="cuda")
+    ops.lora_grad(out0, U1, G1r, r, 1, r, accumulate=False)
+    ops.lora_grad(Y2, tout0, G2r, 1, N, r, accumulate=False)
+    tout = torch.full((M, 64), 3.0, device="cuda", dtype=dt); out = torch.empty(M, N, device="cuda", dtype=dt)
+    G1 = torch.zeros(N, r, device="cuda"); G2 = torch.zeros(r, N, device="cuda")
+    ops.gemm_nt_lora_mulgrad(A, W, P, Q, s, tout, out, q, U1, G1, (r, 1), Y2, G2, (1, N), r, accumulate=False, p_drop=p)
+    assert torch.equal(out, out0) and torch.equal(tout, tout0)
+    assert (G1 - G1r).abs().max().item() < 2e-5 * G1r.abs().max().item() and (G2 - G2r).abs().max().item() < 2e-5 * G2r.abs().max().item()
+    dec = (q.float() - 26.0) * (0.005 / (1 - p))
+    acc = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt_lora(A, W, P, Q, s, None, acc.to(dt), epilogue=L.EPI_STORE)      # (shape check of the plain form)
+    plain = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt_lora(A, W, P, Q, s, None, plain, epilogue=L.EPI_STORE)
+    assert relerr((out0.float()).cpu(), (plain.float() * dec).cpu()) < 1.5e-2

@@ -300,3 +300,20 @@ def test_few_shot_sampler_matches_reference(golden_dir):
     assert set(counts.values()) == {4}
     with pytest.raises(ValueError):
         create_few_shot_dataset(DS(), 10, seed=1)
+
+
+def test_driver_per_task_hyper_parameters_follow_the_reference():
+    """driver_cl.task_hyper == train_own_forget_cl.py:999-1011: cl_beta_list[task], cl_prof_list[task] overriding pro_f_weight when the
+    list is given, and --warmup_alpha as a FLAG that makes alpha 0 before alpha_epoch and big_alpha (not --alpha) from then on; the
+    recipe of scripts/run_cl_forget.sh:217-218 parses. Defaults are the reference's (util/args.py:363-376)."""
+    import driver_cl
+    a = driver_cl.get_args(["--num_tasks", "4", "--alpha", "0.0001", "--cl_beta_list", "0.2", "0.25", "0.25", "0.2", "--pro_f_weight", "0.01",
+                            "--average_weight", "--ema_epoch", "30", "--ema_decay", "0.9", "--cl_prof_list", "0.015", "0.06", "0.025", "0.012"])
+    assert [driver_cl.task_hyper(a, t, 0) for t in range(4)] == [(0.2, 0.015, 1e-4), (0.25, 0.06, 1e-4), (0.25, 0.025, 1e-4), (0.2, 0.012, 1e-4)]
+    with pytest.raises(IndexError):
+        driver_cl.task_hyper(a, 4, 0)
+    b = driver_cl.get_args(["--warmup_alpha", "--alpha_epoch", "3", "--big_alpha", "0.002", "--alpha", "0.5", "--beta", "0.3"])
+    assert [driver_cl.task_hyper(b, 1, e)[2] for e in range(5)] == [0.0, 0.0, 0.0, 0.002, 0.002]
+    assert driver_cl.task_hyper(b, 2, 0)[:2] == (0.3, b.pro_f_weight)          # no lists: --beta / --pro_f_weight for every task
+    d = driver_cl.get_args([])
+    assert (d.ema_decay, d.ema_epoch, d.big_alpha, d.alpha_epoch, d.warmup_alpha, d.cl_beta_list, d.cl_prof_list) == (0.99, 50, 1e-4, 20, False, [], [])
