@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — forgetting-step images/sec of the GS-LoRA step on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config 2|4|5]
 
 N > 1: one process per GPU over RCCL. Either the driver launches the ranks (`python -m torch.distributed.run --nproc-per-node N
 bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when WORLD_SIZE is not set,
@@ -13,6 +13,15 @@ per-GPU batch 512 remain + 512 forget images resident in HBM (weak scaling; `--s
 bf16 speed mode, dropout 0.1 / emb-dropout 0.1 (the reference's training setting), prototype term on, FusedAdamW (lr 1e-2, wd 0.05).
 One "step" = the engine_cl.train_one_epoch loop body (2 forwards, 5 loss terms, backward, packed scalar all-reduce + gradient
 all-reduce when N > 1, AdamW). Prints ONE JSON line on rank 0.
+
+--config selects the BASELINE.json configuration (default 2, the one the metric is quoted on); the same JSON contract for all:
+  2  ViT-P8S8 d6 r=8, per-GPU batch 512 + 512, dropout 0.1, eager launches (GPU-bound)                      [configs[1]]
+  4  ViT-B/16 224 px r=16 (ModifiedViT, 100-way linear head), per-GPU batch 48 + 48 (scripts/run_cl_forget_image.sh:15: -b 48),
+     dropout 0 (torchvision default), the step replayed as HIP-graph segments (what the engines pick below 256 images)   [configs[3]]
+  5  few-shot GS-LoRA++: ViT-P8S8 d6 r=8, per-GPU batch 4 + 4, BND_pro 50, pro_f_weight 0.017 (scripts/run_cl_forget.sh:223-235),
+     HIP-graph replay (launch-bound regime)                                                                  [configs[4]]
+For graph-replayed configs the per-kernel HIP-event timings of `roofline` come from eager steps run AFTER the timed region (a replay
+makes no Python launch to bracket); the kernels are the same.
 """
 import argparse
 import json
@@ -42,6 +51,19 @@ FLOP_IMG_ALG = 15.646e9
 # fractions of the MFMA peak below are quoted on section 8(d)'s ALGORITHMIC count, the executed count is carried beside it.
 FLOP_IMG_EXEC = FLOP_IMG_ALG - (1.43065e9 + 1.02518e9) * (196.0 / 197.0)
 T_TOK = 197
+# ViT-B/16 r=16: fwd 35.707 + bwd 35.385 GFLOP/img algorithmic; executed: the last block's backward (1/12 of 11 generic-layer
+# backwards ~ 3.2 GFLOP/img) and the forward behind its QKV projection (QK^T + PV 0.119, out-proj 0.232, FFN + LoRA 1.878 = 2.229) on 1/197 of the rows
+VITB = dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, num_class=100, lora_rank=16)
+FLOP_IMG_ALG_VITB = 71.09e9
+FLOP_IMG_EXEC_VITB = FLOP_IMG_ALG_VITB - (35.385e9 / 11.0 + 2.229e9) * (196.0 / 197.0)
+CONFIGS = {
+    2: dict(model="vitp8s8", batch=512, dropout=0.1, graph=False, BND_pro=18.0, pro_f=0.01, pro_r=0.01, rank=8,
+            name="BASELINE configs[1]: ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8"),
+    4: dict(model="vitb16", batch=48, dropout=0.0, graph=True, BND_pro=18.0, pro_f=0.05, pro_r=0.05, rank=16,
+            name="BASELINE configs[3]: ViT-B/16 224px ImageNet100-shaped forget step, LoRA r=16, 100-way linear head"),
+    5: dict(model="vitp8s8", batch=4, dropout=0.1, graph=True, BND_pro=50.0, pro_f=0.017, pro_r=0.01, rank=8,
+            name="BASELINE configs[4]: few-shot + prototype-regularised GS-LoRA++ step, ViT-P8S8 depth-6, LoRA r=8"),
+}
 
 
 def build_model(dtype, dropout, device):
@@ -56,6 +78,23 @@ def build_model(dtype, dropout, device):
         for n, p in m.named_parameters():
             if "lora_B" in n:
                 p.normal_(0.0, 0.02)
+    return m.to(device).set_compute_dtype(dtype).train()
+
+
+def build_vitb16(dtype, rank, device):
+    """ModifiedViT over the torchvision-named ViT-B/16 parameter tree, LoRA r on both FFN linears (replace_ffn_with_lora), 100-way head."""
+    import loralib as lora
+    from util.utils import replace_ffn_with_lora
+    from vit_pytorch_face import ModifiedViT
+    from vit_pytorch_face.modified_VIT import vit_b_16
+    torch.manual_seed(1337)
+    m = replace_ffn_with_lora(ModifiedViT(vit_b_16(num_classes=100)), rank=rank)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("lora_B"):
+                p.normal_(0, 0.02)
+        m.heads.head.weight.normal_(0, 0.02)
+    lora.mark_only_lora_as_trainable(m)
     return m.to(device).set_compute_dtype(dtype).train()
 
 
@@ -88,33 +127,42 @@ def host_cpu():
     return max(1, n_phys), model
 
 
-def cpu_baseline(batch=16, steps=3, dropout=0.1):
+def cpu_baseline(batch=16, steps=3, dropout=0.1, sweep=(16, 32, 64)):
     """SURVEY.md 8(d) / BASELINE.md section 3: the build's CPU restatement of the reference step (oracle port; the reference's Python
     cannot travel to the GPU box) timed on the host cores: fp32, B = 16 + 16, full-size model, dropout 0.1 ON (torch's own Bernoulli
-    dropout at the reference's 19 sites, as the reference trains), torch.set_num_threads(physical cores), 1 warm-up + `steps` timed."""
+    dropout at the reference's 19 sites, as the reference trains), 1 warm-up + `steps` timed. `value` is at torch.set_num_threads(physical
+    cores) as 8(d) specifies; a 32-image step does not feed that many threads, so the best of a short thread sweep (1 warm-up + 2 timed
+    steps each) is carried beside it — THAT is the figure to hold a GPU / CPU ratio against."""
     from oracle import gslora_oracle as O
     from oracle import recipe
     cfg = recipe.cfg_full()
     cores, model = host_cpu()
-    torch.set_num_threads(cores)
-    st = recipe.make_state(cfg)
     xr = torch.tensor(recipe.make_images(cfg, batch, seed=1)); yr = torch.tensor(recipe.make_labels(cfg, batch, seed=1, hi=80))
     xf = torch.tensor(recipe.make_images(cfg, batch, seed=2)); yf = torch.tensor(recipe.make_labels(cfg, batch, seed=2, lo=80))
     proto = torch.tensor(recipe.make_prototypes(cfg))
     hy = dict(beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"], BND_pro=HYPER["BND_pro"], pro_f_weight=HYPER["pro_f"],
               pro_r_weight=HYPER["pro_r"], wd=HYPER["wd"], dropout=dropout)
-    opt = None
-    times = []
-    for s in range(steps + 1):
-        t0 = time.perf_counter()
-        _, _, new_st, opt = O.train_step(st, cfg, xr, yr, xf, yf, hy, opt_state=opt, step=s + 1, lr=HYPER["lr"], proto=proto)
-        st = {k: v.numpy() for k, v in new_st.items()}
-        if s:
-            times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
+
+    def run(threads, nsteps):
+        torch.set_num_threads(threads)
+        st, opt, times = recipe.make_state(cfg), None, []
+        for s in range(nsteps + 1):
+            t0 = time.perf_counter()
+            _, _, new_st, opt = O.train_step(st, cfg, xr, yr, xf, yf, hy, opt_state=opt, step=s + 1, lr=HYPER["lr"], proto=proto)
+            st = {k: v.numpy() for k, v in new_st.items()}
+            if s:
+                times.append(time.perf_counter() - t0)
+        return sorted(times)[len(times) // 2]
+    t = run(cores, steps)
+    sw = {}
+    for th in sorted(set(x for x in sweep if x < cores)):
+        sw[str(th)] = round(2 * batch / run(th, 2), 3)
+    best = max([(v, k) for k, v in sw.items()] + [(round(2 * batch / t, 3), str(cores))])
     return {"value": round(2 * batch / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "thread_sweep": sw, "best_of_sweep": {"value": best[0], "threads": int(best[1])},
             "sample": f"oracle train_step (fp32 torch CPU, dropout {dropout}), ViT-P8S8 d6 r8, B={batch}+{batch}, median of {steps} timed steps "
-                      f"after 1 warm-up, {t:.2f} s/step, {cores} threads = physical cores visible, CPU: {model}"}
+                      f"after 1 warm-up, {t:.2f} s/step, {cores} threads = physical cores visible, CPU: {model}; thread sweep = images/s at "
+                      f"fewer threads (1 warm-up + 2 timed steps each)"}
 
 
 def self_launch(args):
@@ -154,32 +202,41 @@ class GsLoraWorkload:
         from gslora_hip.optim import FusedAdamW
         from gslora_hip.step import GraphedStep, gs_lora_step
         self.args, self.B = args, args.batch
-        B = self.B
-        self.model = build_model(args.dtype, args.dropout, dev)
+        B, C = self.B, CONFIGS[args.config]
+        vitb = C["model"] == "vitb16"
+        self.model = build_vitb16(args.dtype, C["rank"], dev) if vitb else build_model(args.dtype, args.dropout, dev)
         self.opt = FusedAdamW([p for p in self.model.parameters() if p.requires_grad], lr=HYPER["lr"], weight_decay=HYPER["wd"], eps=1e-8)
-        crit = torch.nn.CrossEntropyLoss()
+        self.crit = crit = torch.nn.CrossEntropyLoss()
         g = torch.Generator(device="cpu").manual_seed(1337 + rank)
         import random
         order = list(range(100)); random.seed(1337); random.shuffle(order)
-        mk_img = lambda: (torch.randint(0, 256, (B, 3, 112, 112), generator=g, dtype=torch.uint8).float() / 255.0).to(dev)
+        if vitb:      # [B, 3, 224, 224] normalised by the ImageNet mean / std (train_own_forget_cl.py:138-146)
+            mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+            mk_img = lambda: (((torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255.0) - mean) / std).to(dev)
+            dim = VITB["dim"]
+        else:
+            mk_img = lambda: (torch.randint(0, 256, (B, 3, 112, 112), generator=g, dtype=torch.uint8).float() / 255.0).to(dev)
+            dim = FULL["dim"]
         self.x_r, self.x_f = mk_img(), mk_img()
         self.y_r = torch.tensor(order[:80])[torch.randint(0, 80, (B,), generator=g)].to(dev)
         self.y_f = torch.tensor(order[80:])[torch.randint(0, 20, (B,), generator=g)].to(dev)
-        self.proto = torch.randn(100, FULL["dim"], generator=g).to(dev)
+        self.proto = torch.randn(100, dim, generator=g).to(dev)
         self.graph = bool(args.graph)
-        self.stepper = GraphedStep(self.model, self.opt, crit) if args.graph else (lambda *a, **k: gs_lora_step(self.model, self.opt, crit, *a, **k))
+        self.eager = lambda *a, **k: gs_lora_step(self.model, self.opt, crit, *a, **k)
+        self.stepper = GraphedStep(self.model, self.opt, crit) if args.graph else self.eager
+        self.kw = dict(beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"], use_structure=True, group_type="block", use_prototype=True,
+                       proto_table=self.proto, w_f=C["pro_f"], w_r=C["pro_r"], BND_pro=C["BND_pro"])
 
-    def step(self):
-        return self.stepper(self.x_r, self.y_r, self.x_f, self.y_f, beta=HYPER["beta"], alpha=HYPER["alpha"], BND=HYPER["BND"],
-                            use_structure=True, group_type="block", use_prototype=True, proto_table=self.proto, w_f=HYPER["pro_f"],
-                            w_r=HYPER["pro_r"], BND_pro=HYPER["BND_pro"])
+    def step(self, eager=False):
+        return (self.eager if eager else self.stepper)(self.x_r, self.y_r, self.x_f, self.y_f, **self.kw)
 
 
 def kernel_roofline(name, what, recs, flops_of, bytes_of):
     """Live numbers of one GEMM family: HIP-event duration of every launch in the timed region (events recorded on the stream the
     kernel is launched on), algorithmic FLOPs / bytes per launch from the launch's own shape."""
     durs = [a.elapsed_time(b) for a, b, *_ in recs]
-    dense = [(d, r) for d, r in zip(durs, recs) if r[2] >= 4096]           # the cls-row launches of the last block are a different shape
+    mmax = max(r[2] for r in recs)
+    dense = [(d, r) for d, r in zip(durs, recs) if r[2] == mmax]            # the cls-row launches of the last block are a different shape
     if not dense:
         return None
     avg_ms = sum(d for d, _ in dense) / len(dense)
@@ -197,13 +254,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU images per forward (remain and forget each); with --scaling strong: the GLOBAL batch")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration: 2 (default, the metric's), 4 ViT-B/16 r=16 b48, 5 few-shot b4")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU images per forward (remain and forget each; default: the config's); with --scaling strong: the GLOBAL batch")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--dropout", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step as captured HIP graph segments (the engines' default for launch-bound batches)")
+    ap.add_argument("--graph", action="store_true", default=None, help="replay the step as captured HIP graph segments (the engines' default for launch-bound batches; default: the config's)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     args = ap.parse_args()
+    C = CONFIGS[args.config]
+    args.batch = C["batch"] if args.batch is None else args.batch
+    args.dropout = C["dropout"] if args.dropout is None else args.dropout
+    args.graph = C["graph"] if args.graph is None else args.graph
 
     stub = os.environ.get("GSL_BENCH_STUB") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -275,8 +338,15 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = {}
     per_step = [0.0]
+    prof_source = "HIP events around every launch inside the timed region"
     if not stub:
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        if args.graph:      # a replay makes no Python launch to bracket: time the same kernels in eager steps OUTSIDE the timed region
+            ops.PROFILE = {"ffn1": [], "ffn2dx": []}
+            for _ in range(3):
+                wl.step(eager=True)
+            fence()
+            prof_source = "HIP events around every launch of 3 eager steps run after the timed region (the timed steps are HIP-graph replays)"
         prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -285,61 +355,68 @@ def main():
     meters = pack.tolist()
 
     if rank == 0:
-        r = FULL["lora_rank"]
-        D, MLP = FULL["dim"], FULL["mlp_dim"]
+        C = CONFIGS[args.config]
+        vitb = C["model"] == "vitb16"
+        r = C["rank"]
+        flop_alg, flop_exec = (FLOP_IMG_ALG_VITB, FLOP_IMG_EXEC_VITB) if vitb else (FLOP_IMG_ALG, FLOP_IMG_EXEC)
         kernels = []
         if prof.get("ffn1"):
-            # fused FFN1: [x | s x A1^T] [W1 | B1]^T, bias + GELU + GELU' + dropout, TWO bf16 [M, mlp] outputs.
-            # FLOPs = 2 M N (K + r); bytes = A + LoRA segment read, h + GELU' written
+            # fused FFN1: [x | s x A1^T] [W1 | B1]^T, bias + GELU + GELU' + dropout, TWO [M, mlp] outputs (h bf16, GELU' as the 8-bit code).
+            # FLOPs = 2 M N (K + r); bytes = A + LoRA segment read, h (2 B) + GELU' (1 B) written
             kernels.append(kernel_roofline(
-                "gsl_gemm_nt<BIAS_GELU>", "fused FFN1 + LoRA-up K-segment + bias + GELU + GELU' + dropout (forward)", prof["ffn1"],
-                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * N * r, lambda M, N, K, K2: int(M * (K + K2) * 2 + 2 * M * N * 2)))
+                "gsl_gemm_nt<BIAS_GELU_G8>", "fused FFN1 + LoRA-up K-segment + bias + GELU + 8-bit GELU' + dropout (forward)", prof["ffn1"],
+                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * N * r, lambda M, N, K, K2: int(M * (K + K2) * 2 + M * N * 2 + M * N)))
         if prof.get("ffn2dx"):
             # FFN2-dX: dZ = (dY W2 + t A2) * GELU' with t = s dY B2 in the kernel, + the two LoRA-gradient reductions of its tiles.
-            # FLOPs = 2 M N K + LoRA (down 2 M K r, up 2 M N r, two reductions 2 * 2 M N r); bytes = dY + GELU' + h read, dZ written
+            # FLOPs = 2 M N K + LoRA (down 2 M K r, up 2 M N r, two reductions 2 * 2 M N r); bytes = dY + 8-bit GELU' + h read, dZ written
             kernels.append(kernel_roofline(
                 "gsl_gemm_nt_lora_mulgrad", "FFN2-dX x GELU' + in-kernel LoRA + dB1 / dA2 reductions (backward)", prof["ffn2dx"],
-                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * K * r + 6.0 * M * N * r, lambda M, N, K, K2: int(M * K * 2 + 3 * M * N * 2)))
+                lambda M, N, K, K2: 2.0 * M * N * K + 2.0 * M * K * r + 6.0 * M * N * r, lambda M, N, K, K2: int(M * K * 2 + 2 * M * N * 2 + M * N)))
         kernels = [k for k in kernels if k]
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (rocprofv3 cannot wrap itself)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if kernels and pj.get("rows_per_launch") == kernels[0]["rows_per_launch"]:
+            if kernels and args.config == 2 and pj.get("rows_per_launch") == kernels[0]["rows_per_launch"]:
                 traffic, traffic_source = pj["hbm_bytes_per_launch"], pj.get("source")
         except Exception:
             pass
         k0 = kernels[0] if kernels else None
         ips = world * 2 * B * args.steps / elapsed
+        img = "224x224, ImageNet-normalised" if vitb else "112x112"
+        metric = {2: "forgetting-step images/sec, ViT-P8S8 d6 112px r=8", 4: "forgetting-step images/sec, ViT-B/16 224px r=16",
+                  5: "forgetting-step images/sec, ViT-P8S8 d6 112px r=8, few-shot batch"}[args.config]
         out = {
-            "metric": "forgetting-step images/sec, ViT-P8S8 d6 112px r=8", "value": round(ips, 2), "unit": "images/s",
+            "metric": metric, "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("STUB (CPU plumbing test, not a measurement)" if stub else
-                                    f"ViT-P8S8 depth-6 CASIA-100-shaped single-task forget step, LoRA r=8, per-GPU batch {B} remain + "
-                                    f"{B} forget (112x112 synthetic), dropout {args.dropout}, prototype term on, FusedAdamW"),
-                       "global_batch": world * 2 * B, "tokens_per_image": T_TOK, "parallelism": f"dp{world}"},
+                                    f"{C['name']}, per-GPU batch {B} remain + {B} forget ({img} synthetic), dropout {args.dropout}, prototype "
+                                    f"term on (BND_pro {C['BND_pro']}, w_f {C['pro_f']}), FusedAdamW" + (", HIP-graph replay" if args.graph else "")),
+                       "baseline_config": args.config, "global_batch": world * 2 * B, "tokens_per_image": T_TOK, "parallelism": f"dp{world}"},
         }
         if k0:
             # the step's roof is the bf16 MFMA peak; the dominant kernel is priced against it with 8(d)'s FLOPs
             # (2 M N (K + r)). Its HBM view (it writes two [M, mlp] outputs: 228 FLOP/B, below the 312 FLOP/B ridge) is carried beside it.
             out["roofline"] = {"bound": "mfma", "kernel": k0["kernel"] + " — " + k0["what"], "achieved": k0["mfma_tflops"],
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k0["mfma_frac_of_peak"], "traffic": traffic,
-                               "traffic_source": traffic_source, "launches_timed": k0["launches_timed"],
+                               "traffic_source": traffic_source, "timing_source": prof_source, "launches_timed": k0["launches_timed"],
                                "rows_per_launch": k0["rows_per_launch"], "avg_ms": k0["avg_ms"],
                                "algorithmic_flops": k0["algorithmic_flops"], "algorithmic_bytes": k0["algorithmic_bytes"],
                                "hbm_view": {"achieved": k0["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k0["hbm_frac_of_peak"]},
                                "kernels": kernels}
         out.update({
-            "step_flops_frac_of_peak": round((FLOP_IMG_ALG * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-            "step_flops_frac_of_peak_executed": round((FLOP_IMG_EXEC * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-            "flops_per_image": {"algorithmic_8d": FLOP_IMG_ALG, "executed": round(FLOP_IMG_EXEC)},
+            "step_flops_frac_of_peak": round((flop_alg * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "step_flops_frac_of_peak_executed": round((flop_exec * world * 2 * B * args.steps / elapsed) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "flops_per_image": {"algorithmic_8d": flop_alg, "executed": round(flop_exec)},
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
             "hip_graph": bool(args.graph),
             "ms_per_step_events": {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
                                    "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
         })
-        if world == 1 and not args.no_cpu_baseline and not stub:
+        if world == 1 and not args.no_cpu_baseline and not stub and args.config == 2:
             out["cpu_baseline"] = cpu_baseline()
+        elif not stub and args.config != 2:
+            out["cpu_baseline_note"] = "timed on the configuration the metric is quoted on only (python bench.py --config 2)"
     # the JSON line must be the LAST line of the job's stdout: RCCL writes its version banner through C stdio, which a piped stdout
     # only flushes at exit (i.e. after Python's own print) — push every rank's C buffer out first, then let rank 0 print
     sys.stdout.flush()

@@ -123,12 +123,15 @@ def evaluate(model, testloader_forget, testloader_remain, device, batch, epoch, 
         if Hmean > highest_H_mean:
             highest_H_mean = Hmean
             net = m.module if cfg["MULTI_GPU"] else m
-            torch.save(net.state_dict(), os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
-                cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time())))
-            if len(os.listdir(cfg["WORK_PATH"])) >= 3:
-                ckpts = sorted((f for f in os.listdir(cfg["WORK_PATH"]) if f.endswith(".pth")),
-                               key=lambda f: os.path.getmtime(os.path.join(cfg["WORK_PATH"], f)))
-                os.remove(os.path.join(cfg["WORK_PATH"], ckpts[0]))
+            from engine_cl import save_barrier, save_rank
+            if save_rank():      # one process per GPU: one writer / pruner of the shared work directory (see engine_cl.evaluate)
+                torch.save(net.state_dict(), os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
+                    cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time())))
+                if len(os.listdir(cfg["WORK_PATH"])) >= 3:
+                    ckpts = sorted((f for f in os.listdir(cfg["WORK_PATH"]) if f.endswith(".pth")),
+                                   key=lambda f: os.path.getmtime(os.path.join(cfg["WORK_PATH"], f)))
+                    os.remove(os.path.join(cfg["WORK_PATH"], ckpts[0]))
+            save_barrier()
     return highest_H_mean
 
 

@@ -105,6 +105,18 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
             meters["losses_prototype_remain"])
 
 
+def save_rank():
+    """True on the rank that owns the shared work directory (rank 0 of an initialised process group, or the only process)."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def save_barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def evaluate(model, testloader_forget, testloader_remain, device, batch: int, epoch: int, forget_acc_before: float,
              highest_H_mean: float, cfg: dict, optimizer, task_i: str, testloader_open=None):
     """Eval-mode accuracies, H-mean, best-checkpoint save + prune to two (reference :247-315)."""
@@ -121,13 +133,17 @@ def evaluate(model, testloader_forget, testloader_remain, device, batch: int, ep
     if Hmean > highest_H_mean:
         highest_H_mean = Hmean
         net = model.module if cfg["MULTI_GPU"] else model
-        path = os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
-            cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time()))
-        torch.save(net.state_dict(), path)
-        if len(os.listdir(cfg["WORK_PATH"])) >= 4:   # keep the two newest checkpoints (+ config.txt)
-            ckpts = sorted((f for f in os.listdir(cfg["WORK_PATH"]) if f.endswith(".pth")),
-                           key=lambda f: os.path.getmtime(os.path.join(cfg["WORK_PATH"], f)))
-            os.remove(os.path.join(cfg["WORK_PATH"], ckpts[0]))
+        # one process per GPU: every rank evaluates the (replicated) test loaders and reaches the same decision; ONE rank writes and
+        # prunes the shared work directory, the others wait (concurrent writers corrupt the file, the second pruner finds it gone)
+        if save_rank():
+            path = os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
+                cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time()))
+            torch.save(net.state_dict(), path)
+            if len(os.listdir(cfg["WORK_PATH"])) >= 4:   # keep the two newest checkpoints (+ config.txt)
+                ckpts = sorted((f for f in os.listdir(cfg["WORK_PATH"]) if f.endswith(".pth")),
+                               key=lambda f: os.path.getmtime(os.path.join(cfg["WORK_PATH"], f)))
+                os.remove(os.path.join(cfg["WORK_PATH"], ckpts[0]))
+        save_barrier()
     return highest_H_mean
 
 

@@ -72,6 +72,9 @@ class FusedAdamW(torch.optim.Optimizer):
         for p, st in self.state.items():      # scattered parameters (one launch per tensor)
             if st:
                 state[idx[id(p)]] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
+        for pid, st in (getattr(self, "_loaded", None) or {}).items():      # loaded, not yet consumed by a step(): still this optimizer's state
+            if pid in idx and idx[pid] not in state:
+                state[idx[pid]] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
         sd["state"] = state
         return sd
 
@@ -80,8 +83,14 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         params = [p for g in self.param_groups for p in g["params"]]
         self._loaded = {id(params[int(i)]): st for i, st in state.items()}
-        self._flat.clear()
         self.state.clear()
+        # Flat groups that exist keep their buffers — captured HIP graphs hold the addresses of m / v / step_dev / lr_dev — and take the
+        # loaded moments and step count IN PLACE; graph_sync() then brings the device counters in line before the next replay.
+        for ent in self._flat.values():
+            if ent.get("ok"):
+                self._apply_loaded(ent)
+        for gi in [gi for gi, ent in self._flat.items() if not ent.get("ok")]:
+            del self._flat[gi]
 
     def _apply_loaded(self, ent):
         """Fill a freshly built flat group from a loaded checkpoint (called once, when the group is first seen after load_state_dict)."""

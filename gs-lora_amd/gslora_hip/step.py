@@ -64,42 +64,64 @@ class HipBackend:
         return b.grad, b.offsets[b.per_layer]
 
 
+def _bucket_messages(net, backend):
+    """The gradient exchange of one data-parallel step as an ordered list of slices of the flat LoRA-gradient bucket. EVERY mode of the
+    step (eager with the overlapped first message, eager without overlap, HIP-graph segments) issues exactly these all-reduces in this
+    order, so ranks that momentarily run different modes (one replays a captured graph, another runs its first eager step of a new
+    configuration, a third fell back after a failed capture) still post matching collectives."""
+    sl = backend.early_grad_slice(net) if hasattr(backend, "early_grad_slice") else None
+    if sl is None:
+        return [backend.grad_bucket(net)]
+    flat, split = sl
+    return [flat[split:], flat[:split]]      # blocks 1 .. L-1 (final once the backward reaches block 0), then block 0
+
+
 class _OverlappedBucketReduce:
     """Gradient all-reduce in two messages: blocks 1..L-1 on a side stream as soon as block 1's gradients are written (it runs
     under block 0's FFN backward), block 0 afterwards. The structure-loss gradient is parameter-only and pre-scaled by 1/world; its
-    autograd node is created after the network's, so it has been added to the bucket before the network backward starts."""
+    autograd node is created after the network's, so it has been added to the bucket before the network backward starts.
+    `overlap` is False when the step runs two network backwards (fuse_batches=False: the hook would fire during the first one while
+    the second still accumulates into the slice): the same two messages are then posted after the backward."""
 
-    def __init__(self, net, backend):
-        self.net, self.backend, self.work, self.split, self.side = net, backend, None, None, None
-        sl = backend.early_grad_slice(net) if hasattr(backend, "early_grad_slice") else None
+    def __init__(self, net, backend, overlap=True):
+        self.net, self.backend, self.work, self.side, self.runner = net, backend, None, None, None
+        # the two-slice form is known up front (the bucket exists); a backend without slices hands over its bucket after the backward
+        self.msgs = _bucket_messages(net, backend) if hasattr(backend, "early_grad_slice") else None
         runner = net.runner() if hasattr(net, "runner") else None
-        if sl is not None and runner is not None:
-            self.flat, self.split, self.runner = sl[0], sl[1], runner
+        if overlap and self.msgs is not None and len(self.msgs) == 2 and runner is not None:
+            self.runner = runner
             runner.grad_hook = self._hook
 
     def _hook(self, layer):
         if layer != 1 or self.work is not None:
             return
-        if self.flat.is_cuda:
+        first = self.msgs[0]
+        if first.is_cuda:
             if self.side is None:
-                self.side = _side_stream(self.flat.device)
+                self.side = _side_stream(first.device)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                self.work = dist.all_reduce(self.flat[self.split:], async_op=True)
+                self.work = dist.all_reduce(first, async_op=True)
         else:
-            self.work = dist.all_reduce(self.flat[self.split:], async_op=True)
+            self.work = dist.all_reduce(first, async_op=True)
+
+    def cancel(self):
+        """The backward raised: take the hook off the runner (an in-flight first message is waited for, nothing else is posted)."""
+        if self.runner is not None:
+            self.runner.grad_hook = None
+        if self.work is not None:
+            self.work.wait()
 
     def finish(self):
-        if self.split is None:
-            dist.all_reduce(self.backend.grad_bucket(self.net))      # one flat message: 0.94 MiB for ViT-P8S8 r=8
+        if self.runner is not None:
+            self.runner.grad_hook = None
+        if self.work is None:        # no overlap (single block, two backwards, or a hook that never fired): the same messages, in order
+            for m in (self.msgs if self.msgs is not None else _bucket_messages(self.net, self.backend)):
+                dist.all_reduce(m)
             return
-        self.runner.grad_hook = None
-        if self.work is None:        # the hook never fired (single block, or a backward that stopped early)
-            dist.all_reduce(self.flat)
-            return
-        dist.all_reduce(self.flat[:self.split])
+        dist.all_reduce(self.msgs[1])
         self.work.wait()
-        if self.flat.is_cuda:
+        if self.msgs[0].is_cuda:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
@@ -131,8 +153,8 @@ class _EagerComm:
         dist.all_reduce(pack)
 
     @staticmethod
-    def bucket_reducer(net, backend):
-        return _OverlappedBucketReduce(net, backend)
+    def bucket_reducer(net, backend, overlap=True):
+        return _OverlappedBucketReduce(net, backend, overlap)
 
 
 def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
@@ -200,8 +222,12 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
     structure = backend.structure_loss(net, group_type, grad_scale=1.0 / world) if use_structure else None
     total, meters = backend.combine_pack(pack, ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, beta, BND, alpha, w_f, w_r, BND_pro)
     optimizer.zero_grad()
-    reducer = _comm.bucket_reducer(net, backend)
-    total.backward()
+    reducer = _comm.bucket_reducer(net, backend, overlap=fuse_batches)      # two forwards = two network backwards: no early message
+    try:
+        total.backward()
+    except BaseException:
+        reducer.cancel()
+        raise
     reducer.finish()
     optimizer.step()
     return meters
@@ -210,8 +236,9 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
 class _SegmentedCapture:
     """Captures a data-parallel step as HIP-graph SEGMENTS around its two collectives: [forward, loss sums, pack] | all-reduce(pack) |
     [scalar tail, backward] | all-reduce(gradient bucket) | [AdamW, meters]. The collectives stay eager (any backend; nothing of RCCL is
-    captured), the ~190-370 kernel launches between them are replayed. During the capture pass the eager collectives run on
-    not-yet-computed buffers, which is harmless: only replays produce values. All segments share one memory pool."""
+    captured), the ~190-370 kernel launches between them are replayed. The capture pass itself sends nothing; replays post the eager
+    step's messages in the eager step's order (_bucket_messages), so ranks in different modes stay matched. All segments share one
+    memory pool."""
 
     def __init__(self):
         self.pool = torch.cuda.graph_pool_handle()
@@ -228,28 +255,34 @@ class _SegmentedCapture:
         if ctx is not None:
             ctx.__exit__(*exc)
 
-    def _cut(self, tensor):
+    def _cut(self, tensors):
+        """Close the current segment; `tensors` are all-reduced, in order, between it and the next one at every replay. Nothing is sent
+        during the capture pass itself (no kernel runs while capturing, the buffers hold no values yet): a rank that captures posts
+        exactly one step's worth of collectives — those of the replay that follows — like a rank that runs the same step eagerly."""
         self.end()
-        dist.all_reduce(tensor)
-        self.colls.append(tensor)
+        self.colls.append(list(tensors))
         self.begin()
 
     def all_reduce_scalars(self, pack):
-        self._cut(pack)
+        self._cut([pack])
 
-    def bucket_reducer(self, net, backend):
+    def bucket_reducer(self, net, backend, overlap=True):
         cap = self
 
         class _R:
             def finish(self_inner):
-                cap._cut(backend.grad_bucket(net))
+                cap._cut(_bucket_messages(net, backend))      # the eager step's messages, in its order
+
+            def cancel(self_inner):
+                pass
         return _R()
 
     def replay(self):
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.colls):
-                dist.all_reduce(self.colls[i])
+                for t in self.colls[i]:
+                    dist.all_reduce(t)
 
 
 class GraphedStep:
@@ -414,6 +447,13 @@ class MeterQueue:
         if not self.pending:
             return
         rows = torch.stack([p for p, _, _ in self.pending]).tolist()     # the single host sync
+        for k, row in enumerate(rows):
+            # the reference stops with a KeyError on a label without a prototype (engine_cl.py:587-589) and never trains on a NaN loss; here
+            # such a batch poisons the device-resident total, so the first read of the meters is where the run must stop
+            if not all(v == v and abs(v) != float("inf") for v in row):
+                self.pending = []
+                raise FloatingPointError(f"gs-lora_amd: non-finite training meters {dict(zip(self.ORDER, row))} at deferred step {k} of "
+                                         f"{len(rows)} (a label without a prototype, or diverged weights); the LoRA weights are no longer usable")
         for row, (_, n_r, n_f) in zip(rows, self.pending):
             for name, w, v in zip(self.ORDER, self.WEIGHT, row):
                 m = meters.get(name)

@@ -164,3 +164,46 @@ def test_two_rank_step_equals_single_process(hyper):
     # both ranks end with identical replicas
     for k in params1:
         assert np.array_equal(ret[0][1][k], ret[1][1][k])
+
+
+def _eval_worker(rank, world, port, work, ret):
+    sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-lora_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import engine
+    import engine_cl
+    accs = iter([40.0, 70.0] * 8)
+    engine_cl.eval_data = lambda *a, **k: next(accs)          # every rank sees the same (replicated) test loaders
+    engine._eval_data_cl = lambda *a, **k: next(accs)
+    model = nn.Linear(4, 4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    cfg = {"MULTI_GPU": False, "WORK_PATH": work, "BACKBONE_NAME": "VIT"}
+    h = engine_cl.evaluate(model, None, None, "cpu", batch=99, epoch=0, forget_acc_before=100.0, highest_H_mean=0.0, cfg=cfg,
+                           optimizer=opt, task_i="0")
+    h2 = engine.evaluate(model, None, None, "cpu", batch=199, epoch=0, forget_acc_before=100.0, highest_H_mean=0.0, cfg=cfg, optimizer=opt)
+    ret[rank] = (h, h2)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_evaluate_into_one_work_directory(tmp_path):
+    """one process per GPU — every rank evaluates and reaches the same best-H-mean decision, ONE rank saves and prunes the
+    shared work directory, the others wait at a barrier (no concurrent writers, no FileNotFoundError in the second pruner)."""
+    import time
+    work = str(tmp_path)
+    open(os.path.join(work, "config.txt"), "w").write("cfg\n")
+    for i, name in enumerate(["Backbone_VIT_Epoch_1_Batch_10_Time_old_checkpoint.pth", "Backbone_VIT_Epoch_1_Batch_20_Time_old_checkpoint.pth"]):
+        p = os.path.join(work, name)
+        torch.save({"dummy": torch.zeros(1)}, p)
+        os.utime(p, (time.time() - 1000 + 10 * i, time.time() - 1000 + 10 * i))
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, work, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ret[0] == ret[1] and ret[0][0] > 0
+    files = sorted(f for f in os.listdir(work) if f.endswith(".pth"))
+    new = [f for f in files if "_old_" not in f]
+    assert len(new) == 2 and any("_Batch_100_" in f for f in new) and any("_Batch_200_" in f for f in new)      # one file per evaluate(), not per rank
+    assert len(files) == 2, files          # both engines pruned down to two checkpoints, once

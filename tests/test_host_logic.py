@@ -317,3 +317,119 @@ def test_driver_per_task_hyper_parameters_follow_the_reference():
     assert driver_cl.task_hyper(b, 2, 0)[:2] == (0.3, b.pro_f_weight)          # no lists: --beta / --pro_f_weight for every task
     d = driver_cl.get_args([])
     assert (d.ema_decay, d.ema_epoch, d.big_alpha, d.alpha_epoch, d.warmup_alpha, d.cl_beta_list, d.cl_prof_list) == (0.99, 50, 1e-4, 20, False, [], [])
+
+
+# ---------------------------------------------------------------------------------------------------------------- ADVICE (round 2)
+def test_data_parallel_gradient_messages_do_not_depend_on_the_mode(monkeypatch):
+    """Eager with the overlapped first message, eager without overlap (two backwards) and the HIP-graph segments must post the SAME
+    all-reduces in the SAME order (pack | blocks 1..L-1 | block 0): ranks that momentarily run different modes — one replays a captured
+    graph, one runs a first eager step, one fell back after a failed capture — would otherwise mismatch and hang or corrupt gradients.
+    The capture pass itself must post nothing."""
+    from gslora_hip import step as st
+    sent = []
+    monkeypatch.setattr(st.dist, "all_reduce", lambda t, async_op=False: (sent.append(t.numel()), type("W", (), {"wait": lambda self: None})())[1])
+    flat = torch.zeros(100)
+
+    class Runner:
+        grad_hook = None
+
+    class Net:
+        r = Runner()
+
+        def runner(self):
+            return self.r
+
+    class Backend:
+        @staticmethod
+        def early_grad_slice(net):
+            return flat, 30
+
+        @staticmethod
+        def grad_bucket(net):
+            return flat
+    net = Net()
+    # eager, overlapped: the hook of layer 1 fires during the backward
+    red = st._OverlappedBucketReduce(net, Backend)
+    assert net.r.grad_hook is not None
+    net.r.grad_hook(3); net.r.grad_hook(1); net.r.grad_hook(1); net.r.grad_hook(0)
+    red.finish()
+    assert sent == [70, 30] and net.r.grad_hook is None
+    # eager, two backwards (fuse_batches=False): no hook is installed, same messages after the backward
+    sent.clear()
+    red = st._OverlappedBucketReduce(net, Backend, overlap=False)
+    assert net.r.grad_hook is None
+    red.finish()
+    assert sent == [70, 30]
+    # a backward that raises: the hook comes off the runner, nothing further is posted
+    sent.clear()
+    red = st._OverlappedBucketReduce(net, Backend)
+    red.cancel()
+    assert net.r.grad_hook is None and sent == []
+    # graph segments: nothing during the capture pass, the eager sequence at every replay
+    cap = st._SegmentedCapture.__new__(st._SegmentedCapture)
+    cap.graphs, cap.colls, cap._ctx = [], [], None
+    monkeypatch.setattr(st._SegmentedCapture, "begin", lambda self: self.graphs.append(type("G", (), {"replay": lambda s: None})()))
+    monkeypatch.setattr(st._SegmentedCapture, "end", lambda self, exc=(None, None, None): None)
+    cap.begin()
+    pack = torch.zeros(8)
+    cap.all_reduce_scalars(pack)
+    cap.bucket_reducer(net, Backend).finish()
+    cap.end()
+    assert sent == []
+    cap.replay()
+    assert sent == [8, 70, 30]
+    # single-block models: one message in every mode
+    sent.clear()
+    one = type("B1", (), {"grad_bucket": staticmethod(lambda n: flat)})
+    st._OverlappedBucketReduce(net, one).finish()
+    assert sent == [100]
+
+
+def test_meter_queue_stops_on_non_finite_meters():
+    from gslora_hip.step import MeterQueue
+    from util.utils import AverageMeter
+    q = MeterQueue()
+    q.push(torch.tensor([1.0, 2.0, 3.0, 0.1, 50.0, 60.0, 0.2, 0.3]), 4, 4)
+    meters = {k: AverageMeter() for k in MeterQueue.ORDER}
+    q.flush(meters)
+    assert meters["losses_total"].avg == 3.0
+    q.push(torch.tensor([1.0, 2.0, float("nan"), 0.1, 50.0, 60.0, 0.2, 0.3]), 4, 4)
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        q.flush(meters)
+    assert q.pending == []
+
+
+def test_fused_adamw_load_state_dict_keeps_the_buffers_captured_graphs_point_at(monkeypatch):
+    """load_state_dict() with live flat buffers copies the loaded moments / step IN PLACE (captured HIP graphs hold the addresses of
+    m / v / step_dev / lr_dev), and a state_dict() taken before the next step() still carries the loaded state."""
+    from gslora_hip import ops
+    from gslora_hip.optim import FusedAdamW
+
+    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step):      # torch restatement of gsl_adamw_flat for the CPU
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.mul_(1 - lr * wd).addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+    monkeypatch.setattr(ops, "adamw_flat", adamw_flat)
+    flat, gflat = torch.randn(24), torch.randn(24)
+    ps = [torch.nn.Parameter(flat[:16].view(4, 4)), torch.nn.Parameter(flat[16:].view(2, 4))]
+    ps[0].grad, ps[1].grad = gflat[:16].view(4, 4), gflat[16:].view(2, 4)
+    opt = FusedAdamW(ps, lr=1e-2)
+    opt.step(); opt.step()
+    ent = opt._flat[0]
+    assert ent["ok"] and ent["step"] == 2
+    sd = opt.state_dict()
+    ptr_m, ptr_v = ent["m"].data_ptr(), ent["v"].data_ptr()
+    other = {"state": {0: {"step": torch.tensor(7.0), "exp_avg": torch.full((4, 4), 0.5), "exp_avg_sq": torch.full((4, 4), 0.25)},
+                       1: {"step": torch.tensor(7.0), "exp_avg": torch.full((2, 4), -0.5), "exp_avg_sq": torch.full((2, 4), 0.125)}},
+             "param_groups": sd["param_groups"]}
+    opt.load_state_dict(other)
+    ent2 = opt._flat[0]
+    assert ent2 is ent and ent["m"].data_ptr() == ptr_m and ent["v"].data_ptr() == ptr_v          # same buffers
+    assert ent["step"] == 7 and torch.equal(ent["m"][:16], torch.full((16,), 0.5)) and torch.equal(ent["v"][16:], torch.full((8,), 0.125))
+    opt.step()
+    assert opt._flat[0]["step"] == 8
+    # a fresh optimizer: the loaded state is visible to state_dict() before any step()
+    opt2 = FusedAdamW(ps, lr=1e-2)
+    opt2.load_state_dict(other)
+    st = opt2.state_dict()["state"]
+    assert float(st[0]["step"]) == 7.0 and torch.equal(st[1]["exp_avg"], torch.full((2, 4), -0.5))
