@@ -442,17 +442,29 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   f32x4_t g1[4], g2[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) g1[t] = g2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  // The global operands of a 32-row round (g', h: 4 x 16 B per lane each, U1: 2 x 16 B) are requested as soon as the registers of the
-  // previous round's operands are dead — after its multiply / LDS hand-over, in front of its transpose reads and MFMAs — so that the
-  // round trip (which grows from ~2.5 k to ~5 k cycles when all CUs stream) is covered by that MFMA section and the next round's
-  // staging writes. No second register set: the kernel sits at 252 VGPRs.
-  uint4 (&ax)[4] = go.ax;
-  uint4 (&hx)[4] = go.hx;
-  uint4 &u1a = go.u1a, &u1b = go.u1b;
-  auto request = [&](int ic) { gf_request<G8>(e, go, mw, nw, ic, lane); };
+  // The global operands of a 32-row round (g': 4 x 8 or 16 B per lane, h: 4 x 16 B, U1: 2 x 16 B) live in TWO register sets that
+  // alternate between the rounds: round 0's were requested by the caller (under the rank-r tail), round 1's are requested here, and
+  // round q + 2's as soon as round q has consumed its set (after its multiply / LDS hand-over). A round's operands are therefore in
+  // flight for more than a whole round (~1.5) instead of half of one, which covers the round trip that grows from ~2.5 k to ~5 k
+  // cycles when all CUs stream. The second set costs no registers at the kernel level: the K loop's operand fragments (72 VGPRs) are
+  // dead here and every round frees 32 accumulator registers. GSL_MULGRAD_PREFETCH=1 builds the single-set form (A/B probes).
+#ifndef GSL_MULGRAD_PREFETCH
+#define GSL_MULGRAD_PREFETCH 2
+#endif
+  constexpr bool TWOSETS = (GSL_MULGRAD_PREFETCH >= 2);
+  GfOperands gob;
+  if constexpr (TWOSETS) {
+    asm volatile("" ::: "memory");
+    if (NI / 2 > 1) gf_request<G8>(e, gob, mw, nw, 1, lane);
+    asm volatile("" ::: "memory");
+  }
   const float sq8 = e.drop.scale / G8_K;
 #pragma unroll
   for (int ic = 0; ic < NI / 2; ++ic) {
+    GfOperands& op = (TWOSETS && (ic & 1)) ? gob : go;      // (the loop is fully unrolled: a compile-time choice)
+    uint4 (&ax)[4] = op.ax;
+    uint4 (&hx)[4] = op.hx;
+    uint4 &u1a = op.u1a, &u1b = op.u1b;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -496,7 +508,9 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       *reinterpret_cast<uint4*>(ub + lane * 16 + 8) = in ? u1b : make_uint4(0u, 0u, 0u, 0u);
     }
     asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
-    if (ic + 1 < NI / 2) request(ic + 1);
+    // this round's set is consumed: refill it for the round that uses it next
+    if constexpr (TWOSETS) { if (ic + 2 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 2, lane); }
+    else { if (ic + 1 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 1, lane); }
     asm volatile("" ::: "memory");
     GfFrag b1, b2;
     b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
@@ -787,6 +801,95 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
     for (int j = 0; j < 4; ++j) {
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       epilogue4<EPI, bf16_t>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel, 64x64 tile, 4-stage LDS-DMA ring: few rows
+// The launch-bound regime (few-shot batches: M = 1 576 rows; the cls-row tail of the last block: M = batch) has too few 128x128 tiles
+// to occupy the chip — M = 1 576, N = 512 are 52 workgroups, and their K = 2048 loop then runs tile after tile with two barriers
+// each: 32 us where the vendor library needs 11 (tools/probes/small_m_gemm.py). Here: 64x64 tiles (4x the workgroups), four waves
+// (2 x 2, 32x32 each), BK = 64, a ring of four 16 KB stages with the LDS-DMA running three K tiles ahead, counted vmcnt and ONE raw
+// barrier per K tile. Same swizzle / fragment layout / epilogues as the kernels above (fragment-path stores: the outputs are small).
+constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, NSTS = 4;
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                              const bf16_t* __restrict__ A2, int lda2,
+                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NSTS * STS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + BNS - 1) / BNS;
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m0 = (tile / nbn) * BMS, n0 = (tile % nbn) * BNS;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+
+  auto issue = [&](int kt) {      // 4 DMA instructions per wave and K tile: rows wave*16 .. +15 of the A part and of the W part
+    bf16_t* st = smem + (kt % NSTS) * STS;
+    const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = wave * 2 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BMS * BK + rb * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+  int aoff[2][2], boff[2][2];      // fragment read offsets inside a stage (bf16 elements), per k-step
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 32 + i * 16 + fr, rb = wn * 32 + i * 16 + fr;
+      aoff[i][ks] = ra * BK + (((ks * 4 + fc) ^ (ra & 7)) << 3);
+      boff[i][ks] = BMS * BK + rb * BK + (((ks * 4 + fc) ^ (rb & 7)) << 3);
+    }
+
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(NSTS - 2, nk - 1 - kt);      // K tiles that may still be in flight behind tile kt
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
+    if (kt + 3 < nk) issue(kt + 3);    // overwrites the stage of tile kt - 1
+    const bf16_t* st = smem + (kt % NSTS) * STS;
+    bf16x8_t af[2][2], wf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i][ks]);
+        wf[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + boff[i][ks]);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 32 + i * 16 + fr, n0 + wn * 32 + j * 16 + fc * 4, v);
     }
 }
 
@@ -1303,6 +1406,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     // kernel is ahead.   1 = 128x128 single stage, 3 = 256x128 three-stage ring, 8 = 256x256 8-phase ping-pong.
     const long tiles256 = (long)((e.M + 255) / 256) * ((e.N + 255) / 256);
     int variant = (e.M < 1024 || tiles256 < 128) ? 1 : (e.N >= 512 ? 8 : 3);
+    // fewer than ~200 tiles of 128x128 leave CUs idle and serialise the K loop: 64x64 tiles with a 4-stage ring (12). Measured at
+    // M = 1 576 (tools/probes/small_m_gemm.py, profiles/r03_c_small_m.md).
+    if (variant == 1 && (long)nblk < 200) variant = 12;
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
 #ifdef GSL_DEV
@@ -1377,6 +1483,8 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                          (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
+    } else if (variant == 12) {
+      GSL_LAUNCH((gemm_bf16_small_kernel<EPI>), ((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS), 256);
     } else {
       GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
     }

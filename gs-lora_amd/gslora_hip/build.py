@@ -31,14 +31,17 @@ def needs_build(dev=False):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, dev=False):
-    out = OUT_DEV if dev else OUT
-    if not force and not needs_build(dev):
+def build(force=False, verbose=True, dev=False, defines=(), out=None, tag=None):
+    """defines / out / tag: an A/B build of the product sources with extra -D flags into another file (tools/probes/, never loaded by
+    default: `GSLORA_HIP_LIB=<out> python bench.py`)."""
+    variant = out is not None
+    out = out or (OUT_DEV if dev else OUT)
+    if not variant and not force and not needs_build(dev):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build", "dev" if dev else "prod")
+    objdir = os.path.join(HERE, "build", tag or ("dev" if dev else "prod"))
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + (["-DGSL_DEV"] if dev else [])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + (["-DGSL_DEV"] if dev else []) + list(defines)
     procs = []
     objs = []
     for src in SOURCES:      # one hipcc per translation unit, in parallel (gemm.hip dominates)
@@ -59,4 +62,12 @@ def build(force=False, verbose=True, dev=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, dev="--dev" in sys.argv)
+    # python -m gslora_hip.build [--force] [--dev] [--variant NAME -DX=1 ...]  (variant -> <repo>/build_variants/libgslora_hip_NAME.so)
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        vdir = os.path.join(os.path.dirname(os.path.dirname(HERE)), "build_variants")
+        os.makedirs(vdir, exist_ok=True)
+        print(build(defines=[a for a in sys.argv if a.startswith("-D")], out=os.path.join(vdir, f"libgslora_hip_{name}.so"), tag="variant_" + name,
+                    dev="--dev" in sys.argv))
+    else:
+        build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -35,6 +35,9 @@ TAIL_CLS = os.environ.get("GSLORA_TAIL_CLS", "1") != "0"
 # 8-bit fixed-point code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN.
 # GSLORA_GP8=0 keeps it in bf16 (the parity mode always keeps it in f32).
 GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
+# rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
+# on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
+INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
 # layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
 # read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
 QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
@@ -278,8 +281,10 @@ class ViTRunner:
         return tab
 
     def lora_in_kernel(self, dtype, rows):
-        """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation)."""
-        return dtype == torch.bfloat16 and rows >= 1024 and self._rank <= 16
+        """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation). The in-kernel form
+        exists on the 256x256 8-phase kernel only: with few rows (launch-bound batches, the cls-row tail of the last block) its
+        N = 512 GEMMs would run on a handful of workgroups, and the two-launch form on the small-tile kernels wins (INK_MIN_ROWS)."""
+        return dtype == torch.bfloat16 and rows >= INK_MIN_ROWS and self._rank <= 16
 
     def ensure_bucket(self, spec=None):
         spec = spec or self.model.hip_spec()
