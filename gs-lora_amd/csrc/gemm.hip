@@ -1674,6 +1674,11 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   int rc = check_launch("gsl_gemm_nt_lora_mulgrad");
   if (rc) return rc;
   const int NR4 = (int)(NR / 4);
+  if (nslab == 1) {      // one slab: the second level sums the M tiles itself, in the same order (one launch less in the launch-bound regime)
+    hipLaunchKernelGGL(mulgrad_reduce2_kernel, dim3(((int)NR + 255) / 256, 2), dim3(256), 0, st, ws, (long)((size_t)ntile * NR), G1, g1sn,
+                       g1sj, G2, g2sn, g2sj, N, R, r, ntile, accumulate);
+    return check_launch("gsl_gemm_nt_lora_mulgrad(reduce)");
+  }
   hipLaunchKernelGGL(mulgrad_reduce1_kernel, dim3((NR4 + 255) / 256, nslab, 2), dim3(256), 0, st, (const float4*)ws, (float4*)part2, NR4,
                      ntile, (long)((size_t)ntile * NR / 4), (long)((size_t)nslab * NR / 4));
   hipLaunchKernelGGL(mulgrad_reduce2_kernel, dim3(((int)NR + 255) / 256, 2), dim3(256), 0, st, part2, (long)((size_t)nslab * NR), G1, g1sn,

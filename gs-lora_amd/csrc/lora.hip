@@ -349,8 +349,9 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
         return check_launch("gsl_lora_grad(reduce)");
       }
       float* part2m = ws + (size_t)nsplit * N * R;
-      const int nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
-      hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((totm + 255) / 256, nslabm), dim3(256), 0, st, ws, part2m, totm, nsplit);
+      int nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
+      if (nslabm == 1) { part2m = ws; nslabm = nsplit; }      // one slab: the second level sums the splits itself, in the same order (one launch less)
+      else hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((totm + 255) / 256, nslabm), dim3(256), 0, st, ws, part2m, totm, nsplit);
       if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
       else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
       return check_launch("gsl_lora_grad(reduce)");
@@ -368,8 +369,10 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
 #undef LAUNCH
   int rc = check_launch("gsl_lora_grad(partial)");
   if (rc) return rc;
-  const int tot = N * R, nslab = (nsplit + LG_FAN - 1) / LG_FAN;
-  hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((tot + 255) / 256, nslab), dim3(256), 0, st, ws, part2, tot, nsplit);
+  const int tot = N * R;
+  int nslab = (nsplit + LG_FAN - 1) / LG_FAN;
+  if (nslab == 1) { part2 = ws; nslab = nsplit; }
+  else hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((tot + 255) / 256, nslab), dim3(256), 0, st, ws, part2, tot, nsplit);
   if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
   else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
   return check_launch("gsl_lora_grad(reduce)");
