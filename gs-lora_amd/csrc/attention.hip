@@ -913,20 +913,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
 // Row-cooperative form: 8 lanes share one key row (8 head dims each: 16-byte bf16 / 2 x 16-byte f32 accesses), so a wave instruction
 // touches 8 complete 128-byte K / V / dK / dV rows instead of 64 different ones (the thread-per-key form moved 1.03 GB at 2.4 TB/s).
 // The two dot products are finished with three xor-shuffles inside the 8-lane group; dq0 is reduced in a fixed order.
+// Operand addressing of the two cls kernels. qkv_layout 0: token-major qkv [B*T, 3*H*64]; 1: head-major [B][H][3][T][64]; 2 (round 3):
+// the last block's projection computes Q for the cls rows only — kv token-major [B*T, 2*H*64] (k | v) + q_cls [B, H*64].
+struct ClsAddr {
+  long ldi, ko, vo;      // row stride of the K / V rows of one (image, head), offsets of the K and V panels from `base`
+};
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+__device__ __forceinline__ const T* cls_base(const T* qkv, int b, int h, int Tn, int H, int layout, ClsAddr& a) {
+  const long ld3 = 3L * H * HD, ld2 = 2L * H * HD;
+  if (layout == 1) { a.ldi = HD; a.ko = (long)Tn * HD; a.vo = 2L * Tn * HD; return qkv + (size_t)(b * H + h) * 3 * Tn * HD; }
+  if (layout == 2) { a.ldi = ld2; a.ko = 0; a.vo = (long)H * HD; return qkv + (size_t)b * Tn * ld2 + h * HD; }
+  a.ldi = ld3; a.ko = (long)H * HD; a.vo = 2L * H * HD;
+  return qkv + (size_t)b * Tn * ld3 + h * HD;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ q_cls, const T* __restrict__ o,
                                                            const T* __restrict__ d_o_cls, const float* __restrict__ lse,
-                                                           T* __restrict__ dqkv, int Tn, int H, float scale, int hm, int cls_compact) {
+                                                           T* __restrict__ dqkv, T* __restrict__ dq_cls, int Tn, int H, float scale, int hm,
+                                                           int cls_compact) {
   __shared__ float q0[HD], g0[HD], red[32][HD];
   __shared__ float sD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)Tn * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
-  const T* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * Tn * HD : (size_t)b * Tn * ld + h * HD);
-  T* db = dqkv + (size_t)b * Tn * ld + h * HD;
+  const long ldo = (long)H * HD;
+  ClsAddr ad;
+  const T* qb = cls_base(qkv, b, h, Tn, H, hm, ad);
+  // outputs: layouts 0 / 1 -> dqkv token-major [B*T, 3*H*64] (dQ rows of the other tokens zero-filled); layout 2 -> dkv [B*T, 2*H*64] + dq_cls
+  const long ldd = (hm == 2 ? 2L : 3L) * H * HD, dko = (hm == 2) ? 0 : (long)H * HD, dvo = dko + (long)H * HD;
+  T* db = dqkv + (size_t)b * Tn * ldd + h * HD;
   const int tid = threadIdx.x;
   if (tid < HD) {
-    q0[tid] = Elem<T>::ld(qb + tid);
+    q0[tid] = Elem<T>::ld(hm == 2 ? q_cls + (size_t)b * ldo + h * HD + tid : qb + tid);
     g0[tid] = Elem<T>::ld(d_o_cls + (size_t)b * ldo + h * HD + tid);
     float v = g0[tid] * Elem<T>::ld(o + (size_t)b * (cls_compact ? 1 : Tn) * ldo + h * HD + tid);
     v = wave_sum(v);
@@ -942,8 +959,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
     const int j = j0 + grp;
     const bool live = j < Tn;
     const int jc = live ? j : Tn - 1;
-    const T* kr = qb + (size_t)jc * ldi + ko + sub * 8;
-    const T* vr = qb + (size_t)jc * ldi + 2 * ko + sub * 8;
+    const T* kr = qb + (size_t)jc * ad.ldi + ad.ko + sub * 8;
+    const T* vr = qb + (size_t)jc * ad.ldi + ad.vo + sub * 8;
     float kv[8], vv[8];
     Elem<T>::ld4(kr, kv); Elem<T>::ld4(kr + 4, kv + 4);
     Elem<T>::ld4(vr, vv); Elem<T>::ld4(vr + 4, vv + 4);
@@ -958,13 +975,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
       float a[8], bb[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { a[i] = ds * qs[i]; bb[i] = p * gs[i]; dq[i] = fmaf(ds, kv[i], dq[i]); }
-      T* dk = db + (size_t)j * ld + H * HD + sub * 8;
-      T* dv = db + (size_t)j * ld + 2 * H * HD + sub * 8;
+      T* dk = db + (size_t)j * ldd + dko + sub * 8;
+      T* dv = db + (size_t)j * ldd + dvo + sub * 8;
       Elem<T>::st4(dk, a); Elem<T>::st4(dk + 4, a + 4);
       Elem<T>::st4(dv, bb); Elem<T>::st4(dv + 4, bb + 4);
-      if (j > 0) {   // dQ of the non-cls tokens is exactly zero
+      if (hm != 2 && j > 0) {   // dQ of the non-cls tokens is exactly zero
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        Elem<T>::st4(db + (size_t)j * ld + sub * 8, z); Elem<T>::st4(db + (size_t)j * ld + sub * 8 + 4, z);
+        Elem<T>::st4(db + (size_t)j * ldd + sub * 8, z); Elem<T>::st4(db + (size_t)j * ldd + sub * 8 + 4, z);
       }
     }
   }
@@ -976,7 +993,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) t += red[g][tid];
-    Elem<T>::st(db + tid, t);
+    Elem<T>::st(hm == 2 ? dq_cls + (size_t)b * ldo + h * HD + tid : db + tid, t);
   }
 }
 
@@ -984,16 +1001,16 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
 // the attention is token-wise), so its attention is one query row per (image, head) against the full K / V panels — a streaming
 // softmax-weighted sum, HBM-bound on the K / V rows (8 lanes per row as above). o_cls [B, H*64], lse_cls [B, H].
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__ qkv, T* __restrict__ o_cls, float* __restrict__ lse_cls,
-                                                           int Tn, int H, float scale, int hm) {
+__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ q_cls, T* __restrict__ o_cls,
+                                                           float* __restrict__ lse_cls, int Tn, int H, float scale, int hm) {
   __shared__ float q0[HD], sc[256], red[32][HD];
   __shared__ float sm[16];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)Tn * HD : (long)H * HD;
-  const T* qb = qkv + (hm ? (size_t)(b * H + h) * 3 * Tn * HD : (size_t)b * Tn * ld + h * HD);
+  const long ldo = (long)H * HD;
+  ClsAddr ad;
+  const T* qb = cls_base(qkv, b, h, Tn, H, hm, ad);
   const int tid = threadIdx.x;
-  if (tid < HD) q0[tid] = Elem<T>::ld(qb + tid);
+  if (tid < HD) q0[tid] = Elem<T>::ld(hm == 2 ? q_cls + (size_t)b * ldo + h * HD + tid : qb + tid);
   __syncthreads();
   const int grp = tid >> 3, sub = tid & 7;
   float qs[8];
@@ -1002,7 +1019,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__
   for (int j0 = 0; j0 < Tn; j0 += 32) {
     const int j = j0 + grp;
     const int jc = j < Tn ? j : Tn - 1;
-    const T* kr = qb + (size_t)jc * ldi + ko + sub * 8;
+    const T* kr = qb + (size_t)jc * ad.ldi + ad.ko + sub * 8;
     float kv[8];
     Elem<T>::ld4(kr, kv); Elem<T>::ld4(kr + 4, kv + 4);
     float sdot = 0.f;
@@ -1025,7 +1042,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__
   for (int j0 = 0; j0 < Tn; j0 += 32) {
     const int j = j0 + grp;
     if (j < Tn) {
-      const T* vr = qb + (size_t)j * ldi + 2 * ko + sub * 8;
+      const T* vr = qb + (size_t)j * ad.ldi + ad.vo + sub * 8;
       float vv[8];
       Elem<T>::ld4(vr, vv); Elem<T>::ld4(vr + 4, vv + 4);
       const float p = sc[j];
@@ -1045,30 +1062,31 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__
   if (tid == 0) lse_cls[(size_t)b * H + h] = m + logf(e);
 }
 
-extern "C" int gsl_attention_fwd_cls(const void* qkv, void* o_cls, float* lse_cls, int B, int T, int H, float scale, int dtype,
-                                     int qkv_layout, gsl_stream_t s) {
+extern "C" int gsl_attention_fwd_cls(const void* qkv, const void* q_cls, void* o_cls, float* lse_cls, int B, int T, int H, float scale,
+                                     int dtype, int qkv_layout, gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o_cls && lse_cls && B > 0 && T > 1 && T <= 256 && H > 0, "null/size (T <= 256)");
-  GSL_CHECK_ARG(qkv_layout == 0 || qkv_layout == 1, "qkv_layout: 0 token-major, 1 head-major");
+  GSL_CHECK_ARG(qkv_layout >= 0 && qkv_layout <= 2 && (qkv_layout != 2 || q_cls), "qkv_layout: 0 token-major, 1 head-major, 2 kv + q_cls");
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16)
-    hipLaunchKernelGGL(attn_fwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (bf16_t*)o_cls, lse_cls, T, H, scale, qkv_layout);
+    hipLaunchKernelGGL(attn_fwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)q_cls, (bf16_t*)o_cls, lse_cls, T, H, scale, qkv_layout);
   else if (dtype == GSL_F32)
-    hipLaunchKernelGGL(attn_fwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (float*)o_cls, lse_cls, T, H, scale, qkv_layout);
+    hipLaunchKernelGGL(attn_fwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)q_cls, (float*)o_cls, lse_cls, T, H, scale, qkv_layout);
   else return fail(GSL_ERR_ARG, "gsl_attention_fwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_fwd_cls");
 }
 
-extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv, int B,
-                                     int T, int H, float scale, int dtype, int qkv_layout, int cls_compact, gsl_stream_t s) {
+extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* q_cls, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
+                                     void* dq_cls, int B, int T, int H, float scale, int dtype, int qkv_layout, int cls_compact,
+                                     gsl_stream_t s) {
   GSL_CHECK_ARG(qkv && o && d_o_cls && lse && dqkv && B > 0 && T > 1 && H > 0, "null/size");
-  GSL_CHECK_ARG(qkv_layout == 0 || qkv_layout == 1, "qkv_layout: 0 token-major, 1 head-major");
+  GSL_CHECK_ARG(qkv_layout >= 0 && qkv_layout <= 2 && (qkv_layout != 2 || (q_cls && dq_cls)), "qkv_layout: 0 token-major, 1 head-major, 2 kv + q_cls / dq_cls");
   const dim3 grid(B * H), blk(256);
   if (dtype == GSL_BF16)
-    hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)o,
-                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, T, H, scale, qkv_layout, cls_compact);
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)q_cls, (const bf16_t*)o,
+                       (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, (bf16_t*)dq_cls, T, H, scale, qkv_layout, cls_compact);
   else if (dtype == GSL_F32)
-    hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)o,
-                       (const float*)d_o_cls, lse, (float*)dqkv, T, H, scale, qkv_layout, cls_compact);
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)q_cls, (const float*)o,
+                       (const float*)d_o_cls, lse, (float*)dqkv, (float*)dq_cls, T, H, scale, qkv_layout, cls_compact);
   else return fail(GSL_ERR_ARG, "gsl_attention_bwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd_cls");
 }

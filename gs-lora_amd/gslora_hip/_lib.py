@@ -40,8 +40,8 @@ SIGNATURES = {
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
-    "gsl_attention_fwd_cls": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
-    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "gsl_attention_fwd_cls": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
+    "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp],
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],

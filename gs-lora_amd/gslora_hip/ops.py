@@ -15,13 +15,14 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _need(*ts):
+def _need(*ts, rows_ok=False):
+    """rows_ok: 2-D row slices / column blocks (unit inner stride) are accepted — the entry point takes the leading dimension."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError("gslora_hip: tensors must live on a ROCm GPU (the HIP path has no CPU fallback)")
-        if not t.is_contiguous():
+        if not (t.is_contiguous() or (rows_ok and t.dim() == 2 and t.stride(1) == 1)):
             raise RuntimeError("gslora_hip: tensors must be contiguous")
 
 
@@ -53,7 +54,10 @@ PROFILE = None
 
 def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, bias=None, res=None, aux=None, out2=None,
             pos=None, cls=None, T=0, p_drop=0.0, seed=0, site=0, tag=None):
-    _need(A1, W1, A2, W2, out, bias, res, aux, out2, pos, cls)
+    _need(A2, W2, bias, aux, out2, pos, cls)
+    _need(A1, W1, out, res, rows_ok=True)      # lda1 / ldw1 / ldo travel with the call (res shares ldo with out)
+    if res is not None and res.shape[0] > 1 and res.stride(0) != out.stride(0):
+        raise RuntimeError("gemm_nt: res and out must share one row stride")
     M, K1 = A1.shape
     N = W1.shape[0]
     K2 = 0 if A2 is None else A2.shape[1]
@@ -177,24 +181,28 @@ def attention_bwd(qkv, o, d_o, lse, B, T, H, scale, layout=0):
     return dqkv
 
 
-def attention_fwd_cls(qkv, B, T, H, scale, layout=0):
-    """Attention output of the cls query alone (the last block under pool='cls'): o_cls [B, H*64], lse_cls [B, H]."""
-    _need(qkv)
+def attention_fwd_cls(qkv, B, T, H, scale, layout=0, q_cls=None):
+    """Attention output of the cls query alone (the last block under pool='cls'): o_cls [B, H*64], lse_cls [B, H].
+    layout 2: `qkv` is kv [B*T, 2*H*64] (k | v, token-major) and q_cls [B, H*64] holds the queries."""
+    _need(qkv, q_cls)
     o = torch.empty(B, H * 64, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, device=qkv.device, dtype=torch.float32)
-    L.check(L.load().gsl_attention_fwd_cls(_p(qkv), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), int(layout), _stream()),
-            "gsl_attention_fwd_cls")
+    L.check(L.load().gsl_attention_fwd_cls(_p(qkv), _p(q_cls), _p(o), _p(lse), B, T, H, float(scale), code(qkv.dtype), int(layout),
+                                           _stream()), "gsl_attention_fwd_cls")
     return o, lse
 
 
-def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale, layout=0):
-    """o / lse: either the full forward tensors ([B*T, H*64] / [B, H, T]) or the compact ones of attention_fwd_cls ([B, H*64] / [B, H])."""
-    _need(qkv, o, d_o_cls, lse)
-    dqkv = torch.empty(B * T, 3 * H * 64, device=qkv.device, dtype=qkv.dtype)
+def attention_bwd_cls(qkv, o, d_o_cls, lse, B, T, H, scale, layout=0, q_cls=None):
+    """o / lse: either the full forward tensors ([B*T, H*64] / [B, H, T]) or the compact ones of attention_fwd_cls ([B, H*64] / [B, H]).
+    layout 0 / 1 -> dqkv [B*T, 3*H*64]; layout 2 (kv + q_cls) -> (dkv [B*T, 2*H*64], dq_cls [B, H*64])."""
+    _need(qkv, o, d_o_cls, lse, q_cls)
+    nw = 2 if layout == 2 else 3
+    dqkv = torch.empty(B * T, nw * H * 64, device=qkv.device, dtype=qkv.dtype)
+    dq = torch.empty(B, H * 64, device=qkv.device, dtype=qkv.dtype) if layout == 2 else None
     compact = o.shape[0] == B and lse.dim() == 2
-    L.check(L.load().gsl_attention_bwd_cls(_p(qkv), _p(o), _p(d_o_cls), _p(lse), _p(dqkv), B, T, H, float(scale),
+    L.check(L.load().gsl_attention_bwd_cls(_p(qkv), _p(q_cls), _p(o), _p(d_o_cls), _p(lse), _p(dqkv), _p(dq), B, T, H, float(scale),
                                            code(qkv.dtype), int(layout), 1 if compact else 0, _stream()), "gsl_attention_bwd_cls")
-    return dqkv
+    return (dqkv, dq) if layout == 2 else dqkv
 
 
 _ws_cache = {}

@@ -31,6 +31,10 @@ FWD_STREAM_BF16 = os.environ.get("GSLORA_FWD_STREAM", "bf16").lower() != "f32"
 # tail run on B rows instead of B*T (exact: the skipped rows influence no output of the model). GSLORA_TAIL_CLS=0 keeps the dense forward
 # (the backward then still runs on the cls rows).
 TAIL_CLS = os.environ.get("GSLORA_TAIL_CLS", "1") != "0"
+# ... and of that block's QKV projection only K and V are needed for every token: Q is projected for the cls rows alone (kv [M, 2*inner]
+# + q_cls [B, inner]; the backward's dX GEMM contracts over 2*inner and the cls rows get their dQ term from a [B, inner] GEMM).
+# GSLORA_QSPLIT=0 keeps the full projection.
+QSPLIT = os.environ.get("GSLORA_QSPLIT", "1") != "0"
 # bf16 speed mode stores g' = GELU'(.) * dropmask / (1 - p) — written by the fused FFN1 epilogue, read once by the FFN2-dX epilogue — as an
 # 8-bit fixed-point code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN.
 # GSLORA_GP8=0 keeps it in bf16 (the parity mode always keeps it in f32).
@@ -280,6 +284,12 @@ class ViTRunner:
             tab = self._pack_tables[dtype] = (t, mx, len(ents))
         return tab
 
+    def _zeros(self, n, dev):
+        z = self._wcache.get(("zeros", n, dev))
+        if z is None:
+            z = self._wcache[("zeros", n, dev)] = torch.zeros(n, device=dev, dtype=torch.float32)
+        return z
+
     def lora_in_kernel(self, dtype, rows):
         """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation). The in-kernel form
         exists on the 256x256 8-phase kernel only: with few rows (launch-bound batches, the cls-row tail of the last block) its
@@ -355,24 +365,35 @@ class ViTRunner:
         for i, blk in enumerate(sp.blocks):
             n1, n2 = blk.ln1, blk.ln2
             xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
-            qkv = torch.empty(M, 3 * H * 64, device=img.device, dtype=dt)
+            tail = TAIL_CLS and i == len(sp.blocks) - 1 and sp.pool == "cls"
+            qsplit = tail and QSPLIT and not attn_site
+            inner = H * 64
             hm = 1 if (QKV_HEAD_MAJOR and dt == torch.bfloat16) else 0
             epi_qkv = L.EPI_STORE_QKV_HM if hm else L.EPI_STORE
-            uq = None
-            if attn_site and not blk.qkv_lora.merged:      # q / k / v adapters: one block-diagonal LoRA K segment
+            uq = q_cls = None
+            if qsplit:      # K and V for every token, Q for the cls rows only (rows inner .. 3*inner of the fused weight are K | V)
+                wq = self.w(f"qkv{i}", blk.qkv_w, dt)
+                qb_ = None if blk.qkv_b is None else blk.qkv_b.detach()
+                qkv = torch.empty(M, 2 * inner, device=img.device, dtype=dt)
+                ops.gemm_nt(xn, wq[inner:], qkv, bias=None if qb_ is None else qb_[inner:])
+                q_cls = torch.empty(B, inner, device=img.device, dtype=dt)
+                ops.gemm_nt(xn.view(B, T, D)[:, 0].contiguous(), wq[:inner], q_cls, bias=None if qb_ is None else qb_[:inner].contiguous())
+                hm = 2
+            elif attn_site and not blk.qkv_lora.merged:      # q / k / v adapters: one block-diagonal LoRA K segment
+                qkv = torch.empty(M, 3 * inner, device=img.device, dtype=dt)
                 qo = self.qkv_lora_ops(i, blk.qkv_lora, dt)
                 uq = torch.empty(M, PADK, device=img.device, dtype=dt)
                 ops.gemm_nt(xn, qo["A_rows"], uq, alpha=s_lora)
                 ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, A2=uq, W2=qo["Bblk"], epilogue=epi_qkv, T=T,
                             bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             else:
+                qkv = torch.empty(M, 3 * inner, device=img.device, dtype=dt)
                 ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, epilogue=epi_qkv, T=T,
                             bias=None if blk.qkv_b is None else blk.qkv_b.detach())
             xn_keep = xn if (attn_site and save) else None
             del xn
-            tail = TAIL_CLS and i == len(sp.blocks) - 1 and sp.pool == "cls"
             if tail:      # only the cls query of the last block is ever consumed: B rows from here on
-                o, lse = ops.attention_fwd_cls(qkv, B, T, H, sp.attn_scale, layout=hm)
+                o, lse = ops.attention_fwd_cls(qkv, B, T, H, sp.attn_scale, layout=hm, q_cls=q_cls)
                 xres, Mr = x.view(B, T, D)[:, 0].contiguous(), B
             else:
                 o, lse = ops.attention_fwd(qkv, B, T, H, sp.attn_scale, layout=hm)
@@ -416,7 +437,7 @@ class ViTRunner:
                             bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, qkv_hm=hm, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
-                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq, tail=tail))
+                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq, tail=tail, q_cls=q_cls))
             x = x2
         hn = sp.final_ln
         Th = x.shape[0] // B      # rows per image of the stream that reaches the head: T, or 1 after a cls-row-only last block
@@ -539,13 +560,24 @@ class ViTRunner:
             # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
             ops.gemm_nt(dx1b, self.wT(f"wo{i}", blk.out.weight, dt), d_o)
-            if sparse:
-                dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
-            else:
-                dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
             dxn1 = torch.empty(B * T, D, device=dev, dtype=dt)
-            ops.gemm_nt(dqkv, self.wT(f"qkv{i}", blk.qkv_w, dt), dxn1)
-            del d_o, dqkv, dx1b
+            if sparse and st["q_cls"] is not None:      # Q was projected for the cls rows only: dX contracts over K | V, the cls rows get dQ W_q on top
+                inner = H * 64
+                dkv, dq_cls = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=2, q_cls=st["q_cls"])
+                wt = self.wT(f"qkv{i}", blk.qkv_w, dt)                     # [dim, 3*inner]
+                ops.gemm_nt(dkv, wt[:, inner:], dxn1)
+                rows = dxn1.view(B, T * D)[:, :D]                          # the cls rows of dxn1, T*D apart: updated in place
+                ops.gemm_nt(dq_cls, wt[:, :inner], rows, epilogue=L.EPI_BIAS_RES_BF16 if dt == torch.bfloat16 else L.EPI_BIAS_RES_F32,
+                            bias=self._zeros(D, dev), res=rows)
+                del dkv, dq_cls
+            else:
+                if sparse:
+                    dqkv = ops.attention_bwd_cls(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
+                else:
+                    dqkv = ops.attention_bwd(st["qkv"], st["o"], d_o, st["lse"], B, T, H, sp.attn_scale, layout=st["qkv_hm"])
+                ops.gemm_nt(dqkv, self.wT(f"qkv{i}", blk.qkv_w, dt), dxn1)
+                del dqkv
+            del d_o, dx1b
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
                                         p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag,

@@ -138,14 +138,17 @@ GSL_API int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, c
                       float* delta_ws, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s);
 /* The last transformer block when the head pools the cls token (vit_face.py:540): everything after its attention is token-wise, so
  * only the cls query's attention output is ever consumed. Forward of that one query row per (image, head) against the full K / V
- * panels: o_cls[dtype] [B, H*64], lse_cls f32 [B, H]. */
-GSL_API int gsl_attention_fwd_cls(const void* qkv, void* o_cls, float* lse_cls, int B, int T, int H, float scale, int dtype,
-                                  int qkv_layout, gsl_stream_t s);
+ * panels: o_cls[dtype] [B, H*64], lse_cls f32 [B, H].
+ * qkv_layout 0 / 1 as above (q = token 0 of the qkv tensor, q_cls ignored); 2: the block's projection computed Q for the cls rows only —
+ * `qkv` is kv[dtype] token-major [B*T, 2*H*64] (k | v) and q_cls[dtype] [B, H*64] holds the queries. */
+GSL_API int gsl_attention_fwd_cls(const void* qkv, const void* q_cls, void* o_cls, float* lse_cls, int B, int T, int H, float scale,
+                                  int dtype, int qkv_layout, gsl_stream_t s);
 /* Its backward: only the cls query carries an output gradient. d_o_cls[dtype] [B, H*64] is dO of the cls rows;
  * cls_compact != 0: o / lse are the [B, H*64] / [B, H] outputs of gsl_attention_fwd_cls, 0: the full tensors of gsl_attention_fwd
- * ([B*T, H*64] / [B, H, T]; the cls rows are read). Writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens = 0). */
-GSL_API int gsl_attention_bwd_cls(const void* qkv, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
-                                  int B, int T, int H, float scale, int dtype, int qkv_layout, int cls_compact, gsl_stream_t s);
+ * ([B*T, H*64] / [B, H, T]; the cls rows are read). qkv_layout 0 / 1: writes the full dqkv [B*T,3*H*64] (dQ rows of the other tokens
+ * = 0; dq_cls unused); 2: writes dkv [B*T, 2*H*64] into `dqkv` and the query gradients into dq_cls [B, H*64]. */
+GSL_API int gsl_attention_bwd_cls(const void* qkv, const void* q_cls, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
+                                  void* dq_cls, int B, int T, int H, float scale, int dtype, int qkv_layout, int cls_compact, gsl_stream_t s);
 
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
  * Y[dtype] [M,N] with row stride ldy >= N elements (a column block of a wider tensor is allowed), U[dtype] [M,ldu] (first r columns

@@ -827,6 +827,14 @@ def test_attention_fwd_cls_equals_the_cls_rows_of_the_dense_forward(ops, dt, B, 
     dense_l = torch.zeros(B, H, T, device="cuda"); dense_l[:, :, 0] = lse_c
     b = ops.attention_bwd_cls(qin, dense_o, d_o, dense_l, B, T, H, scale, layout=hm)
     assert torch.equal(a, b)
+    # layout 2: K | V token-major + the cls queries on their own (the last block projects Q for the cls rows only): same arithmetic
+    inner = H * 64
+    kv = qkv[:, inner:].contiguous()
+    q_cls = qkv.view(B, T, 3 * inner)[:, 0, :inner].contiguous()
+    o2, lse2 = ops.attention_fwd_cls(kv, B, T, H, scale, layout=2, q_cls=q_cls)
+    assert torch.equal(o2, o_c) and torch.equal(lse2, lse_c)
+    dkv, dq = ops.attention_bwd_cls(kv, o2, d_o, lse2, B, T, H, scale, layout=2, q_cls=q_cls)
+    assert torch.equal(dkv, a[:, inner:]) and torch.equal(dq, a.view(B, T, 3 * inner)[:, 0, :inner])
 
 
 # ---------------------------------------------------------------------------------------------------------------- 8-bit GELU'
