@@ -1459,6 +1459,15 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         return check_launch("gsl_gemm_nt(t256)");
       }
     }
+    if constexpr (EPI == GSL_EPI_STORE) {      // probe: W fragments straight from L2 into registers (13 full, 14 A-DMA stream alone, 15 A-DMA + W loads alone)
+      if (variant >= 13 && variant <= 15) {
+        const int nb3 = ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3);
+        if (variant == 13) GSL_LAUNCH((gemm_bf16_ring3w_kernel<EPI, 0>), nb3, 512);
+        else if (variant == 14) GSL_LAUNCH((gemm_bf16_ring3w_kernel<EPI, 1>), nb3, 512);
+        else GSL_LAUNCH((gemm_bf16_ring3w_kernel<EPI, 2>), nb3, 512);
+        return check_launch("gsl_gemm_nt(ring3w probe)");
+      }
+    }
     if constexpr (EPI == GSL_EPI_STORE) {
       const char* ab = getenv("GSL_GEMM_ABL");
       const int abl = ab ? atoi(ab) : 0;
