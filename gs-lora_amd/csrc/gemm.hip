@@ -1406,9 +1406,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     // kernel is ahead.   1 = 128x128 single stage, 3 = 256x128 three-stage ring, 8 = 256x256 8-phase ping-pong.
     const long tiles256 = (long)((e.M + 255) / 256) * ((e.N + 255) / 256);
     int variant = (e.M < 1024 || tiles256 < 128) ? 1 : (e.N >= 512 ? 8 : 3);
-    // fewer than ~200 tiles of 128x128 leave CUs idle and serialise the K loop: 64x64 tiles with a 4-stage ring (12). Measured at
+    // up to ~256 tiles of 128x128 (one per CU) leave CUs idle and serialise the K loop: 64x64 tiles with a 4-stage ring (12). Measured at
     // M = 1 576 (tools/probes/small_m_gemm.py, profiles/r03_c_small_m.md).
-    if (variant == 1 && (long)nblk < 200) variant = 12;
+    if (variant == 1 && (long)nblk <= 256) variant = 12;
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
 #ifdef GSL_DEV

@@ -61,7 +61,7 @@ constexpr int HEAD_MAXD = 1024;
 
 // X: element type of the residual stream x (f32, or bf16 in speed mode)
 template <typename X>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, int T, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void head_fwd_kernel(const X* __restrict__ x, int T, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, const float* __restrict__ Wn,
                                                        const int64_t* __restrict__ label, float* __restrict__ emb,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, 
                                                        const float* __restrict__ hbias, int linear, int pool_mean) {
   __shared__ float e[HEAD_MAXD];
   __shared__ float sm[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, nwv = blockDim.x >> 6;      // 256 threads, or 1024 when few images share the chip
   const X* xr = x + (size_t)b * T * D;
   float s = 0.f;
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < D; d += nt) {
     float pv = Elem<X>::ld(xr + d);                 // pool = 'cls': token 0 (vit_face.py:540)
     if (pool_mean) {                                // pool = 'mean': x.mean(dim=1) over all T tokens, summed in token order
       for (int t = 1; t < T; ++t) pv += Elem<X>::ld(xr + (size_t)t * D + d);
@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, 
   }
   const float mu = block_sum(s, sm) / D;
   float q = 0.f;
-  for (int d = tid; d < D; d += 256) { const float c = e[d] - mu; q += c * c; }
+  for (int d = tid; d < D; d += nt) { const float c = e[d] - mu; q += c * c; }
   const float rs = rsqrtf(block_sum(q, sm) / D + eps);
   float nn = 0.f;
-  for (int d = tid; d < D; d += 256) {
+  for (int d = tid; d < D; d += nt) {
     const float v = (e[d] - mu) * rs * gamma[d] + beta[d];
     e[d] = v;
     emb[(size_t)b * D + d] = v;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, 
   // a wave owns classes wave, wave + 4, ...; five of them per round so that the loads of five W rows are in flight together (one
   // class per round made the kernel a chain of 25 dependent global-load latencies: 60 us for 100 classes at any batch size)
   constexpr int CB = 5;
-  for (int c0 = wave; c0 < C; c0 += 4 * CB) {
+  for (int c0 = wave; c0 < C; c0 += nwv * CB) {
     float dot[CB];
 #pragma unroll
     for (int k = 0; k < CB; ++k) dot[k] = 0.f;
@@ -107,13 +107,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const X* __restrict__ x, 
       const float ev = e[d];
 #pragma unroll
       for (int k = 0; k < CB; ++k) {
-        const int c = min(c0 + 4 * k, C - 1);
+        const int c = min(c0 + nwv * k, C - 1);
         dot[k] += ev * Wn[(size_t)c * D + d];
       }
     }
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
-      const int c = c0 + 4 * k;
+      const int c = c0 + nwv * k;
       float dk = wave_sum(dot[k]);
       if (lane == 0 && c < C) {
         if (linear) logits[(size_t)b * C + c] = dk + (hbias ? hbias[c] : 0.f);     // plain nn.Linear head (modified_VIT.py:34-36)
@@ -130,11 +130,12 @@ extern "C" int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamm
   GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
   GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
+  const int nthr = B <= 128 ? 1024 : 256;      // one workgroup per image: with few images give each one 16 waves (100 class rows in two rounds)
   if (x_dtype == GSL_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(s), (const bf16_t*)x, T, gamma, beta, eps, Wn, label, emb,
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(nthr), 0, as_stream(s), (const bf16_t*)x, T, gamma, beta, eps, Wn, label, emb,
                        mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
   else
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(256), 0, as_stream(s), (const float*)x, T, gamma, beta, eps, Wn, label, emb,
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(nthr), 0, as_stream(s), (const float*)x, T, gamma, beta, eps, Wn, label, emb,
                        mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
   return check_launch("gsl_head_fwd");
 }

@@ -235,6 +235,7 @@ static inline void lgm_plan(int M, int N, int& bx, int& nsplit, int& rps) {
   if (target < 1) target = 1;
   int steps = (M + LGM_K - 1) / LGM_K;          // 32-row slabs
   nsplit = steps < target ? steps : target;
+  if (steps <= 64 && nsplit > LG_FAN) nsplit = LG_FAN;      // few rows (launch-bound regime): one slab of partials, no first reduction level
   rps = ((steps + nsplit - 1) / nsplit) * LGM_K;
   nsplit = (M + rps - 1) / rps;
 }
