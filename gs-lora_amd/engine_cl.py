@@ -153,13 +153,23 @@ def eval_data(model, dataloader, device, mode: str, batch: int = 0):
     from gslora_hip import ops
     model.eval()
     hits, total = None, 0
-    with torch.no_grad():
-        for images, labels in dataloader:
-            images, labels = images.to(device), labels.to(device).long()
-            outputs, _ = model(images, labels)
-            h = ops.ce_fwd(outputs.float().contiguous(), labels.contiguous())[1]
-            hits = h if hits is None else hits + h
-            total += labels.size(0)
+    # GSLORA_EVAL_DTYPE=fp32: the accuracies — the numbers a forgetting run reports — are taken with the exact-f32 parity kernels whatever
+    # mode the model trains in (bf16 operands flip near-tie predictions: DESIGN.md section 7). Default: the model's own mode.
+    net = _unwrap(model)
+    eval_dt, train_dt = os.environ.get("GSLORA_EVAL_DTYPE"), getattr(net, "compute_dtype", None)
+    if eval_dt and hasattr(net, "set_compute_dtype"):
+        net.set_compute_dtype(eval_dt)
+    try:
+        with torch.no_grad():
+            for images, labels in dataloader:
+                images, labels = images.to(device), labels.to(device).long()
+                outputs, _ = model(images, labels)
+                h = ops.ce_fwd(outputs.float().contiguous(), labels.contiguous())[1]
+                hits = h if hits is None else hits + h
+                total += labels.size(0)
+    finally:
+        if eval_dt and hasattr(net, "set_compute_dtype"):
+            net.set_compute_dtype(train_dt)
     accuracy = 100 * (hits.item() if hits is not None else 0.0) / max(total, 1)
     print("Test {} Accuracy:{:2f}%".format(mode, accuracy))
     _log({"Test {} Accuracy".format(mode): accuracy})
