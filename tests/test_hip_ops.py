@@ -58,8 +58,10 @@ def test_gemm_store_asymmetric(ops, dt):
 @pytest.mark.parametrize("dt", DTS)
 # the last two shapes (170 images x 197 tokens: 131 M-tiles of 256 with a ragged last tile) run the 8-phase 256x256 kernel and its
 # staged full-row epilogues in bf16 mode
+# tile choice by shape (bf16): the first four run the 64x64 ring kernel (<= 256 tiles of 128x128), (2600, 2048) the 128x128 kernel,
+# (9000, 64) the 256x128 ring, the 33 490-row shapes the 256x256 8-phase kernel
 @pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64),
-                                       (33490, 512, 192, 0), (33490, 2048, 512, 64)])
+                                       (2600, 2048, 512, 64), (9000, 64, 512, 0), (33490, 512, 192, 0), (33490, 2048, 512, 64)])
 def test_gemm_epilogues(ops, dt, M, N, K1, K2):
     from gslora_hip import _lib as L
     A1, W1 = rnd(M, K1, seed=1), rnd(N, K1, seed=2, scale=K1 ** -0.5)
