@@ -61,6 +61,15 @@ struct EpiArgs {
 constexpr float G8_K = 200.0f, G8_O = 26.0f;
 template <int EPI> constexpr bool epi_is_mul() { return EPI == GSL_EPI_MUL || EPI == GSL_EPI_MUL_G8; }
 template <int EPI> constexpr bool epi_is_gelu() { return EPI == GSL_EPI_BIAS_GELU || EPI == GSL_EPI_BIAS_GELU_G8; }
+// Layout of the code tensor: SLAB-MAJOR [N / 64][M][64] — the 64 columns a wave owns in both kernels are one contiguous 64-byte piece per
+// row and consecutive rows follow each other, so the 16-row store instruction of the FFN1 epilogue writes 1 KB and the 8-row load
+// instruction of the FFN2-dX epilogue reads 512 B of consecutive memory (row-major [M, N] made them 64-byte pieces 2 KB apart: +8 % write
+// traffic by the PMC counters). The tensor is private to this pair of epilogues (never a GEMM operand); N % 64 == 0.
+#ifdef GSL_G8_ROWMAJOR      // A/B builds only (python -m gslora_hip.build --variant g8rm -DGSL_G8_ROWMAJOR): row-major [M, N] codes
+__device__ __forceinline__ size_t g8_off(int M, int m, int n) { return (size_t)m * 2048 + (size_t)n; }
+#else
+__device__ __forceinline__ size_t g8_off(int M, int m, int n) { return ((size_t)(n >> 6) * (size_t)M + (size_t)m) * 64 + (size_t)(n & 63); }
+#endif
 // kq = 200 * (1 - p): g (already scaled by keep / (1 - p)) -> code
 __device__ __forceinline__ uint32_t g8_pack4(const float g[4], float kq) {
   uint32_t w = 0u;
@@ -140,7 +149,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     for (int i = 0; i < 4; ++i) v[i] *= a[i];
   } else if constexpr (EPI == GSL_EPI_MUL_G8) {
     float a[4];
-    g8_unpack4(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(e.aux) + off), 1.0f / (G8_K) * e.drop.scale, a);
+    g8_unpack4(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(e.aux) + g8_off(e.M, m, n)), 1.0f / (G8_K) * e.drop.scale, a);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= a[i];
   } else if constexpr (EPI == GSL_EPI_PATCH || EPI == GSL_EPI_PATCH_BF16) {
@@ -174,7 +183,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   } else {
     Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
     if constexpr (EPI == GSL_EPI_BIAS_GELU) { if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g); }
-    if constexpr (EPI == GSL_EPI_BIAS_GELU_G8) { if (e.out2) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(e.out2) + off) = g8_pack4(g, G8_K / e.drop.scale); }
+    if constexpr (EPI == GSL_EPI_BIAS_GELU_G8) { if (e.out2) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(e.out2) + g8_off(e.M, m, n)) = g8_pack4(g, G8_K / e.drop.scale); }
   }
 }
 
@@ -313,7 +322,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           const int m = mw + ib * 16 + row, n = nw + c16 * 16;
           if (FULL || (m < e.M && n < e.N)) {
             const uint4 val = *reinterpret_cast<const uint4*>(c8 + row * 80 + c16 * 16);
-            store_stream16(reinterpret_cast<uint8_t*>(e.out2) + (size_t)m * (size_t)e.ldo + (size_t)n, val, e.stmode);
+            store_stream16(reinterpret_cast<uint8_t*>(e.out2) + g8_off(e.M, m, n), val, e.stmode);
           }
         }
       }
@@ -351,7 +360,7 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
 #pragma unroll
     for (int r = 0; r < 8; ++r) {      // aux rows of this 64-row chunk: issued first, consumed after the LDS round trip
       const int m = min(mw + ib * 16 + r * 8 + crow, e.M - 1), n = min(nw + cch * 8, e.N - 8);
-      if constexpr (G8) { const uint2 t = *reinterpret_cast<const uint2*>(aux8 + (size_t)m * e.ldo + n); ax[r].x = t.x; ax[r].y = t.y; }
+      if constexpr (G8) { const uint2 t = *reinterpret_cast<const uint2*>(aux8 + g8_off(e.M, m, n)); ax[r].x = t.x; ax[r].y = t.y; }
       else ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + n);
     }
 #pragma unroll
@@ -415,7 +424,7 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
   for (int r = 0; r < 4; ++r) {
     const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
     if constexpr (G8) {      // 8-bit GELU' codes: 8 bytes per lane and row (only .x / .y of the slot are live)
-      const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(e.aux) + (size_t)m * e.ldo + ncl);
+      const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(e.aux) + g8_off(e.M, m, ncl));
       g.ax[r].x = t.x; g.ax[r].y = t.y;
     } else {
       g.ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + ncl);
@@ -1547,10 +1556,10 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
       GSL_CHECK_ARG(aux, "aux required");
       return launch_gemm<GSL_EPI_MUL>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_GELU_G8:
-      GSL_CHECK_ARG(bias && dtype == GSL_BF16, "bias required, bf16 only");
+      GSL_CHECK_ARG(bias && dtype == GSL_BF16 && (N % 64) == 0, "bias required, bf16 only, N % 64 == 0 (slab-major code tensor)");
       return launch_gemm<GSL_EPI_BIAS_GELU_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_MUL_G8:      // aux = 8-bit GELU' codes [M, ldo bytes]; p_drop = the dropout rate of the forward that wrote them (no mask is applied here)
-      GSL_CHECK_ARG(aux && dtype == GSL_BF16, "aux required, bf16 only");
+      GSL_CHECK_ARG(aux && dtype == GSL_BF16 && (N % 64) == 0, "aux required, bf16 only, N % 64 == 0 (slab-major code tensor)");
       return launch_gemm<GSL_EPI_MUL_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_PATCH:
       GSL_CHECK_ARG(bias && pos && cls && T > 0, "bias/pos/cls/T required");
@@ -1601,8 +1610,8 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
     case GSL_EPI_BIAS_RES_BF16: GSL_CHECK_ARG(bias && res && (ldo % 8) == 0, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_BF16); break;
     case GSL_EPI_BIAS_GELU: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU); break;
     case GSL_EPI_MUL: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL); break;
-    case GSL_EPI_BIAS_GELU_G8: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU_G8); break;
-    case GSL_EPI_MUL_G8: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL_G8); break;
+    case GSL_EPI_BIAS_GELU_G8: GSL_CHECK_ARG(bias && (N % 64) == 0, "bias required, N % 64 == 0"); GSL_LL(GSL_EPI_BIAS_GELU_G8); break;
+    case GSL_EPI_MUL_G8: GSL_CHECK_ARG(aux && (N % 64) == 0, "aux required, N % 64 == 0"); GSL_LL(GSL_EPI_MUL_G8); break;
     default: return fail(GSL_ERR_ARG, "gsl_gemm_nt_lora: unsupported epilogue%s %ld", "", epilogue);
   }
 #undef GSL_LL

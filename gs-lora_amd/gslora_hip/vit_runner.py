@@ -411,7 +411,7 @@ class ViTRunner:
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
             u1 = u2 = None
             h = torch.empty(Mr, mlp, device=img.device, dtype=dt)
-            gp8 = GP8 and dt == torch.bfloat16 and save
+            gp8 = GP8 and dt == torch.bfloat16 and save and mlp % 64 == 0
             epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
             gp = torch.empty(Mr, mlp, device=img.device, dtype=torch.uint8 if gp8 else dt) if save else None
             if lora_on:
@@ -488,6 +488,8 @@ class ViTRunner:
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()     # rows b*T of a [B*T, w] tensor
+        # (the 8-bit GELU' code tensor is slab-major [w/64][rows][64]: its cls rows, again slab-major for B rows)
+        gp_rows = lambda t, w: (t.view(w // 64, B, T, 64)[:, :, 0].contiguous().view(B, w) if t.dtype == torch.uint8 else cls_rows(t, w))
         for i in reversed(range(nl)):
             st = saved["layers"][i]
             blk = blocks[i]
@@ -501,7 +503,7 @@ class ViTRunner:
             sparse = (i == nl - 1) and sp.pool == "cls"      # (with pool='mean' every token carries gradient: dense last block)
             tail = st["tail"]      # the forward of this block already ran on the cls rows: every saved tensor behind the attention is [B, .]
             if sparse and not tail:      # dx / dxb arrive compact ([B, D]) from the head backward
-                dyb, xn2, h, gp, u1, u2 = (dxb, cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), cls_rows(st["gp"], mlp),
+                dyb, xn2, h, gp, u1, u2 = (dxb, cls_rows(st["xn2"], D), cls_rows(st["h"], mlp), gp_rows(st["gp"], mlp),
                                            cls_rows(st["u1"], PADK), cls_rows(st["u2"], PADK))
             else:
                 dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
@@ -613,6 +615,7 @@ class ViTRunner:
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
+        gp_rows = lambda t, w: (t.view(w // 64, B, T, 64)[:, :, 0].contiguous().view(B, w) if t.dtype == torch.uint8 else cls_rows(t, w))
         for i in reversed(range(nl)):
             st = saved["layers"][i]
             blk = sp.blocks[i]
@@ -623,7 +626,7 @@ class ViTRunner:
             sparse = (i == nl - 1) and sp.pool == "cls"      # only the cls rows of the last block carry gradient (see the FFN-site path)
             tail = st["tail"]
             if sparse and not tail:
-                dyb, gp = dxb, cls_rows(st["gp"], mlp)
+                dyb, gp = dxb, gp_rows(st["gp"], mlp)
             else:
                 dyb, gp = dxb, st["gp"]
             Mrows = dyb.shape[0]

@@ -52,11 +52,13 @@ enum gsl_epilogue {
   GSL_EPI_BIAS_RES_BF16 = 7,/* bf16 only, the forward residual stream carried in bf16: out[bf16] = bf16(dropout(acc + bias) + f32(res[bf16]))
                                — f32 arithmetic on the f32 accumulator, one rounding on store; same dropout mask as BIAS_RES_F32 */
   GSL_EPI_PATCH_BF16 = 8,   /* bf16 only: PATCH with a bf16 output */
-  GSL_EPI_MUL_G8 = 9,       /* bf16 only: MUL with aux = the 8-bit GELU' code u8 [M, ldo bytes] written by BIAS_GELU_G8;
+  GSL_EPI_MUL_G8 = 9,       /* bf16 only: MUL with aux = the 8-bit GELU' code tensor (slab-major, see below) written by BIAS_GELU_G8;
                                p_drop = the dropout rate of the forward that wrote it (decode scale 1/(1-p); no mask is applied here) */
   GSL_EPI_BIAS_GELU_G8 = 10 /* bf16 only: BIAS_GELU whose second output is the 8-bit fixed-point code of gelu'(acc+bias)*dropmask:
-                               out2 u8 [M, ldo bytes], q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p).
-                               gelu' lies in [-0.129, 1.129]: absolute error <= 0.0025/(1-p), a dropped element decodes to exactly 0 */
+                               q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p); gelu' lies in [-0.129, 1.129]:
+                               absolute error <= 0.0025/(1-p), a dropped element decodes to exactly 0. out2 is M*N bytes in SLAB-MAJOR
+                               order [N/64][M][64] (element (m, n) at ((n/64)*M + m)*64 + n%64; N % 64 == 0): a tensor private to this
+                               epilogue and its reader, laid out so that both touch consecutive memory */
 };
 
 GSL_API int gsl_version(void);
@@ -101,7 +103,8 @@ GSL_API int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int
  *   G2[n*g2sn + j*g2sj] (+)= sum_m Y2[m,n] * t[m,j]        (dA of the down-projection adapter; Y2 = the saved FFN hidden activation)
  * U1 [M, ldu1 >= 16] bf16 (columns r..15 zero or discarded), Y2 / aux / out [M,N] bf16 with row stride ldo, N % 8 == 0.
  * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible).
- * aux_u8 != 0: aux is the 8-bit GELU' code of GSL_EPI_BIAS_GELU_G8 (u8 [M, ldo bytes]) and p_drop the dropout rate of that forward. */
+ * aux_u8 != 0: aux is the 8-bit GELU' code tensor of GSL_EPI_BIAS_GELU_G8 (slab-major [N/64][M][64], N % 64 == 0) and p_drop the
+ * dropout rate of that forward. */
 GSL_API long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
 GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
                              const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,

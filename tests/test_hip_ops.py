@@ -840,13 +840,25 @@ def test_attention_fwd_cls_equals_the_cls_rows_of_the_dense_forward(ops, dt, B, 
 
 
 # ---------------------------------------------------------------------------------------------------------------- 8-bit GELU'
+def _unslab(q):
+    """slab-major [N/64][M][64] code tensor (stored in a [M, N] uint8 buffer) -> row-major [M, N]"""
+    M, N = q.shape
+    return q.view(N // 64, M, 64).permute(1, 0, 2).reshape(M, N)
+
+
+def _slab(q):
+    M, N = q.shape
+    return q.view(M, N // 64, 64).permute(1, 0, 2).contiguous().view(M, N)
+
+
 @pytest.mark.parametrize("M,N,K1,K2,p", [(130, 128, 64, 0, 0.1), (591, 256, 128, 64, 0.0), (788, 2048, 512, 64, 0.1), (33490, 2048, 512, 64, 0.1),
-                                         (33490, 2056, 512, 0, 0.25)])
+                                         (2600, 2048, 512, 0, 0.25), (33490, 2112, 512, 0, 0.25)])
 def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
     """GSL_EPI_BIAS_GELU_G8: the first output h is bit-identical to BIAS_GELU's; the second is the 8-bit fixed-point code of
     gelu'(a) * keep — q = round(gelu' keep 200 + 26), decoded (q - 26) 0.005 / (1 - p): within half a step (0.0025 / (1 - p)) of the
     bf16 kernel's own f32 value (compared through BIAS_GELU's bf16 output: + its rounding), a dropped element decodes to exactly 0,
-    and the code error has no bias. Fragment path (small M, and N % 16 != 0) and the 8-phase kernel's staged byte path."""
+    and the code error has no bias. The code tensor is slab-major [N/64][M][64]. Fragment paths (64x64 and 128x128 kernels) and the 8-phase
+    kernel's staged byte path."""
     from gslora_hip import _lib as L
     dt = torch.bfloat16
     c = lambda t: None if t is None else t.cuda().to(dt)
@@ -861,6 +873,7 @@ def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
     ops.gemm_nt(A1, W1, h0, epilogue=L.EPI_BIAS_GELU, A2=A2, W2=W2, bias=bias, out2=g0, p_drop=p, seed=7, site=5)
     ops.gemm_nt(A1, W1, h1, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q, p_drop=p, seed=7, site=5)
     assert torch.equal(h0, h1)
+    qs, q = q, _unslab(q)          # the code tensor is slab-major [N/64][M][64]
     assert int(q.max()) <= 252
     dec = (q.float() - 26.0) * (0.005 / (1 - p))
     keep = ops.dropout_mask(M * N, p, 7, 5, "cuda").reshape(M, N).bool() if p > 0 else torch.ones(M, N, device="cuda", dtype=torch.bool)
@@ -873,7 +886,7 @@ def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
     acc = torch.empty(M, N, device="cuda", dtype=torch.float32)
     ops.gemm_nt(A1, W1, acc, epilogue=L.EPI_STORE_F32, A2=A2, W2=W2)
     out = torch.empty(M, N, device="cuda", dtype=dt)
-    ops.gemm_nt(A1, W1, out, epilogue=L.EPI_MUL_G8, A2=A2, W2=W2, aux=q, p_drop=p)
+    ops.gemm_nt(A1, W1, out, epilogue=L.EPI_MUL_G8, A2=A2, W2=W2, aux=qs, p_drop=p)
     want = acc * dec
     assert ((out.float() - want).abs() - 2.0 ** -8 * want.abs()).max() < 1e-5 * max(1.0, want.abs().max().item())
 
@@ -890,7 +903,7 @@ def test_gemm_nt_lora_mulgrad_with_the_8bit_gelu_derivative(ops, M, N, K, r, p):
     Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
     P, Q = c(P), c(Q)
     g = torch.Generator().manual_seed(5)
-    q = torch.randint(0, 253, (M, N), generator=g, dtype=torch.uint8).cuda()
+    q = torch.randint(0, 253, (M, N), generator=g, dtype=torch.uint8).cuda()      # the slab-major buffer; its row-major meaning is _unslab(q)
     Y2 = c(rnd(M, N, seed=8))
     U1 = torch.zeros(M, 64); U1[:, :r] = rnd(M, r, seed=9)
     U1 = c(U1)
@@ -905,7 +918,7 @@ def test_gemm_nt_lora_mulgrad_with_the_8bit_gelu_derivative(ops, M, N, K, r, p):
     ops.gemm_nt_lora_mulgrad(A, W, P, Q, s, tout, out, q, U1, G1, (r, 1), Y2, G2, (1, N), r, accumulate=False, p_drop=p)
     assert torch.equal(out, out0) and torch.equal(tout, tout0)
     assert (G1 - G1r).abs().max().item() < 2e-5 * G1r.abs().max().item() and (G2 - G2r).abs().max().item() < 2e-5 * G2r.abs().max().item()
-    dec = (q.float() - 26.0) * (0.005 / (1 - p))
+    dec = (_unslab(q).float() - 26.0) * (0.005 / (1 - p))
     acc = torch.empty(M, N, device="cuda", dtype=torch.float32)
     ops.gemm_nt_lora(A, W, P, Q, s, None, acc.to(dt), epilogue=L.EPI_STORE)      # (shape check of the plain form)
     plain = torch.empty(M, N, device="cuda", dtype=dt)
