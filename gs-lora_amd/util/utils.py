@@ -11,6 +11,8 @@ import random
 from collections import defaultdict
 
 import torch
+
+from image_iter import CustomSubset  # noqa: E402,F401  (defined where the reference defines it: image_iter.py:124-137; util/utils.py:30 imports it)
 import torch.nn as nn
 
 
@@ -96,21 +98,6 @@ def calculate_prototypes(backbone, dataset, batch_size=32, device="cuda", aug_nu
             counts.index_add_(0, labels, torch.ones_like(labels, dtype=torch.float32))
     sums, counts = sums.cpu(), counts.cpu()
     return {int(c): (sums[c] / counts[c]) for c in torch.nonzero(counts).flatten().tolist()}
-
-
-class CustomSubset(torch.utils.data.Subset):
-    """Subset that keeps `targets` / `classes` of the parent (reference image_iter.py:124-137)."""
-
-    def __init__(self, dataset, indices):
-        super().__init__(dataset, indices)
-        self.targets = dataset.targets
-        self.classes = dataset.classes
-
-    def __getitem__(self, idx):
-        return self.dataset[self.indices[idx]]
-
-    def __len__(self):
-        return len(self.indices)
 
 
 def get_unique_classes(subset, original_dataset):
