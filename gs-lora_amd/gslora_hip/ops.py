@@ -149,16 +149,20 @@ def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_
     _need(dy, x, gamma, mean, rstd)
     M, D = dy.shape
     sdt = dx.dtype if dx is not None else (dres.dtype if dres is not None else torch.float32)
+    own_dx = dx is None
     if dx is None:
         _need(dres)
         dx = torch.empty(M, D, device=dy.device, dtype=sdt)
     elif dres is not None and dres.dtype != dx.dtype:
         raise RuntimeError("layernorm_bwd: dres and dx must share one dtype")
-    dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if want_copy else None
+    # the masked operand copy IS dx when no mask applies (dropout 0: ViT-B/16, eval-free training runs) and the stream already has the
+    # operand dtype: one [M, D] write less per LayerNorm backward
+    alias = bool(want_copy) and float(p_drop) == 0.0 and sdt == dy.dtype and own_dx and not io_row_stride
+    dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if (want_copy and not alias) else None
     L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
                                        int(io_row_stride), _p(dxb), M, D, code(dy.dtype), code(sdt), code(x.dtype), float(p_drop),
                                        int(seed), int(site), int(drop_row_stride), int(dres_cls_T), _stream()), "gsl_layernorm_bwd")
-    return dx, dxb
+    return dx, (dx if alias else dxb)
 
 
 def attention_fwd(qkv, B, T, H, scale, layout=0):
