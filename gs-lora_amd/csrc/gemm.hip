@@ -1140,13 +1140,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   accp[0] = accp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int poff0 = fr * BK + (((0 * 4 + fc) ^ (fr & 7)) << 3), poff1 = fr * BK + (((1 * 4 + fc) ^ (fr & 7)) << 3);
   const int pi = (wn & 1) * 2;      // this wave's two row fragments (within its row half wn >> 1) of the 16 extra columns
-#define GSL_P8_MFMA(RH, CH, BF, PQ)                                                                          \
-  __builtin_amdgcn_s_barrier();                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-  __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                            \
-  if constexpr (LORA && (PQ)) {                                                                             \
-    if ((wn >> 1) == (RH)) {                                                                                \
+  // In-kernel LoRA: the 16 extra output columns t = A P^T need 16 MFMAs per wave row and K tile (8 row fragments x 2 k-steps), shared by
+  // the row's 4 waves. GSL_LORA_SPREAD=1 (measured slower, off): wave wn owns row fragment wn of EACH row half and issues ONE extra MFMA in every phase
+  // (q0 / q1 on the row-half-0 fragment still in registers, q2 / q3 on the row-half-1 fragment): 17 MFMAs per wave and phase. The
+  // default form gives a wave 4 extra MFMAs in ONE phase (20 + 16 + 20 + 16 on the barrier-paced path).
+#ifndef GSL_LORA_SPREAD
+#define GSL_LORA_SPREAD 0
+#endif
+#if GSL_LORA_SPREAD
+#define GSL_P8_PEXTRA(PH)                                                                                   \
+  if constexpr (LORA) {                                                                                     \
+    constexpr int ks_ = (PH) & 1, t_ = (PH) >> 1;                                                           \
+    if (wn == 0) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[0][ks_], accp[t_], 0, 0, 0);      \
+    else if (wn == 1) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[1][ks_], accp[t_], 0, 0, 0); \
+    else if (wn == 2) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[2][ks_], accp[t_], 0, 0, 0); \
+    else accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[3][ks_], accp[t_], 0, 0, 0);               \
+  }
+#else
+#define GSL_P8_PEXTRA(PH)                                                                                   \
+  if constexpr (LORA && ((PH) == 0 || (PH) == 2)) {                                                         \
+    if ((wn >> 1) == ((PH) >> 1)) {                                                                         \
       if (pi) {                                                                                             \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
           accp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[2][ks], accp[0], 0, 0, 0);           \
@@ -1159,7 +1172,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
-  }                                                                                                         \
+  }
+#endif
+  // row fragment (of the wave row's 8) that accp[t] holds
+#if GSL_LORA_SPREAD
+#define GSL_P8_TFRAG(t) ((t) * 4 + wn)
+#else
+#define GSL_P8_TFRAG(t) (2 * wn + (t))
+#endif
+#define GSL_P8_MFMA(RH, CH, BF, PH)                                                                          \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  GSL_P8_PEXTRA(PH)                                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
@@ -1191,7 +1217,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     __builtin_amdgcn_sched_barrier(0);
     stage(kt + 1, P3{});
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    GSL_P8_MFMA(0, 0, bf0, true)
+    GSL_P8_MFMA(0, 0, bf0, 0)
     // ---- q1: (rh0, ch1); reads B-h1; stages B-h0(kt+2)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -1199,7 +1225,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
     __builtin_amdgcn_sched_barrier(0);
     stage(kt + 2, P0{});
-    GSL_P8_MFMA(0, 1, bf1, false)
+    GSL_P8_MFMA(0, 1, bf1, 1)
     // ---- q2: (rh1, ch1); reads A-h1; stages A-h0(kt+2)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -1207,15 +1233,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
     __builtin_amdgcn_sched_barrier(0);
     stage(kt + 2, P1{});
-    GSL_P8_MFMA(1, 1, bf1, true)
+    GSL_P8_MFMA(1, 1, bf1, 2)
     // ---- q3: (rh1, ch0); no reads; stages B-h1(kt+2); the once-per-K-tile counted wait: K tile kt+1 has landed
     stage(kt + 2, P2{});
     if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    GSL_P8_MFMA(1, 0, bf0, false)
+    GSL_P8_MFMA(1, 0, bf0, 3)
   }
 #undef GSL_P8_MFMA
+#undef GSL_P8_PEXTRA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
   if (dbg8) dbg8[2] = __builtin_readcyclecounter();
   if constexpr (LORA && GRAD) {
@@ -1223,7 +1250,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      bf16_t* d = t16 + (wm * 128 + (2 * wn + t) * 16 + fr) * 16 + fc * 4;
+      bf16_t* d = t16 + (wm * 128 + GSL_P8_TFRAG(t) * 16 + fr) * 16 + fc * 4;
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
     }
     __syncthreads();
@@ -1264,12 +1291,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if (dbg8) dbg8[3] = __builtin_readcyclecounter();
     return;
   } else if constexpr (LORA) {
-    // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + (2wn+t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
+    // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + GSL_P8_TFRAG(t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
     __builtin_amdgcn_s_barrier();                      // stages are free
     bf16_t* tbuf = smem;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      bf16_t* d = tbuf + (wm * 128 + (2 * wn + t) * 16 + fr) * 32 + fc * 4;
+      bf16_t* d = tbuf + (wm * 128 + GSL_P8_TFRAG(t) * 16 + fr) * 32 + fc * 4;
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
