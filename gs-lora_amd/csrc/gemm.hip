@@ -48,6 +48,7 @@ struct EpiArgs {
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
   int gR;                         // 8 or 16
   int hmT, hmH;                   // STORE_QKV_HM: tokens per image and heads (0 = plain row-major output)
+  int stamps_all;                 // development (GSL_P8_STAMPS_ALL): every workgroup stamps
   unsigned long long* stamps;     // development (GSL_P8_STAMPS = device address of 256 x 4 u64): cycle stamps of every 64th workgroup of the 8-phase kernel
 };
 
@@ -1121,6 +1122,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   // development: cycle stamps (kernel start, prologue landed, K loop done, epilogue done) of every 64th workgroup
 #ifdef GSL_DEV
   unsigned long long* dbg8 = (e.stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0 && tid == 0) ? e.stamps + (blockIdx.x / 64) * 4 : nullptr;
+  // GSL_P8_STAMPS_ALL: every workgroup records (buffer of gridDim.x x 4 u64), the start stamp carries XCC_ID / HW_ID in its top 16 bits
+  if (e.stamps && e.stamps_all) dbg8 = tid == 0 ? e.stamps + (size_t)blockIdx.x * 4 : nullptr;
+  if (dbg8 && e.stamps_all) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long id = ((unsigned long long)(xcc & 15u) << 12) | ((hw >> 8) & 0xfffu);   // cu_id[11:8], sh_id[12], se_id[15:13]...
+    dbg8[0] = (__builtin_readcyclecounter() & 0xffffffffffffull) | (id << 48);
+  } else
 #else
   constexpr unsigned long long* dbg8 = nullptr;
 #endif
@@ -1419,12 +1429,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr;
+  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
   { const char* sm = getenv("GSL_STORE_MODE"); if (sm) e.stmode = atoi(sm); }
   { const char* sp = getenv("GSL_P8_STAMPS"); if (sp) e.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)); }
+  { const char* sp = getenv("GSL_P8_STAMPS_ALL"); e.stamps_all = sp && atoi(sp); }
 #else
   (void)allow_krot;
 #endif
