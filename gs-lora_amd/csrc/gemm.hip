@@ -40,6 +40,7 @@ struct EpiArgs {
   DropCfg drop;
   int M, N;
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
+  int mrev;    // 8-phase kernel: tiles in reverse order (the consumer starts on the rows its producer wrote last: still in the 256 MB Infinity Cache)
   int stmode;  // output store flavour of the staged bf16 epilogue (development knob GSL_STORE_MODE, see store_stream16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
   // gradient-fused MUL epilogue (gsl_gemm_nt_lora_mulgrad): operands of the two LoRA-gradient reductions that consume this tile
@@ -1059,7 +1060,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nbn = (e.N + BN4 - 1) / BN4;
-  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tile0 = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tile = e.mrev ? (int)gridDim.x - 1 - tile0 : tile0;
   const int m0 = (tile / nbn) * BM4, n0 = (tile % nbn) * BN4;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
   const int krot = e.krot ? (tile % nbn) % nk : 0;
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0;
+  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
@@ -1438,6 +1440,18 @@ static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
   { const char* sp = getenv("GSL_P8_STAMPS_ALL"); e.stamps_all = sp && atoi(sp); }
 #else
   (void)allow_krot;
+#endif
+}
+
+// development: GSL_MREV = bit mask of the 8-phase launches that walk their tiles in reverse order (key: epilogue id; STORE: 0 N > K,
+// 11 N < K, 12 N == K; 16 + epilogue id for the in-kernel-LoRA form; 30 the gradient-fused FFN2-dX)
+static inline int mrev_for(int key) {
+#ifdef GSL_DEV
+  static const long mask = [] { const char* m = getenv("GSL_MREV"); return m ? strtol(m, nullptr, 0) : 0L; }();
+  return (int)((mask >> key) & 1);
+#else
+  (void)key;
+  return 0;
 #endif
 }
 
@@ -1535,8 +1549,10 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     }
 #endif
     if (variant == 8) {
+      EpiArgs e8 = e;
+      e8.mrev = mrev_for(EPI == GSL_EPI_STORE ? (e.N > K1 ? 0 : (e.N < K1 ? 11 : 12)) : EPI);
       hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e8);
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else if (variant == 12) {
@@ -1639,6 +1655,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
 #define GSL_LL(EPIV)                                                                                                              \
   do {                                                                                                                            \
     GSL_LL_DEV(EPIV)                                                                                                              \
+    e.mrev = mrev_for(16 + EPIV);                                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPIV, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,     \
                        ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);                                    \
   } while (0)
@@ -1721,6 +1738,7 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;
   const int nb = ntile * ((N + BN4 - 1) / BN4);
   hipStream_t st = as_stream(s);
+  e.mrev = mrev_for(30);
   if (aux_u8)
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<GSL_EPI_MUL_G8, true, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,
                        ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);

@@ -154,6 +154,105 @@ static int ln_bwd_launch(const void* dy, const void* x, long xs, const float* ga
   return check_launch("gsl_layernorm_bwd");
 }
 
+// =====================================================================================
+// LayerNorm forward + LoRA down-projection in one pass (bf16 mode): xn = LN(x) and u = alpha * xn P^T for the rank-r adapter that reads
+// xn (FFN1's lora_A: the second K segment [xn | u] of the fused FFN1 GEMM, vit_face.py:330 + loralib Linear.forward). The separate
+// skinny GEMM re-read xn (206 MB at M = 201 728) for 16 output columns. Here a wave owns 16 rows at a time and holds them in the MFMA
+// operand layout (lane l: row l % 16, the 8-element chunks 32 s + 8 (l / 16) of every 32-wide k-step s: one 16-byte load per step), so
+// the normalised row, rounded to bf16 for the store, IS the B operand of v_mfma_f32_16x16x32_bf16 against P's fragments (LDS):
+// u^T[j][row] accumulates in k order like the GEMM it replaces. Row statistics: 128 (192) elements per lane + two xor-shuffles over the
+// four lanes of a row; two-pass (mean, centred variance) as the plain kernel. gamma / beta / P live in LDS.
+// u is written as [M, 64] bf16 with columns >= 16 zero (the K-segment width of the consumer).
+// =====================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 ln_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float ln_f32x4_t;
+
+template <int KS>
+__global__ __launch_bounds__(256, (KS <= 16 ? 4 : 3)) void ln_fwd_lora_kernel(const bf16_t* __restrict__ x, long xs, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                          const bf16_t* __restrict__ P, int ldp, float alpha, bf16_t* __restrict__ u) {
+  constexpr int D = KS * 32;
+  constexpr int PLD = D + 8;                  // 16 more bytes per row: the 16 rows of a fragment read start 4 banks apart
+  __shared__ float sg[D], sb[D];
+  __shared__ __attribute__((aligned(16))) bf16_t sP[16 * PLD];
+  for (int i = threadIdx.x; i < D; i += blockDim.x) { sg[i] = gamma[i]; sb[i] = beta[i]; }
+  for (int i = threadIdx.x; i < 16 * (D / 8); i += blockDim.x) {
+    const int j = i / (D / 8), c = i - j * (D / 8);
+    *reinterpret_cast<uint4*>(&sP[j * PLD + c * 8]) = *reinterpret_cast<const uint4*>(P + (size_t)j * ldp + c * 8);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 15, kc = lane >> 4;
+  const int wpb = blockDim.x >> 6, ngrp = (M + 15) >> 4;
+  for (int grp = blockIdx.x * wpb + (threadIdx.x >> 6); grp < ngrp; grp += gridDim.x * wpb) {
+    const int row = grp * 16 + r;
+    const bool valid = row < M;
+    const bf16_t* px = x + (size_t)(valid ? row : M - 1) * xs + kc * 8;
+    uint4 v[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) v[s] = *reinterpret_cast<const uint4*>(px + s * 32);
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint32_t w[4] = {v[s].x, v[s].y, v[s].z, v[s].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum += __uint_as_float(w[i] << 16) + __uint_as_float(w[i] & 0xffff0000u);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mu = sum * (1.0f / D);
+    // the packed row stays the only copy: without the opaque touch the compiler keeps the 128 converted floats of one pass for the next (spills)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(v[s].x), "+v"(v[s].y), "+v"(v[s].z), "+v"(v[s].w));
+    float q = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint32_t w[4] = {v[s].x, v[s].y, v[s].z, v[s].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = __uint_as_float(w[i] << 16) - mu, b = __uint_as_float(w[i] & 0xffff0000u) - mu;
+        q += a * a + b * b;
+      }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rs = rsqrtf(q * (1.0f / D) + eps);
+    const float mu3 = mu;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(v[s].x), "+v"(v[s].y), "+v"(v[s].z), "+v"(v[s].w));
+    ln_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    bf16_t* py = y + (size_t)row * D + kc * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = s * 32 + kc * 8;
+      const float4 g0 = *reinterpret_cast<const float4*>(&sg[k0]), g1 = *reinterpret_cast<const float4*>(&sg[k0 + 4]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&sb[k0]), b1 = *reinterpret_cast<const float4*>(&sb[k0 + 4]);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const uint32_t w[4] = {v[s].x, v[s].y, v[s].z, v[s].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = (__uint_as_float(w[i] << 16) - mu3) * rs * gg[2 * i] + bb[2 * i];
+        const float b = (__uint_as_float(w[i] & 0xffff0000u) - mu3) * rs * gg[2 * i + 1] + bb[2 * i + 1];
+        o[i] = pack2bf(a, b);
+      }
+      union { uint4 q4; ln_bf16x8_t h; } xf, pf;
+      xf.q4 = make_uint4(o[0], o[1], o[2], o[3]);
+      if (valid) *reinterpret_cast<uint4*>(py + s * 32) = xf.q4;
+      pf.q4 = *reinterpret_cast<const uint4*>(&sP[r * PLD + k0]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf.h, xf.h, acc, 0, 0, 0);      // acc[i] = u[row][4 kc + i]
+      __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of step s + 1 behind this step (hoisted, they cost 300 more VGPRs)
+    }
+    if (valid) {
+      bf16_t* pu = u + (size_t)row * 64;
+      *reinterpret_cast<uint2*>(pu + kc * 4) = make_uint2(pack2bf(acc[0] * alpha, acc[1] * alpha), pack2bf(acc[2] * alpha, acc[3] * alpha));
+      *reinterpret_cast<uint4*>(pu + 16 + kc * 8) = make_uint4(0u, 0u, 0u, 0u);
+      if (kc < 2) *reinterpret_cast<uint4*>(pu + 48 + kc * 8) = make_uint4(0u, 0u, 0u, 0u);
+      if (kc == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+  }
+}
+
 #define GSL_DISPATCH_D(D, CALL)                                                             \
   switch (D) {                                                                              \
     case 64: return CALL(1);                                                                \
@@ -192,4 +291,22 @@ extern "C" int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_strid
 #define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, x_dtype, drop, drs, dres_cls_T, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
+}
+
+// LayerNorm forward that also emits u = alpha * LN(x) P^T (bf16 mode; P [>= 16, D] bf16 rows = lora_A rows zero-padded to 16; u [M, 64] bf16,
+// columns >= 16 written as zero): see ln_fwd_lora_kernel. D in {512, 768}.
+extern "C" int gsl_layernorm_fwd_lora(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps, void* y,
+                                      float* mean, float* rstd, int M, int D, const void* P, int ldp, float alpha, void* u,
+                                      gsl_stream_t s) {
+  GSL_CHECK_ARG(x && gamma && beta && y && mean && rstd && P && u && M > 0, "null/size");
+  GSL_CHECK_ARG(D == 512 || D == 768, "width (512 or 768)");
+  GSL_CHECK_ARG((x_row_stride % 8) == 0 && (ldp % 8) == 0 && ldp >= D, "row stride alignment");
+  const int grid = min((M + 63) / 64, 256 * 4);
+  if (D == 512)
+    hipLaunchKernelGGL((ln_fwd_lora_kernel<16>), dim3(grid), dim3(256), 0, as_stream(s), (const bf16_t*)x, x_row_stride, gamma, beta, eps,
+                       (bf16_t*)y, mean, rstd, M, (const bf16_t*)P, ldp, alpha, (bf16_t*)u);
+  else
+    hipLaunchKernelGGL((ln_fwd_lora_kernel<24>), dim3(grid), dim3(256), 0, as_stream(s), (const bf16_t*)x, x_row_stride, gamma, beta, eps,
+                       (bf16_t*)y, mean, rstd, M, (const bf16_t*)P, ldp, alpha, (bf16_t*)u);
+  return check_launch("gsl_layernorm_fwd_lora");
 }

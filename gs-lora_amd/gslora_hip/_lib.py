@@ -37,6 +37,7 @@ SIGNATURES = {
     "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
                                  _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _i, _f, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gsl_layernorm_fwd_lora": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],

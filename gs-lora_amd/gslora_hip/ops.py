@@ -141,6 +141,21 @@ def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     return y, mean, rstd
 
 
+def layernorm_fwd_lora(x, row_stride, M, D, gamma, beta, eps, P, alpha, pad=64):
+    """bf16 mode: (LN(x), mean, rstd, u) with u = alpha * LN(x) P[:16]^T in a [M, 64] K-segment buffer (columns >= 16 zero): LayerNorm and
+    the LoRA down-projection of the layer that consumes it in one pass over x (gsl_layernorm_fwd_lora)."""
+    _need(x, gamma, beta, P)
+    if x.dtype != torch.bfloat16 or P.dtype != torch.bfloat16 or P.shape[0] < 16 or P.shape[1] != D or pad != 64:
+        raise ValueError("layernorm_fwd_lora: bf16 x, P [>= 16, D] bf16, 64-column u")
+    y = torch.empty(M, D, device=x.device, dtype=torch.bfloat16)
+    u = torch.empty(M, pad, device=x.device, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    L.check(L.load().gsl_layernorm_fwd_lora(_p(x), row_stride, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), M, D,
+                                            _p(P), P.stride(0), float(alpha), _p(u), _stream()), "gsl_layernorm_fwd_lora")
+    return y, mean, rstd, u
+
+
 def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
                   io_row_stride=0, drop_row_stride=0, dres_cls_T=0):
     """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the

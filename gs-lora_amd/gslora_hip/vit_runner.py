@@ -42,6 +42,9 @@ GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
 # rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
 INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
+# bf16 stream: the LayerNorm in front of the FFN also emits the FFN1 adapter's down-projection u1 = s * LN(x) A1^T (gsl_layernorm_fwd_lora)
+# instead of a skinny GEMM that re-reads LN(x). Measured time-neutral (profiles/r03_notes.md): off by default, GSLORA_LN_LORA=1 selects it.
+LN_LORA = os.environ.get("GSLORA_LN_LORA", "0") != "0"
 # layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
 # read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
 QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
@@ -402,10 +405,16 @@ class ViTRunner:
             ops.gemm_nt(o, self.w(f"wo{i}", blk.out.weight, dt), x1, epilogue=epi_res,
                         bias=blk.out.bias.detach(), res=xres, p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
             del xres
-            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, Mr, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
             l1, l2 = blk.l1, blk.l2
             mlp = l1.weight.shape[0]
             lora_on = r > 0 and not attn_site and not l1.merged
+            # bf16 stream: LayerNorm 2 also emits u1 = s * xn2 A1^T (the LoRA K segment of FFN1) instead of a skinny GEMM that re-reads xn2
+            ln_u1 = LN_LORA and lora_on and r <= 16 and D in (512, 768) and x1.dtype == torch.bfloat16 and dt == torch.bfloat16
+            if ln_u1:
+                xn2, mean2, rstd2, u1_ln = ops.layernorm_fwd_lora(x1, D, Mr, D, n2.weight.detach(), n2.bias.detach(), eps,
+                                                                   self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), s_lora)
+            else:
+                xn2, mean2, rstd2 = ops.layernorm_fwd(x1, D, Mr, D, n2.weight.detach(), n2.bias.detach(), eps, dt)
             if lora_on and (abs(l1.scaling * r - 1.0) > 1e-9 or abs(l2.scaling * r - 1.0) > 1e-9):
                 raise NotImplementedError("gs-lora_amd: the fused LoRA path uses scaling = 1 / r (lora_alpha = 1, the only value GS-LoRA "
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
@@ -415,8 +424,11 @@ class ViTRunner:
             epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
             gp = torch.empty(Mr, mlp, device=img.device, dtype=torch.uint8 if gp8 else dt) if save else None
             if lora_on:
-                u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
-                ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
+                if ln_u1:
+                    u1 = u1_ln
+                else:
+                    u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
+                    ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, A2=u1,
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                             p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")

@@ -118,6 +118,12 @@ GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int 
  * D in {64,128,256,512,768,1024}. */
 GSL_API int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                       void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s);
+/* LayerNorm forward + the LoRA down-projection that reads its output, in one pass (bf16 mode): y = LN(x) [M,D] bf16 and
+ * u = alpha * y P^T for the rank-r adapter of the layer that consumes y (FFN1's lora_A, vit_face.py:330 + loralib Linear.forward):
+ * P [>= 16, D] bf16 at row stride ldp (rows j < r = lora_A[j,:], the rest zero), u [M,64] bf16 dense with columns >= 16 written as zero —
+ * the LoRA K segment of gsl_gemm_nt. Replaces gsl_layernorm_fwd + a skinny gsl_gemm_nt that re-read y. x bf16 at x_row_stride; D in {512, 768}. */
+GSL_API int gsl_layernorm_fwd_lora(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps, void* y,
+                           float* mean, float* rstd, int M, int D, const void* P, int ldp, float alpha, void* u, gsl_stream_t s);
 /* dx = dres + LN'(dy) ; dxb[dtype] = dx * dropmask(site) (nullable). dy is `dtype` [M,D] (dense). dres / dx — the residual-GRADIENT
  * stream — are `stream_dtype`: f32, or bf16 when dtype is bf16 (speed mode: the stream is re-read and re-written by every LayerNorm
  * backward of the chain). x (the saved forward stream) is `x_dtype`.

@@ -924,3 +924,31 @@ def test_gemm_nt_lora_mulgrad_with_the_8bit_gelu_derivative(ops, M, N, K, r, p):
     plain = torch.empty(M, N, device="cuda", dtype=dt)
     ops.gemm_nt_lora(A, W, P, Q, s, None, plain, epilogue=L.EPI_STORE)
     assert relerr((out0.float()).cpu(), (plain.float() * dec).cpu()) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,D,r", [(1000, 512, 8), (37, 512, 8), (16 * 300 + 5, 768, 16), (1, 512, 4)])
+def test_layernorm_fwd_with_lora_down_projection(ops, M, D, r):
+    """gsl_layernorm_fwd_lora: LayerNorm + u = alpha * LN(x) P^T in one pass over the bf16 stream, against the two launches it replaces
+    (gsl_layernorm_fwd, then the skinny gsl_gemm_nt over its output) and against torch fp32. Ragged row counts exercise the partial
+    16-row group; the 64-column K-segment buffer must come back with columns >= 16 zeroed (it is torch.empty)."""
+    dt = torch.bfloat16
+    x = (rnd(M, D, seed=1, scale=2.0) + 0.5).to(dt).cuda()
+    g, b = (1 + 0.1 * rnd(D, seed=2)).cuda(), (0.1 * rnd(D, seed=3)).cuda()
+    P = torch.zeros(64, D); P[:r] = rnd(r, D, seed=4, scale=D ** -0.5)
+    P = P.to(dt).cuda()
+    alpha = 1.0 / r
+    torch.empty(M, 64, device="cuda", dtype=dt).fill_(7.0)          # poison the allocator's next [M, 64] block
+    y, mean, rstd, u = ops.layernorm_fwd_lora(x, D, M, D, g, b, 1e-5, P, alpha)
+    y0, mean0, rstd0 = ops.layernorm_fwd(x, D, M, D, g, b, 1e-5, dt)
+    u0 = torch.empty(M, 64, device="cuda", dtype=dt)
+    ops.gemm_nt(y0, P, u0, alpha=alpha)
+    ref = F.layer_norm(x.float().cpu(), (D,), g.cpu(), b.cpu(), 1e-5)
+    assert (y.float().cpu() - ref).abs().max() < 3e-2
+    assert (mean - mean0).abs().max() < 1e-5 and relerr(rstd, rstd0) < 1e-5
+    # the two kernels sum the row in different orders: at most one bf16 ulp apart, and only where the f32 value sits on a rounding edge
+    d = (y.float() - y0.float()).abs()
+    assert (d <= y0.float().abs() * 2.0 ** -7 + 1e-6).all() and (d > 0).float().mean() < 0.02
+    assert torch.count_nonzero(u[:, 16:]) == 0 and torch.count_nonzero(u[:, r:16]) == 0
+    u_ref = alpha * (y.float() @ P[:16].float().t())                 # from the bf16 rows the kernel itself wrote
+    assert (u[:, :16].float() - u_ref).abs().max() <= u_ref.abs().max() * 2.0 ** -8 + 1e-6
+    assert (u.float() - u0.float()).abs().max() < 2e-2 * max(1.0, u0.float().abs().max().item())
