@@ -40,6 +40,7 @@ struct EpiArgs {
   DropCfg drop;
   int M, N;
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
+  int pf;      // 8-phase kernel: after its K loop a workgroup touches the first A lines of the tile that takes a slot of its XCD next (see the kernel)
   int mrev;    // 8-phase kernel: tiles in reverse order (the consumer starts on the rows its producer wrote last: still in the 256 MB Infinity Cache)
   int stmode;  // output store flavour of the staged bf16 epilogue (development knob GSL_STORE_MODE, see store_stream16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
@@ -1207,6 +1208,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   __builtin_amdgcn_s_barrier();                                                                             \
   __builtin_amdgcn_sched_barrier(0);
 
+  // (development, measured useless: profiles/r03_notes.md) L2 warm-up for the NEXT round: block b + 256 is dispatched to this block's XCD (b % 8) when one of its 32 slots frees. Its prologue
+  // waits on A rows nobody has read yet (2.5 - 6 k cycles, profiles/r03_h_wg_timeline.md); touching one dword per 128-byte line of its
+  // first two K tiles pulls them into this XCD's L2 ahead of time. The loads land in a 2 KB LDS dump (LDS-DMA: no VGPR is written behind
+  // the compiler's back) and are never read. Issue point (e.pf): 1 after the K loop, 2 in K-loop step 0, 3 in step nk - 3 — inside the
+  // loop right behind the counted wait, so that the next step's wait (which retires it, in order) comes a whole K tile later.
+#ifdef GSL_DEV
+  __shared__ uint32_t pf_dump[512];
+  auto warm_next = [&]() {
+    const int nb = (int)blockIdx.x + 256;
+    if (nb < (int)gridDim.x) {
+      const int t0 = e.remap ? xcd_remap(nb, gridDim.x) : nb;
+      const int t2 = e.mrev ? (int)gridDim.x - 1 - t0 : t0;
+      const int prow = min((t2 / nbn) * BM4 + (tid >> 1), e.M - 1);
+      int pk = (krot + (tid & 1)) * BK;                // its loop steps 0 and 1 (K rotation included)
+      if (pk >= K1) pk = 0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(A1 + (size_t)prow * lda1 + pk), (lptr_t)(pf_dump + wave * 64), 4, 0, 0);
+    }
+  };
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const bf16_t* As0 = smem + (kt & 1) * STG;
     const bf16_t* As1 = As0 + HT;
@@ -1251,12 +1271,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#ifdef GSL_DEV
+    if ((e.pf == 2 && kt == 0) || (e.pf == 3 && kt == nk - 3)) warm_next();
+#endif
     GSL_P8_MFMA(1, 0, bf0, 3)
   }
 #undef GSL_P8_MFMA
 #undef GSL_P8_PEXTRA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
   if (dbg8) dbg8[2] = __builtin_readcyclecounter();
+#ifdef GSL_DEV
+  if (e.pf == 1) warm_next();
+#endif
   if constexpr (LORA && GRAD) {
     // same as below with t kept as [256][16] behind the staging regions (the K-loop stages end before it: no barrier needed first)
     bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
@@ -1431,13 +1457,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0;
+  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
   { const char* sm = getenv("GSL_STORE_MODE"); if (sm) e.stmode = atoi(sm); }
   { const char* sp = getenv("GSL_P8_STAMPS"); if (sp) e.stamps = reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)); }
   { const char* sp = getenv("GSL_P8_STAMPS_ALL"); e.stamps_all = sp && atoi(sp); }
+  { const char* pf = getenv("GSL_PF"); if (pf) e.pf = atoi(pf); }
 #else
   (void)allow_krot;
 #endif
