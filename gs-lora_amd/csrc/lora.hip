@@ -165,13 +165,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 lg_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float lg_f32x4_t;
 constexpr int LGM_CN = 256, LGM_YLD = LGM_CN + 16, LGM_ULD = 32, LGM_K = 32;
 
-template <int R>
-__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
-                                                             float* __restrict__ part, int M, int N, int rows_per_split) {
+// body of one workgroup: column block bxi (256 columns of Y), row split `split`; R = padded rank of the partial layout (8 or 16)
+__device__ __forceinline__ void lgm_block(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
+                                          float* __restrict__ part, int M, int N, int rows_per_split, int R, int bxi, int split) {
   __shared__ __attribute__((aligned(16))) bf16_t ys[2][LGM_K * LGM_YLD];
   __shared__ __attribute__((aligned(16))) bf16_t us[2][LGM_K * LGM_ULD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * LGM_CN, split = blockIdx.y;
+  const int n0 = bxi * LGM_CN;
   const int r0 = split * rows_per_split, r1 = min(M, r0 + rows_per_split);
   const int lc = tid & 31, lr = tid >> 5;
   uint4 yreg[4], ureg = make_uint4(0, 0, 0, 0);
@@ -228,6 +228,45 @@ __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __res
         part[((size_t)split * N + n) * R + i16] = acc[t][r];
       }
   }
+}
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
+                                                             float* __restrict__ part, int M, int N, int rows_per_split) {
+  lgm_block(Y, ldy, U, ldu, part, M, N, rows_per_split, R, blockIdx.x, blockIdx.y);
+}
+
+// ---- batched form: every LoRA-gradient reduction of a backward pass in two launches (the launch-bound regime: few-shot batches run 24
+// of them, 48 launches of 3 - 8 us each). The descriptors travel BY VALUE in the kernel arguments, so a captured HIP graph carries them.
+constexpr int LGB_MAX = 24;
+struct LgbEntry {
+  const bf16_t* Y; const bf16_t* U; float* G;
+  long ldy, gsn, gsj, ws0;
+  int ldu, M, N, r, R, acc, bx, nsplit, rps, wg0, rb0;      // wg0 / rb0: first workgroup of this entry in the partial / reduce launch
+};
+struct LgbArgs { int n; LgbEntry e[LGB_MAX]; };
+
+__global__ __launch_bounds__(256) void lora_grad_batch_partial_kernel(const LgbArgs a, float* __restrict__ ws) {
+  int d = 0;
+  for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].wg0) ? k : d;
+  const LgbEntry& e = a.e[d];
+  const int local = (int)blockIdx.x - e.wg0;
+  lgm_block(e.Y, e.ldy, e.U, e.ldu, ws + e.ws0, e.M, e.N, e.rps, e.R, local % e.bx, local / e.bx);
+}
+// fixed-order sum of an entry's splits, output strides (+ accumulate) applied on the way out
+__global__ __launch_bounds__(256) void lora_grad_batch_reduce_kernel(const LgbArgs a, const float* __restrict__ ws) {
+  int d = 0;
+  for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].rb0) ? k : d;
+  const LgbEntry& e = a.e[d];
+  const int idx = ((int)blockIdx.x - e.rb0) * 256 + (int)threadIdx.x;
+  if (idx >= e.N * e.R) return;
+  const int n = idx / e.R, j = idx - n * e.R;
+  if (j >= e.r) return;
+  const float* p = ws + e.ws0 + idx;
+  const size_t NR = (size_t)e.N * e.R;
+  float s = 0.f;
+  for (int k = 0; k < e.nsplit; ++k) s += p[(size_t)k * NR];
+  float* g = e.G + (size_t)n * e.gsn + (size_t)j * e.gsj;
+  *g = e.acc ? (*g + s) : s;
 }
 static inline void lgm_plan(int M, int N, int& bx, int& nsplit, int& rps) {
   bx = N / LGM_CN;
@@ -435,6 +474,61 @@ __global__ void gnorm_final_kernel(const float* __restrict__ partial, const int3
     for (int g = 0; g < ngroups; ++g) l += group_norm[g];
     loss[0] = l;
   }
+}
+
+static int lgb_plan(const gsl_lgrad_desc* descs, int n, LgbArgs* out, long* ws_elems, int* nwg, int* nrb) {
+  long ws = 0; int wg = 0, rb = 0;
+  for (int k = 0; k < n; ++k) {
+    const gsl_lgrad_desc& d = descs[k];
+    GSL_CHECK_ARG(d.Y && d.U && d.G && d.M > 0 && d.N > 0 && d.ldy >= d.N, "null/size");
+    GSL_CHECK_ARG(d.r >= 1 && d.r <= 16 && d.ldu >= 16 && (d.ldu % 8) == 0 && (d.ldy % 8) == 0 && (d.N % LGM_CN) == 0, "r in [1,16], ldu >= 16, N % 256 == 0, 16-byte rows");
+    GSL_CHECK_ARG((reinterpret_cast<uintptr_t>(d.Y) % 16) == 0 && (reinterpret_cast<uintptr_t>(d.U) % 16) == 0, "16-byte aligned operands");
+    int bx, nsplit, rps;
+    lgm_plan(d.M, d.N, bx, nsplit, rps);
+    const int R = d.r <= 8 ? 8 : 16;
+    if (out) {
+      LgbEntry& e = out->e[k];
+      e.Y = (const bf16_t*)d.Y; e.U = (const bf16_t*)d.U; e.G = d.G; e.ldy = d.ldy; e.gsn = d.gsn; e.gsj = d.gsj; e.ws0 = ws;
+      e.ldu = d.ldu; e.M = d.M; e.N = d.N; e.r = d.r; e.R = R; e.acc = d.accumulate; e.bx = bx; e.nsplit = nsplit; e.rps = rps;
+      e.wg0 = wg; e.rb0 = rb;
+    }
+    ws += (long)nsplit * d.N * R;
+    wg += bx * nsplit;
+    rb += (d.N * R + 255) / 256;
+  }
+  if (out) out->n = n;
+  if (ws_elems) *ws_elems = ws;
+  if (nwg) *nwg = wg;
+  if (nrb) *nrb = rb;
+  return GSL_OK;
+}
+
+extern "C" long gsl_lora_grad_batch_ws_elems(const gsl_lgrad_desc* descs, int n) {
+  long total = 0;
+  for (int k0 = 0; k0 < n; k0 += LGB_MAX) {
+    long ws = 0;
+    if (lgb_plan(descs + k0, min(LGB_MAX, n - k0), nullptr, &ws, nullptr, nullptr) != GSL_OK) return -1;
+    if (ws > total) total = ws;
+  }
+  return total;
+}
+
+// n LoRA-gradient reductions G_k (+)= Y_k^T U_k (bf16 operands, see gsl_lora_grad) in two launches per 24 descriptors. descs is a HOST
+// array: the launch carries the descriptors by value (HIP-graph capture keeps them). The G_k of one call must not overlap.
+extern "C" int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, gsl_stream_t s) {
+  GSL_CHECK_ARG(descs && n > 0 && ws, "null/size");
+  hipStream_t st = as_stream(s);
+  for (int k0 = 0; k0 < n; k0 += LGB_MAX) {
+    LgbArgs a;
+    int nwg = 0, nrb = 0;
+    const int rc = lgb_plan(descs + k0, min(LGB_MAX, n - k0), &a, nullptr, &nwg, &nrb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lora_grad_batch_partial_kernel, dim3(nwg), dim3(256), 0, st, a, ws);
+    hipLaunchKernelGGL(lora_grad_batch_reduce_kernel, dim3(nrb), dim3(256), 0, st, a, (const float*)ws);
+    const int rc2 = check_launch("gsl_lora_grad_batch");
+    if (rc2) return rc2;
+  }
+  return GSL_OK;
 }
 
 extern "C" int gsl_group_norms_fwd(const float* flat, const int64_t* toff, const int64_t* tnumel, const int32_t* tgroup,

@@ -45,6 +45,8 @@ SIGNATURES = {
     "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp],
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
     "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
+    "gsl_lora_grad_batch_ws_elems": [_vp, _i],
+    "gsl_lora_grad_batch": [_vp, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
     "gsl_head_fwd": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
     "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp],
@@ -64,7 +66,8 @@ SIGNATURES = {
     "gsl_pack_pad_batch": [_vp, _i, _l, _i, _vp],
     "gsl_dropout_mask": [_vp, _l, _f, _u64, _u32, _vp],
 }
-_RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long, "gsl_gemm_mulgrad_ws_elems": C.c_long}
+_RESTYPES = {"gsl_last_error": C.c_char_p, "gsl_lora_grad_ws_elems": C.c_long, "gsl_gemm_mulgrad_ws_elems": C.c_long,
+             "gsl_lora_grad_batch_ws_elems": C.c_long}
 
 _lib = None
 

@@ -1,5 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (include/gslora_hip.h). PyTorch supplies device
 memory and the stream; every FLOP of the step runs in libgslora_hip.so. No fallbacks."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -245,6 +247,44 @@ def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
         _ws_cache[key] = ws
     L.check(lib.gsl_lora_grad(_p(Y), Y.stride(0), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype),
                               1 if accumulate else 0, _p(ws), _stream()), "gsl_lora_grad")
+
+
+class _LgradDesc(ctypes.Structure):      # mirrors struct gsl_lgrad_desc (include/gslora_hip.h), 72 bytes
+    _fields_ = [("Y", ctypes.c_void_p), ("ldy", ctypes.c_long), ("U", ctypes.c_void_p), ("ldu", ctypes.c_int), ("M", ctypes.c_int),
+                ("N", ctypes.c_int), ("r", ctypes.c_int), ("accumulate", ctypes.c_int), ("pad_", ctypes.c_int), ("G", ctypes.c_void_p),
+                ("gsn", ctypes.c_long), ("gsj", ctypes.c_long)]
+
+
+def lora_grad_batchable(Y, U, r):
+    """Can this reduction ride in gsl_lora_grad_batch (bf16 MFMA form: 256-column blocks, 16-byte rows)?"""
+    return (Y.dtype == torch.bfloat16 and U.dtype == torch.bfloat16 and Y.is_cuda and Y.stride(1) == 1 and U.stride(1) == 1
+            and Y.shape[1] % 256 == 0 and Y.stride(0) % 8 == 0 and U.stride(0) % 8 == 0 and U.stride(0) >= 16 and 1 <= r <= 16
+            and Y.data_ptr() % 16 == 0 and U.data_ptr() % 16 == 0)
+
+
+def lora_grad_batch(entries):
+    """entries: [(Y, U, G, gsn, gsj, r, accumulate)] as for lora_grad — all of them in two launches (gsl_lora_grad_batch). The
+    descriptors travel in the kernel arguments: nothing to keep alive on the host, HIP-graph capture friendly."""
+    if not entries:
+        return
+    assert ctypes.sizeof(_LgradDesc) == 72
+    arr = (_LgradDesc * len(entries))()
+    for k, (Y, U, G, gsn, gsj, r, acc) in enumerate(entries):
+        arr[k] = _LgradDesc(Y.data_ptr(), Y.stride(0), U.data_ptr(), U.stride(0), Y.shape[0], Y.shape[1], r, 1 if acc else 0, 0,
+                            G.data_ptr(), gsn, gsj)
+    lib = L.load()
+    need = lib.gsl_lora_grad_batch_ws_elems(arr, len(entries))
+    if need < 0:
+        L.check(int(need), "gsl_lora_grad_batch_ws_elems")
+    dev = entries[0][0].device
+    key = (dev.index,)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _ws_retired.append(ws)      # a captured HIP graph may still launch with the old workspace: never free it
+        ws = torch.empty(max(need, 1 << 22), device=dev, dtype=torch.float32)
+        _ws_cache[key] = ws
+    L.check(lib.gsl_lora_grad_batch(arr, len(entries), _p(ws), _stream()), "gsl_lora_grad_batch")
 
 
 def loss_combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):

@@ -42,6 +42,10 @@ GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
 # rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
 INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
+# rows below which the LoRA-gradient reductions of a backward pass are collected and issued as ONE batched pair of launches
+# (gsl_lora_grad_batch) instead of two to three launches each: the launch-bound regime (few-shot batches: 24 reductions, 48 launches).
+# Above it the reductions stay where their operands are produced (most ride in the FFN2-dX epilogue; operands are freed early).
+LGRAD_BATCH_MAX_ROWS = int(os.environ.get("GSLORA_LGRAD_BATCH_MAX_ROWS", "8192"))
 # bf16 stream: the LayerNorm in front of the FFN also emits the FFN1 adapter's down-projection u1 = s * LN(x) A1^T (gsl_layernorm_fwd_lora)
 # instead of a skinny GEMM that re-reads LN(x). Measured time-neutral (profiles/r03_notes.md): off by default, GSLORA_LN_LORA=1 selects it.
 LN_LORA = os.environ.get("GSLORA_LN_LORA", "0") != "0"
@@ -502,6 +506,18 @@ class ViTRunner:
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()     # rows b*T of a [B*T, w] tensor
         # (the 8-bit GELU' code tensor is slab-major [w/64][rows][64]: its cls rows, again slab-major for B rows)
         gp_rows = lambda t, w: (t.view(w // 64, B, T, 64)[:, :, 0].contiguous().view(B, w) if t.dtype == torch.uint8 else cls_rows(t, w))
+        pending = []      # deferred LoRA-gradient reductions (launch-bound regime): (Y, U, G, gsn, gsj, r, accumulate), operands kept alive
+
+        def lgrad(Y, U, G, gsn, gsj, rr):
+            if Y.shape[0] < LGRAD_BATCH_MAX_ROWS and B * T < LGRAD_BATCH_MAX_ROWS and ops.lora_grad_batchable(Y, U, rr):
+                pending.append((Y, U, G, gsn, gsj, rr, True))
+            else:
+                ops.lora_grad(Y, U, G, gsn, gsj, rr)
+
+        def flush():
+            ops.lora_grad_batch(pending)
+            pending.clear()
+
         for i in reversed(range(nl)):
             st = saved["layers"][i]
             blk = blocks[i]
@@ -539,9 +555,9 @@ class ViTRunner:
                 ops.gemm_nt(dyb, self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows", dt), v2, alpha=s_lora)
                 ops.gemm_nt(dyb, self.wT(f"w2_{i}", l2.weight, dt), da, epilogue=epi_mul, A2=v2,
                             W2=self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols", dt), aux=gp, p_drop=p_drop)
-            ops.lora_grad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                # dB2[c, j]
+            lgrad(dyb, u2, gv[id(l2.lora_B)], r, 1, r)                        # dB2[c, j]
             if not fused_grads:
-                ops.lora_grad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)            # dA2[j, hid]
+                lgrad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)                    # dA2[j, hid]
             v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             dxn2 = None
             if ink and i > 0:   # v1 = s*da*B1 is produced inside the FFN1-dX GEMM
@@ -551,11 +567,13 @@ class ViTRunner:
             else:
                 ops.gemm_nt(da, self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows", dt), v1, alpha=s_lora)
             if not fused_grads:
-                ops.lora_grad(da, u1, gv[id(l1.lora_B)], r, 1, r)             # dB1[hid, j]
-            ops.lora_grad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                # dA1[j, c]
+                lgrad(da, u1, gv[id(l1.lora_B)], r, 1, r)                     # dB1[hid, j]
+            lgrad(xn2, v1, gv[id(l1.lora_A)], 1, D, r)                        # dA1[j, c]
             if self.grad_hook is not None:
+                flush()      # the hook hands finished gradient slices to the all-reduce
                 self.grad_hook(i)
             if i == 0:
+                flush()
                 break   # nothing below the layer-0 FFN input is trainable
             if dxn2 is None:
                 dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)

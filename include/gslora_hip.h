@@ -166,6 +166,15 @@ GSL_API int gsl_attention_bwd_cls(const void* qkv, const void* q_cls, const void
 GSL_API long gsl_lora_grad_ws_elems(int M, int N, int r);
 GSL_API int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj,
                   int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
+/* The same for n reductions in two launches per 24 descriptors (the launch-bound regime: a few-shot step runs 24 of them). bf16 operands
+ * only, N % 256 == 0, 16-byte aligned rows; any M >= 1. `descs` is a HOST array — the launches carry the descriptors by value, so a captured
+ * HIP graph keeps them. The G of one call must not overlap. ws: gsl_lora_grad_batch_ws_elems(descs, n) floats (-1: invalid descriptor). */
+typedef struct gsl_lgrad_desc {
+  const void* Y; long ldy; const void* U; int ldu; int M; int N; int r; int accumulate; int pad_; float* G; long gsn, gsj;
+} gsl_lgrad_desc;
+GSL_API long gsl_lora_grad_batch_ws_elems(const gsl_lgrad_desc* descs, int n);
+GSL_API int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, gsl_stream_t s);
+
 
 /* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35).
  * linear_head != 0 selects the ViT-B/16 path instead (modified_VIT.py:32-38): logits = emb * W^T + head_bias, with Wn = W

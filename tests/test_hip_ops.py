@@ -952,3 +952,37 @@ def test_layernorm_fwd_with_lora_down_projection(ops, M, D, r):
     u_ref = alpha * (y.float() @ P[:16].float().t())                 # from the bf16 rows the kernel itself wrote
     assert (u[:, :16].float() - u_ref).abs().max() <= u_ref.abs().max() * 2.0 ** -8 + 1e-6
     assert (u.float() - u0.float()).abs().max() < 2e-2 * max(1.0, u0.float().abs().max().item())
+
+
+def test_lora_grad_batch_equals_the_single_reductions(ops):
+    """gsl_lora_grad_batch: a backward pass's LoRA-gradient reductions in two launches (descriptors by value in the kernel arguments)
+    against one gsl_lora_grad per reduction and torch fp32. Shapes of a few-shot step: dense rows, the 8 cls rows of the last block, both
+    output strides, r = 8 and 16, accumulate on and off, column blocks of wider tensors."""
+    dt = torch.bfloat16
+    cases = [(1576, 512, 8, True), (1576, 2048, 8, True), (8, 512, 8, True), (8, 2048, 8, False), (700, 768, 16, True), (33, 256, 4, False),
+             (5000, 512, 8, True)]
+    ents, single, refs = [], [], []
+    for k, (M, N, r, acc) in enumerate(cases):
+        Yw = rnd(M, N + 256, seed=10 + k).to(dt).cuda()
+        Y = Yw[:, 256:] if k % 2 else Yw[:, :N]                      # a column block of a wider tensor
+        U = torch.zeros(M, 64, dtype=dt, device="cuda"); U[:, :r] = rnd(M, r, seed=40 + k).to(dt).cuda()
+        g0 = rnd(N * r, seed=70 + k).cuda()
+        gsn, gsj = (r, 1) if k % 3 else (1, N)
+        G1, G2 = g0.clone(), g0.clone()
+        ents.append((Y, U, G1, gsn, gsj, r, acc))
+        single.append((Y, U, G2, gsn, gsj, r, acc))
+        want = Y.float().t() @ U[:, :r].float()                       # [N, r]
+        want = want.reshape(-1) if (gsn, gsj) == (r, 1) else want.t().reshape(-1)
+        refs.append(want + (g0 if acc else 0))
+    assert all(ops.lora_grad_batchable(e[0], e[1], e[5]) for e in ents)
+    ops.lora_grad_batch(ents)
+    for (Y, U, G, gsn, gsj, r, acc) in single:
+        ops.lora_grad(Y, U, G, gsn, gsj, r, accumulate=acc)
+    for k, (e, s1, ref) in enumerate(zip(ents, single, refs)):
+        scale = ref.abs().max().item()
+        assert (e[2] - ref).abs().max().item() < 2e-5 * max(1.0, scale) * cases[k][0] ** 0.5, k
+        assert (e[2] - s1[2]).abs().max().item() < 1e-5 * max(1.0, scale), k      # same partials, at most a different summation order
+    # more descriptors than one launch carries (24)
+    many = [(ents[0][0], ents[0][1], torch.zeros(512 * 8, device="cuda"), 8, 1, 8, False) for _ in range(30)]
+    ops.lora_grad_batch(many)
+    assert all(torch.equal(m[2], many[0][2]) for m in many) and many[0][2].abs().max() > 0
