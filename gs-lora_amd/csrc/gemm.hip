@@ -816,19 +816,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
     }
 }
 
+// operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
+// up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+struct LoraInk {
+  const bf16_t* P; int ldp;
+  const bf16_t* Q; int ldq;
+  float s;
+  bf16_t* tout; int ldt;
+};
+
 // ------------------------------------------------------------------ bf16 MFMA kernel, 64x64 tile, 4-stage LDS-DMA ring: few rows
 // The launch-bound regime (few-shot batches: M = 1 576 rows; the cls-row tail of the last block: M = batch) has too few 128x128 tiles
 // to occupy the chip — M = 1 576, N = 512 are 52 workgroups, and their K = 2048 loop then runs tile after tile with two barriers
 // each: 32 us where the vendor library needs 11 (tools/probes/small_m_gemm.py). Here: 64x64 tiles (4x the workgroups), four waves
 // (2 x 2, 32x32 each), BK = 64, a ring of four 16 KB stages with the LDS-DMA running three K tiles ahead, counted vmcnt and ONE raw
 // barrier per K tile. Same swizzle / fragment layout / epilogues as the kernels above (fragment-path stores: the outputs are small).
-constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, NSTS = 4;
-template <int EPI>
+// LORA = true: the in-kernel LoRA form of the 8-phase kernel on this tile — out = epilogue(A W^T + t Q^T) with t = s * A P^T computed
+// here: the 16 rows of P ride along in every stage (one more DMA instruction for waves 0 and 1), wave (wm, wn) owns the row fragment
+// wm * 32 + wn * 16 of t (two extra MFMAs per K tile), and the rank-r update is one more k-step from LDS at the end. In the launch-bound
+// regime this removes the separate skinny GEMM (K = 2048: 12 us on 25 workgroups) per adapted layer and direction.
+constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, STSL = (BMS + BNS + 16) * BK, NSTS = 4;
+template <int EPI, bool LORA = false>
 __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
-                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
   resolve_drop(e.drop);
+  constexpr int STS = LORA ? STSL : ::STS;
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTS * STS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -851,9 +865,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
       __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BMS * BK + rb * 8 * BK), 16, 0, 0);
     }
+    if constexpr (LORA) {
+      if (wave < 2) {
+        const int row = wave * 8 + lrow, c = lc ^ (row & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(lk.P + (size_t)row * lk.ldp + k0 + c * 8),
+                                         (lptr_t)(st + (BMS + BNS) * BK + wave * 8 * BK), 16, 0, 0);
+      }
+    }
   };
 
   f32x4_t acc[2][2];
+  f32x4_t accp = f32x4_t{0.f, 0.f, 0.f, 0.f};      // LORA: t[row wm*32 + wn*16 + fr][j = fc*4 + reg]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -874,9 +896,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
   if (nk > 2) issue(2);
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = min(NSTS - 2, nk - 1 - kt);      // K tiles that may still be in flight behind tile kt
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LORA && wave < 2) {                             // five DMA instructions per K tile for the two waves that also fetch P
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
     if (kt + 3 < nk) issue(kt + 3);    // overwrites the stage of tile kt - 1
     const bf16_t* st = smem + (kt % NSTS) * STS;
@@ -888,6 +916,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
         af[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i][ks]);
         wf[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + boff[i][ks]);
       }
+    if constexpr (LORA) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // the wave's own row fragment of A, read again from LDS: selecting af[wn] at run time would index a register array (scratch)
+        const int rt = wm * 32 + wn * 16 + fr;
+        const bf16x8_t ta = *reinterpret_cast<const bf16x8_t*>(st + rt * BK + (((ks * 4 + fc) ^ (rt & 7)) << 3));
+        const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(st + (BMS + BNS) * BK + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
+        accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ta, accp, 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -895,6 +933,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+  }
+  if constexpr (LORA) {
+    // t -> LDS [64][32] bf16 (columns 16..31 zero), stored once (N-tile 0) for the gradient reductions, then the rank-r update
+    __builtin_amdgcn_s_barrier();                      // the stages are free
+    bf16_t* tbuf = smem;
+    {
+      bf16_t* d = tbuf + (wm * 32 + wn * 16 + fr) * 32 + fc * 4;
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[0], lk.s * accp[1]), pack2bf(lk.s * accp[2], lk.s * accp[3]));
+      *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (n0 == 0 && lk.tout) {                          // 64 rows x 64 columns = 512 16-byte pieces, two per thread
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int piece = tid * 2 + q, row = piece >> 3, c = piece & 7;
+        if (m0 + row < e.M) {
+          const uint4 v = c < 2 ? *reinterpret_cast<const uint4*>(tbuf + row * 32 + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(lk.tout + (size_t)(m0 + row) * lk.ldt + c * 8) = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = min(n0 + wn * 32 + j * 16 + fr, e.N - 1);
+      const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 32 + i * 16 + fr) * 32 + fc * 8);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, tf, acc[i][j], 0, 0, 0);
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1020,12 +1089,6 @@ constexpr int BM4 = 256, BN4 = 256, ST4 = (BM4 + BN4) * BK;
 #include "gemm_dev_a.inc"
 #endif
 
-struct LoraInk {
-  const bf16_t* P; int ldp;
-  const bf16_t* Q; int ldq;
-  float s;
-  bf16_t* tout; int ldt;
-};
 constexpr int ST4L = (BM4 + BN4 + 16) * BK;
 
 // ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 8-phase ping-pong schedule
@@ -1583,7 +1646,8 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else if (variant == 12) {
-      GSL_LAUNCH((gemm_bf16_small_kernel<EPI>), ((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS), 256);
+      hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
     } else {
       GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
     }
@@ -1679,9 +1743,17 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
 #else
 #define GSL_LL_DEV(EPIV)
 #endif
+  // few rows (the launch-bound regime): the 64x64 ring kernel, same rule as gsl_gemm_nt's tile choice
+  const long tiles256 = (long)nb, nblk128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const bool small = (M < 1024 || tiles256 < 128) && nblk128 <= 256;
 #define GSL_LL(EPIV)                                                                                                              \
   do {                                                                                                                            \
     GSL_LL_DEV(EPIV)                                                                                                              \
+    if (small) {                                                                                                                  \
+      hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \
+                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
+      break;                                                                                                                      \
+    }                                                                                                                             \
     e.mrev = mrev_for(16 + EPIV);                                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPIV, true>), dim3(nb), dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)W,     \
                        ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e);                                    \

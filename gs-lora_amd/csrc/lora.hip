@@ -478,13 +478,19 @@ __global__ void gnorm_final_kernel(const float* __restrict__ partial, const int3
 
 static int lgb_plan(const gsl_lgrad_desc* descs, int n, LgbArgs* out, long* ws_elems, int* nwg, int* nrb) {
   long ws = 0; int wg = 0, rb = 0;
+  // row splits: the launch as a whole should fill the chip about four times over (1024 workgroups), not every entry on its own
+  long sum_bx = 0;
+  for (int k = 0; k < n; ++k) sum_bx += descs[k].N > 0 ? descs[k].N / LGM_CN : 0;
+  const int split_target = (int)max(1L, min(32L, 1024 / max(1L, sum_bx)));
   for (int k = 0; k < n; ++k) {
     const gsl_lgrad_desc& d = descs[k];
     GSL_CHECK_ARG(d.Y && d.U && d.G && d.M > 0 && d.N > 0 && d.ldy >= d.N, "null/size");
     GSL_CHECK_ARG(d.r >= 1 && d.r <= 16 && d.ldu >= 16 && (d.ldu % 8) == 0 && (d.ldy % 8) == 0 && (d.N % LGM_CN) == 0, "r in [1,16], ldu >= 16, N % 256 == 0, 16-byte rows");
     GSL_CHECK_ARG((reinterpret_cast<uintptr_t>(d.Y) % 16) == 0 && (reinterpret_cast<uintptr_t>(d.U) % 16) == 0, "16-byte aligned operands");
-    int bx, nsplit, rps;
-    lgm_plan(d.M, d.N, bx, nsplit, rps);
+    const int bx = d.N / LGM_CN, steps = (d.M + LGM_K - 1) / LGM_K;
+    int nsplit = min(steps, split_target);
+    const int rps = ((steps + nsplit - 1) / nsplit) * LGM_K;
+    nsplit = (d.M + rps - 1) / rps;
     const int R = d.r <= 8 ? 8 : 16;
     if (out) {
       LgbEntry& e = out->e[k];

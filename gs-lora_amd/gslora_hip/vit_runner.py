@@ -42,6 +42,7 @@ GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
 # rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
 INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
+INK_SMALL = os.environ.get("GSLORA_INK_SMALL", "1") != "0"      # the in-kernel form on the small-tile kernel (few rows)
 # rows below which the LoRA-gradient reductions of a backward pass are collected and issued as ONE batched pair of launches
 # (gsl_lora_grad_batch) instead of two to three launches each: the launch-bound regime (few-shot batches: 24 reductions, 48 launches).
 # Above it the reductions stay where their operands are produced (most ride in the FFN2-dX epilogue; operands are freed early).
@@ -297,11 +298,20 @@ class ViTRunner:
             z = self._wcache[("zeros", n, dev)] = torch.zeros(n, device=dev, dtype=torch.float32)
         return z
 
-    def lora_in_kernel(self, dtype, rows):
-        """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation). The in-kernel form
-        exists on the 256x256 8-phase kernel only: with few rows (launch-bound batches, the cls-row tail of the last block) its
-        N = 512 GEMMs would run on a handful of workgroups, and the two-launch form on the small-tile kernels wins (INK_MIN_ROWS)."""
-        return dtype == torch.bfloat16 and rows >= INK_MIN_ROWS and self._rank <= 16
+    def lora_in_kernel(self, dtype, rows, N=None):
+        """The bf16 wide GEMMs compute the LoRA down-projection inside the kernel (no extra pass over the activation): on the 256x256
+        8-phase kernel from INK_MIN_ROWS rows on, and on the 64x64 ring kernel wherever gsl_gemm_nt_lora picks it (few rows: the
+        launch-bound regime, where the separate skinny GEMM is a 6 - 12 us launch per adapted layer and direction). In between, the
+        N = 512 GEMMs would run the 8-phase kernel on a handful of workgroups and the two-launch K-segment form wins."""
+        if dtype != torch.bfloat16 or self._rank > 16:
+            return False
+        if rows >= INK_MIN_ROWS:
+            return True
+        if N is None or not INK_SMALL:
+            return False
+        t256 = ((rows + 255) // 256) * ((N + 255) // 256)
+        t128 = ((rows + 127) // 128) * ((N + 127) // 128)
+        return (rows < 1024 or t256 < 128) and t128 <= 256      # the tile rule of gsl_gemm_nt_lora (csrc/gemm.hip)
 
     def ensure_bucket(self, spec=None):
         spec = spec or self.model.hip_spec()
@@ -437,13 +447,13 @@ class ViTRunner:
                             W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                             p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
                 u2 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
-                if not self.lora_in_kernel(dt, Mr):
+                if not self.lora_in_kernel(dt, Mr, D):
                     ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
             else:
                 ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, bias=l1.bias.detach(),
                             out2=gp, p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag)
             x2 = torch.empty(Mr, D, device=img.device, dtype=xdt)
-            if lora_on and self.lora_in_kernel(dt, Mr):
+            if lora_on and self.lora_in_kernel(dt, Mr, D):
                 ops.gemm_nt_lora(h, self.w(f"w2_{i}", l2.weight, dt), self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows16", dt),
                                  self.lora_pack(f"B2_{i}", l2.lora_B, "B_cols32", dt), s_lora, u2, x2, epilogue=epi_res,
                                  bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
@@ -537,11 +547,12 @@ class ViTRunner:
                 dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
             Mrows = dyb.shape[0]
             # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
-            ink = self.lora_in_kernel(dt, Mrows)
+            ink = self.lora_in_kernel(dt, Mrows, mlp)       # FFN2-dX (N = mlp)
+            ink1 = self.lora_in_kernel(dt, Mrows, D)        # FFN1-dX (N = dim)
             epi_mul = L.EPI_MUL_G8 if gp.dtype == torch.uint8 else L.EPI_MUL      # g' as the 8-bit code of the forward (decode scale from p_drop)
             v2 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             da = torch.empty(Mrows, mlp, device=dev, dtype=dt)
-            fused_grads = ink and FUSE_LORA_GRAD
+            fused_grads = ink and FUSE_LORA_GRAD and Mrows >= INK_MIN_ROWS      # the gradient-fused epilogue lives on the 8-phase kernel
             if fused_grads:
                 # v2 = s*dy*B2 is produced inside the dX GEMM, and the two gradient reductions that contract over the rows of its
                 # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
@@ -560,7 +571,7 @@ class ViTRunner:
                 lgrad(h, v2, gv[id(l2.lora_A)], 1, mlp, r)                    # dA2[j, hid]
             v1 = torch.empty(Mrows, PADK, device=dev, dtype=dt)
             dxn2 = None
-            if ink and i > 0:   # v1 = s*da*B1 is produced inside the FFN1-dX GEMM
+            if ink1 and i > 0:   # v1 = s*da*B1 is produced inside the FFN1-dX GEMM
                 dxn2 = torch.empty(Mrows, D, device=dev, dtype=dt)
                 ops.gemm_nt_lora(da, self.wT(f"w1_{i}", l1.weight, dt), self.lora_pack(f"B1_{i}", l1.lora_B, "BT_rows16", dt),
                                  self.lora_pack(f"A1_{i}", l1.lora_A, "AT_cols32", dt), s_lora, v1, dxn2)

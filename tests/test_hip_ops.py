@@ -370,7 +370,9 @@ def test_layernorm_bwd_strided_inplace(ops, dt):
     assert (dxb.float().cpu() - want[:, 0] * keep * 2).abs().max() < tol(dt, 4e-5, 6e-2)
 
 
-@pytest.mark.parametrize("M,N,K,r", [(2100, 512, 2048, 8), (1300, 2048, 512, 8), (1111, 768, 256, 16), (300, 256, 64, 4)])
+# (the first four shapes run on the 64x64 ring kernel, the last two on the 256x256 8-phase kernel: the tile rule of gsl_gemm_nt_lora)
+@pytest.mark.parametrize("M,N,K,r", [(2100, 512, 2048, 8), (1300, 2048, 512, 8), (1111, 768, 256, 16), (300, 256, 64, 4),
+                                     (20000, 512, 1024, 8), (16500, 2048, 512, 16)])
 def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
     """out = epilogue(A W^T + t Q^T), t = s*(A P^T) computed inside the kernel; t is also returned (bf16, padded to 64)."""
     from gslora_hip import _lib as L
@@ -985,4 +987,5 @@ def test_lora_grad_batch_equals_the_single_reductions(ops):
     # more descriptors than one launch carries (24)
     many = [(ents[0][0], ents[0][1], torch.zeros(512 * 8, device="cuda"), 8, 1, 8, False) for _ in range(30)]
     ops.lora_grad_batch(many)
-    assert all(torch.equal(m[2], many[0][2]) for m in many) and many[0][2].abs().max() > 0
+    # (the two launches split the rows differently: same sums up to the f32 summation order)
+    assert all(torch.allclose(m[2], many[0][2], rtol=1e-5, atol=1e-4) for m in many) and many[0][2].abs().max() > 0
