@@ -438,14 +438,22 @@ class ViTRunner:
             epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
             gp = torch.empty(Mr, mlp, device=img.device, dtype=torch.uint8 if gp8 else dt) if save else None
             if lora_on:
-                if ln_u1:
-                    u1 = u1_ln
-                else:
+                if Mr < INK_MIN_ROWS and not ln_u1 and self.lora_in_kernel(dt, Mr, mlp):
+                    # few rows: u1 = s * xn2 A1^T inside the FFN1 GEMM (64x64 ring kernel) instead of a skinny launch in front of it.
+                    # (At full size the K-segment form below is as fast: the 8 N-tiles of a row panel would each recompute u1.)
                     u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
-                    ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
-                ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, A2=u1,
-                            W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
-                            p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
+                    ops.gemm_nt_lora(xn2, self.w(f"w1_{i}", l1.weight, dt), self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows16", dt),
+                                     self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols32", dt), s_lora, u1, h, epilogue=epi_gelu,
+                                     bias=l1.bias.detach(), out2=gp, p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
+                else:
+                    if ln_u1:
+                        u1 = u1_ln
+                    else:
+                        u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
+                        ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
+                    ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, A2=u1,
+                                W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
+                                p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
                 u2 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
                 if not self.lora_in_kernel(dt, Mr, D):
                     ops.gemm_nt(h, self.lora_pack(f"A2_{i}", l2.lora_A, "A_rows", dt), u2, alpha=s_lora)
