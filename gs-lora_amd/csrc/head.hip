@@ -457,3 +457,103 @@ extern "C" int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, co
   return check_launch("gsl_loss_combine");
 }
 
+// =====================================================================================
+// The whole loss section of a single-process step in ONE launch (the launch-bound regime: few-shot batches replay ~20 one-block kernels
+// here — CE rows + sums for the remain and forget rows, prototype KL rows + sums, the scalar tail, and the four backward kernels that
+// turn its five coefficients into dlogits / demb). One workgroup of 16 waves: a wave owns every 16th row; row statistics stay in LDS
+// between the forward and the backward half. Same device functions, same fixed summation orders as the separate kernels
+// (sum_rows_kernel's 256-lane partition included): coefficients and gradients bit-identical to the multi-launch path.
+// rows [0, nr) are the remain batch, [nr, N) the forget batch (engine_cl.py:59-125); N <= GSL_LOSS_TAIL_MAX_ROWS.
+// =====================================================================================
+constexpr int LT_MAX = 256;
+__global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int nr,
+                                                         int C, const float* __restrict__ emb, const float* __restrict__ proto, int D,
+                                                         int Cp, const float* structure, float beta, float BND, float alpha, float w_f,
+                                                         float w_r, float BND_pro, float* out14, float* __restrict__ dlogits,
+                                                         float* __restrict__ demb) {
+  __shared__ float ce_s[LT_MAX], hit_s[LT_MAX], kl_s[LT_MAX], lse_s[LT_MAX], la_s[LT_MAX], lt_s[LT_MAX];
+  __shared__ float sm[16], coef_s[5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nf = N - nr;
+  for (int r = wave; r < N; r += 16) {
+    float mx, lse; int am;
+    row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
+    const int y = (int)labels[r];
+    if (lane == 0) { ce_s[r] = lse - logits[(size_t)r * C + y]; hit_s[r] = (am == y) ? 1.f : 0.f; lse_s[r] = lse; }
+    if (emb) {
+      const long yl = (long)labels[r];
+      if (yl < 0 || yl >= Cp) { if (lane == 0) kl_s[r] = __int_as_float(0x7fc00000); continue; }
+      const float* a = emb + (size_t)r * D;
+      const float* t = proto + (size_t)yl * D;
+      const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
+      float acc = 0.f;
+      for (int d = lane; d < D; d += 64) {
+        const float ltd = t[d] - lt;
+        acc += expf(ltd) * (ltd - (a[d] - la));
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) { kl_s[r] = acc; la_s[r] = la; lt_s[r] = lt; }
+    }
+  }
+  __syncthreads();
+  // the six batch sums, in sum_rows_kernel's order (256 lanes stride the rows, fixed-order combine; the other waves add exact zeros)
+  auto range_sum = [&](const float* v, int base, int n) {
+    float a = 0.f;
+    if (threadIdx.x < 256) for (int r = threadIdx.x; r < n; r += 256) a += v[base + r];
+    return block_sum(a, sm);
+  };
+  const float ce_r = range_sum(ce_s, 0, nr), hit_r = range_sum(hit_s, 0, nr);
+  const float ce_f = range_sum(ce_s, nr, nf), hit_f = range_sum(hit_s, nr, nf);
+  float kl_f = 0.f, kl_r = 0.f;
+  if (emb) { kl_f = range_sum(kl_s, nr, nf); kl_r = range_sum(kl_s, 0, nr); }
+  if (threadIdx.x == 0) {      // gsl_loss_combine, operation for operation
+    const float n_r = (float)nr, n_f = (float)nf;
+    const float loss_remain = ce_r / n_r;
+    const float hinge_f = BND - ce_f / n_f;
+    const float loss_forget = fmaxf(hinge_f, 0.f);
+    const float st = structure ? structure[0] : 0.f;
+    float pro_f = 0.f, pro_r = 0.f, hinge_p = 0.f;
+    if (emb) { hinge_p = BND_pro - kl_f / n_f; pro_f = w_f * fmaxf(hinge_p, 0.f); pro_r = w_r * (kl_r / n_r); }
+    const float tot = loss_forget * beta + loss_remain + st * alpha + (pro_f + pro_r);
+    float* meters = out14 + 1;
+    float* coefs = out14 + 9;
+    out14[0] = tot;
+    meters[0] = beta * loss_forget; meters[1] = loss_remain; meters[2] = tot; meters[3] = alpha * st;
+    meters[4] = hit_f * (100.0f / n_f); meters[5] = hit_r * (100.0f / n_r); meters[7] = pro_r;
+    meters[6] = emb ? pro_f : w_f * fmaxf(BND_pro, 0.f);
+    coef_s[0] = coefs[0] = 1.0f / n_r;
+    coef_s[1] = coefs[1] = hinge_f > 0.f ? -beta / n_f : 0.f;
+    coef_s[2] = coefs[2] = (emb && hinge_p > 0.f) ? -w_f / n_f : 0.f;
+    coef_s[3] = coefs[3] = emb ? w_r / n_r : 0.f;
+    coef_s[4] = coefs[4] = alpha;
+  }
+  __syncthreads();
+  for (int r = wave; r < N; r += 16) {      // gsl_ce_bwd / gsl_proto_kl_bwd with the coefficients above (upstream gradient 1)
+    const float k = coef_s[r < nr ? 0 : 1] * 1.0f;
+    const int y = (int)labels[r];
+    const float lse = lse_s[r];
+    for (int c = lane; c < C; c += 64) dlogits[(size_t)r * C + c] = k * (expf(logits[(size_t)r * C + c] - lse) - (c == y ? 1.f : 0.f));
+    if (emb) {
+      const long yl = (long)labels[r];
+      if (yl < 0 || yl >= Cp) {
+        for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = __int_as_float(0x7fc00000);
+        continue;
+      }
+      const float* a = emb + (size_t)r * D;
+      const float* t = proto + (size_t)yl * D;
+      const float la = la_s[r], lt = lt_s[r];
+      const float kk = coef_s[r < nr ? 3 : 2] * 1.0f;
+      for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = kk * (expf(a[d] - la) - expf(t[d] - lt));
+    }
+  }
+}
+extern "C" int gsl_loss_tail_max_rows(void) { return LT_MAX; }
+extern "C" int gsl_loss_tail(const float* logits, const int64_t* labels, int N, int nr, int C, const float* emb, const float* proto, int D,
+                             int Cp, const float* structure, float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
+                             float* out14, float* dlogits, float* demb, gsl_stream_t s) {
+  GSL_CHECK_ARG(logits && labels && out14 && dlogits && N > 0 && N <= LT_MAX && nr > 0 && nr < N && C > 0, "null/size (0 < nr < N <= 256 rows)");
+  GSL_CHECK_ARG(!emb || (proto && demb && D > 0 && Cp > 0), "prototype term: emb, proto and demb together");
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, labels, N, nr, C, emb, proto, D, Cp, structure, beta, BND,
+                     alpha, w_f, w_r, BND_pro, out14, dlogits, demb);
+  return check_launch("gsl_loss_tail");
+}

@@ -55,6 +55,8 @@ SIGNATURES = {
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gsl_loss_combine": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
     "gsl_loss_combine_pack": [_vp, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "gsl_loss_tail_max_rows": [],
+    "gsl_loss_tail": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
     "gsl_proto_kl_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "gsl_group_norms_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gsl_group_norms_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp],

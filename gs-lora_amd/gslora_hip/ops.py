@@ -299,6 +299,23 @@ def loss_combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f
     return out[0], out[1:9], out[9:14]
 
 
+def loss_tail_max_rows():
+    return int(L.load().gsl_loss_tail_max_rows())
+
+
+def loss_tail(logits, labels, nr, emb, proto, structure, beta, BND, alpha, w_f, w_r, BND_pro):
+    """The loss section of a single-process step in one launch (gsl_loss_tail): -> (total, meters [8], coefs [5], dlogits, demb or None)."""
+    _need(logits, labels, emb, proto, structure)
+    N, C = logits.shape
+    out = torch.empty(14, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits)
+    demb = None if emb is None else torch.empty_like(emb)
+    L.check(L.load().gsl_loss_tail(_p(logits), _p(labels), N, int(nr), C, _p(emb), _p(proto), 0 if emb is None else emb.shape[1],
+                                   0 if proto is None else proto.shape[0], _p(structure), float(beta), float(BND), float(alpha), float(w_f),
+                                   float(w_r), float(BND_pro), _p(out), _p(dlogits), _p(demb), _stream()), "gsl_loss_tail")
+    return out[0], out[1:9], out[9:14], dlogits, demb
+
+
 def loss_combine_pack(pack8, structure, has_proto, beta, BND, alpha, w_f, w_r, BND_pro):
     """Data-parallel scalar tail from the all-reduced 8-float pack -> (total [0-dim], meters [8], coefs [5]) — see gsl_loss_combine_pack."""
     _need(pack8, structure)

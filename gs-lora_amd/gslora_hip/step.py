@@ -8,11 +8,16 @@ batch MEANS, so their global values are all-reduced (one packed 8-float message)
 hinges are evaluated — that keeps the single-GPU / nn.DataParallel semantics of the reference —
 and the flat LoRA gradient bucket (0.94 MiB for ViT-P8S8 r=8) is sum-all-reduced after backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import losses
+from . import losses, ops
+
+# launch-bound batches, one process: the loss section of the step as one launch (gsl_loss_tail). GSLORA_LOSS_TAIL=0: the separate kernels.
+LOSS_TAIL = os.environ.get("GSLORA_LOSS_TAIL", "1") != "0"
 
 
 def _world():
@@ -47,6 +52,8 @@ class HipBackend:
     structure_loss = staticmethod(losses.structure_loss)
     combine = staticmethod(losses.combine)
     combine_pack = staticmethod(losses.combine_pack)
+    loss_tail = staticmethod(ops.loss_tail)
+    loss_tail_max_rows = staticmethod(ops.loss_tail_max_rows)
 
     @staticmethod
     def grad_bucket(net):
@@ -185,6 +192,29 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         out_r, emb_r = model(x_r.float(), y_r)
         out_f, emb_f = model(x_f.float(), y_f)
     n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
+    if (split is not None and LOSS_TAIL and not _dp_active() and hasattr(backend, "loss_tail") and out.dtype == torch.float32
+            and out.is_contiguous() and out.dim() == 2 and 0 < nr < out.shape[0] <= backend.loss_tail_max_rows()
+            and y_all.dtype == torch.int64 and y_all.device == out.device
+            and (not use_prototype or (emb.dtype == torch.float32 and emb.is_contiguous() and proto_table is not None))):
+        # launch-bound batches, one process: the whole loss section — CE / KL rows and sums of both row ranges, hinges, meters, and the
+        # backward down to dlogits / demb — is ONE launch (gsl_loss_tail) instead of ~20; the gradients enter the network's autograd
+        # node directly, the group-lasso node gets its coefficient alpha. Same values as the multi-launch path below, bit for bit.
+        structure = backend.structure_loss(net, group_type, grad_scale=1.0) if use_structure else None
+        total, meters, coefs, dlogits, demb = backend.loss_tail(out.detach(), y_all, nr, emb.detach() if use_prototype else None,
+                                                                proto_table if use_prototype else None,
+                                                                None if structure is None else structure.detach(), beta, BND, alpha,
+                                                                w_f, w_r, BND_pro)
+        optimizer.zero_grad()
+        roots, grads = [out], [dlogits]
+        if use_prototype:
+            roots.append(emb)
+            grads.append(demb)
+        if structure is not None:
+            roots.append(structure)
+            grads.append(coefs[4])
+        torch.autograd.backward(roots, grads)
+        optimizer.step()
+        return meters
     if split is not None:
         ce_r_sum, hit_r, ce_f_sum, hit_f = backend.ce_sum_top1_split(split[0], split[2], split[3])
     elif _plain_ce(criterion):

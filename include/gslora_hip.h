@@ -223,6 +223,16 @@ GSL_API int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, const
  * device. Same outputs as gsl_loss_combine; coefs5 are the derivatives with respect to THIS rank's local sums (= those of the global sums). */
 GSL_API int gsl_loss_combine_pack(const float* pack8, const float* structure, int has_proto, float beta, float BND, float alpha, float w_f,
                           float w_r, float BND_pro, float* total, float* meters8, float* coefs5, gsl_stream_t s);
+/* The loss section of a single-process step in ONE launch (launch-bound batches): per-row CE / top-1 of logits [N,C] and prototype KL of
+ * emb [N,D] against proto [Cp,D] (emb NULL: no prototype term), their sums over the remain rows [0,nr) and the forget rows [nr,N), the scalar
+ * tail of gsl_loss_combine (out14 = total, meters8, coefs5) and the backward of all of it for an upstream gradient of 1: dlogits [N,C],
+ * demb [N,D]. Coefficients and gradients bit-identical to (meters within an ulp of) gsl_ce_fwd + gsl_proto_kl_fwd + gsl_loss_combine + gsl_ce_bwd + gsl_proto_kl_bwd on the two row
+ * ranges. 0 < nr < N <= gsl_loss_tail_max_rows(). structure (nullable): device scalar, the group-lasso value. */
+GSL_API int gsl_loss_tail_max_rows(void);
+GSL_API int gsl_loss_tail(const float* logits, const int64_t* labels, int N, int nr, int C, const float* emb, const float* proto, int D,
+                  int Cp, const float* structure, float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
+                  float* out14, float* dlogits, float* demb, gsl_stream_t s);
+
 
 
 /* ---- K12 group-lasso norms over a flat LoRA buffer (engine_cl.py:349-432, util/cal_norm.py:4-146).

@@ -989,3 +989,35 @@ def test_lora_grad_batch_equals_the_single_reductions(ops):
     ops.lora_grad_batch(many)
     # (the two launches split the rows differently: same sums up to the f32 summation order)
     assert all(torch.allclose(m[2], many[0][2], rtol=1e-5, atol=1e-4) for m in many) and many[0][2].abs().max() > 0
+
+
+@pytest.mark.parametrize("N,nr,C,D,proto,struct", [(8, 4, 100, 512, True, True), (96, 48, 100, 768, True, False), (37, 5, 12, 128, False, True),
+                                                  (256, 255, 100, 512, True, True)])
+def test_loss_tail_equals_the_separate_kernels(ops, N, nr, C, D, proto, struct):
+    """gsl_loss_tail (the loss section of a single-process step in one launch) against gsl_ce_fwd / gsl_proto_kl_fwd / gsl_loss_combine /
+    gsl_ce_bwd / gsl_proto_kl_bwd on the two row ranges: the same meters, bit-identical coefficients and gradients, for active and inactive hinges."""
+    logits = (rnd(N, C, seed=1, scale=3.0)).cuda()
+    labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(2)).cuda()
+    emb = rnd(N, D, seed=3).cuda() if proto else None
+    table = rnd(C, D, seed=4).cuda() if proto else None
+    st = torch.tensor(13.5, device="cuda") if struct else None
+    for BND, BND_pro in ((105.0, 50.0), (0.5, 1e-4)):      # hinges active / inactive
+        hyper = dict(beta=0.15, BND=BND, alpha=1e-2, w_f=0.05, w_r=0.1, BND_pro=BND_pro)
+        total, meters, coefs, dl, de = ops.loss_tail(logits, labels, nr, emb, table, st, **hyper)
+        cr, cf = ops.ce_fwd(logits[:nr], labels[:nr]), ops.ce_fwd(logits[nr:], labels[nr:])
+        kf = ops.proto_kl_fwd(emb[nr:], labels[nr:], table)[0] if proto else None
+        kr = ops.proto_kl_fwd(emb[:nr], labels[:nr], table)[0] if proto else None
+        t0, m0, c0 = ops.loss_combine(cr[0], cf[0], kf, kr, st, cr[1], cf[1], float(nr), float(N - nr), **hyper)
+        # (the scalar tail is compiled twice: an fma contraction may differ in the last bit of the total; coefficients and gradients are exact)
+        assert torch.allclose(total, t0, rtol=3e-7, atol=0) and torch.allclose(meters, m0, rtol=3e-7, atol=0) and torch.equal(coefs, c0)
+        dl0 = torch.empty_like(logits)
+        ops.ce_bwd(logits[:nr], labels[:nr], c0[0:1].contiguous(), 1.0, dlogits=dl0[:nr], accumulate=False)
+        ops.ce_bwd(logits[nr:], labels[nr:], c0[1:2].contiguous(), 1.0, dlogits=dl0[nr:], accumulate=False)
+        assert torch.equal(dl, dl0)
+        if proto:
+            de0 = torch.empty_like(emb)
+            ops.proto_kl_bwd(emb[:nr], labels[:nr], table, c0[3:4].contiguous(), 1.0, demb=de0[:nr], accumulate=False)
+            ops.proto_kl_bwd(emb[nr:], labels[nr:], table, c0[2:3].contiguous(), 1.0, demb=de0[nr:], accumulate=False)
+            assert torch.equal(de, de0)
+        else:
+            assert de is None
