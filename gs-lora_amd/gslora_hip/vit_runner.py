@@ -394,7 +394,7 @@ class ViTRunner:
                 qkv = torch.empty(M, 2 * inner, device=img.device, dtype=dt)
                 ops.gemm_nt(xn, wq[inner:], qkv, bias=None if qb_ is None else qb_[inner:])
                 q_cls = torch.empty(B, inner, device=img.device, dtype=dt)
-                ops.gemm_nt(xn.view(B, T, D)[:, 0].contiguous(), wq[:inner], q_cls, bias=None if qb_ is None else qb_[:inner].contiguous())
+                ops.gemm_nt(xn.view(B, T * D)[:, :D], wq[:inner], q_cls, bias=None if qb_ is None else qb_[:inner].contiguous())      # A = the cls rows, T*D apart
                 hm = 2
             elif attn_site and not blk.qkv_lora.merged:      # q / k / v adapters: one block-diagonal LoRA K segment
                 qkv = torch.empty(M, 3 * inner, device=img.device, dtype=dt)
@@ -480,7 +480,12 @@ class ViTRunner:
             logits, emb, meanh, rstdh = ops.head_fwd(x, B, Th, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, None, 1.0, 0.0,
                                                      head_bias=sp.head_b.detach(), linear=True)
         else:
-            Wn = ops.cosface_prep(sp.head_w.detach().contiguous()) if label is not None else None
+            if label is None:
+                Wn = None
+            elif sp.head_w.requires_grad:
+                Wn = ops.cosface_prep(sp.head_w.detach().contiguous())
+            else:      # frozen head (GS-LoRA trains the adapters only): the row-normalised weight is computed once per weight version
+                Wn = self._cached(self._wcache, ("cosface_wn",), sp.head_w, lambda p: ops.cosface_prep(p.contiguous()))
             logits, emb, meanh, rstdh = ops.head_fwd(x, B, Th, D, hn.weight.detach(), hn.bias.detach(), eps, Wn, label,
                                                      sp.cos_s, sp.cos_m, pool_mean=(sp.pool == "mean"))
         saved = None
