@@ -465,7 +465,23 @@ extern "C" int gsl_loss_combine(const float* ce_r_sum, const float* ce_f_sum, co
 // (sum_rows_kernel's 256-lane partition included): coefficients and gradients bit-identical to the multi-launch path.
 // rows [0, nr) are the remain batch, [nr, N) the forget batch (engine_cl.py:59-125); N <= GSL_LOSS_TAIL_MAX_ROWS.
 // =====================================================================================
-constexpr int LT_MAX = 256;
+constexpr int LT_MAX = 256, LT_V = 16;      // rows per launch; values per lane of a row held in registers (C, D <= 64 * LT_V)
+// a row in registers: element lane + 64 i in v[i] (the lane-strided order of row_softmax_stats / row_lse); every pass over the row then
+// runs from registers — the workgroup is alone on its CU, each global pass would be an exposed L2 round trip
+__device__ __forceinline__ void lt_load(const float* row, int n, int lane, float v[LT_V]) {
+#pragma unroll
+  for (int i = 0; i < LT_V; ++i) { const int c = lane + 64 * i; v[i] = c < n ? row[c] : 0.f; }
+}
+__device__ __forceinline__ float lt_lse(const float v[LT_V], int n, int lane) {      // = row_lse
+  float m = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < LT_V; ++i) if (lane + 64 * i < n) m = fmaxf(m, v[i]);
+  m = wave_max(m);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < LT_V; ++i) if (lane + 64 * i < n) se += expf(v[i] - m);
+  return m + logf(wave_sum(se));
+}
 __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int nr,
                                                          int C, const float* __restrict__ emb, const float* __restrict__ proto, int D,
                                                          int Cp, const float* structure, float beta, float BND, float alpha, float w_f,
@@ -476,20 +492,36 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nf = N - nr;
   for (int r = wave; r < N; r += 16) {
-    float mx, lse; int am;
-    row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
+    float lg[LT_V];
+    lt_load(logits + (size_t)r * C, C, lane, lg);
+    // row_softmax_stats on the registers: max with the first-index tie-break, then the log-sum-exp
+    float m = -3.0e38f; int mi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < LT_V; ++i) { const int c = lane + 64 * i; if (c < C && lg[i] > m) { m = lg[i]; mi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+      if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < LT_V; ++i) if (lane + 64 * i < C) se += expf(lg[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
     const int y = (int)labels[r];
-    if (lane == 0) { ce_s[r] = lse - logits[(size_t)r * C + y]; hit_s[r] = (am == y) ? 1.f : 0.f; lse_s[r] = lse; }
+    if (lane == 0) { ce_s[r] = lse - logits[(size_t)r * C + y]; hit_s[r] = (mi == y) ? 1.f : 0.f; lse_s[r] = lse; }
     if (emb) {
       const long yl = (long)labels[r];
       if (yl < 0 || yl >= Cp) { if (lane == 0) kl_s[r] = __int_as_float(0x7fc00000); continue; }
-      const float* a = emb + (size_t)r * D;
-      const float* t = proto + (size_t)yl * D;
-      const float la = row_lse(a, D, lane), lt = row_lse(t, D, lane);
+      float a[LT_V], t[LT_V];
+      lt_load(emb + (size_t)r * D, D, lane, a);
+      lt_load(proto + (size_t)yl * D, D, lane, t);
+      const float la = lt_lse(a, D, lane), lt = lt_lse(t, D, lane);
       float acc = 0.f;
-      for (int d = lane; d < D; d += 64) {
-        const float ltd = t[d] - lt;
-        acc += expf(ltd) * (ltd - (a[d] - la));
+#pragma unroll
+      for (int i = 0; i < LT_V; ++i) if (lane + 64 * i < D) {
+        const float ltd = t[i] - lt;
+        acc += expf(ltd) * (ltd - (a[i] - la));
       }
       acc = wave_sum(acc);
       if (lane == 0) { kl_s[r] = acc; la_s[r] = la; lt_s[r] = lt; }
@@ -532,18 +564,23 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict
     const float k = coef_s[r < nr ? 0 : 1] * 1.0f;
     const int y = (int)labels[r];
     const float lse = lse_s[r];
-    for (int c = lane; c < C; c += 64) dlogits[(size_t)r * C + c] = k * (expf(logits[(size_t)r * C + c] - lse) - (c == y ? 1.f : 0.f));
+    float lg[LT_V];
+    lt_load(logits + (size_t)r * C, C, lane, lg);
+#pragma unroll
+    for (int i = 0; i < LT_V; ++i) { const int c = lane + 64 * i; if (c < C) dlogits[(size_t)r * C + c] = k * (expf(lg[i] - lse) - (c == y ? 1.f : 0.f)); }
     if (emb) {
       const long yl = (long)labels[r];
       if (yl < 0 || yl >= Cp) {
         for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = __int_as_float(0x7fc00000);
         continue;
       }
-      const float* a = emb + (size_t)r * D;
-      const float* t = proto + (size_t)yl * D;
+      float a[LT_V], t[LT_V];
+      lt_load(emb + (size_t)r * D, D, lane, a);
+      lt_load(proto + (size_t)yl * D, D, lane, t);
       const float la = la_s[r], lt = lt_s[r];
       const float kk = coef_s[r < nr ? 3 : 2] * 1.0f;
-      for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = kk * (expf(a[d] - la) - expf(t[d] - lt));
+#pragma unroll
+      for (int i = 0; i < LT_V; ++i) { const int d = lane + 64 * i; if (d < D) demb[(size_t)r * D + d] = kk * (expf(a[i] - la) - expf(t[i] - lt)); }
     }
   }
 }
@@ -551,7 +588,8 @@ extern "C" int gsl_loss_tail_max_rows(void) { return LT_MAX; }
 extern "C" int gsl_loss_tail(const float* logits, const int64_t* labels, int N, int nr, int C, const float* emb, const float* proto, int D,
                              int Cp, const float* structure, float beta, float BND, float alpha, float w_f, float w_r, float BND_pro,
                              float* out14, float* dlogits, float* demb, gsl_stream_t s) {
-  GSL_CHECK_ARG(logits && labels && out14 && dlogits && N > 0 && N <= LT_MAX && nr > 0 && nr < N && C > 0, "null/size (0 < nr < N <= 256 rows)");
+  GSL_CHECK_ARG(logits && labels && out14 && dlogits && N > 0 && N <= LT_MAX && nr > 0 && nr < N && C > 0 && C <= 64 * LT_V && D <= 64 * LT_V,
+                "null/size (0 < nr < N <= 256 rows, C and D <= 1024)");
   GSL_CHECK_ARG(!emb || (proto && demb && D > 0 && Cp > 0), "prototype term: emb, proto and demb together");
   hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, labels, N, nr, C, emb, proto, D, Cp, structure, beta, BND,
                      alpha, w_f, w_r, BND_pro, out14, dlogits, demb);

@@ -18,6 +18,9 @@ from . import losses, ops
 
 # launch-bound batches, one process: the loss section of the step as one launch (gsl_loss_tail). GSLORA_LOSS_TAIL=0: the separate kernels.
 LOSS_TAIL = os.environ.get("GSLORA_LOSS_TAIL", "1") != "0"
+# rows (remain + forget images) up to which it is used: the one workgroup handles 16 rows at a time (92 us at 96 rows of a 768-wide
+# embedding — no better than the ~19 short launches it replaces; 4+4 images: one pass)
+LOSS_TAIL_ROWS = int(os.environ.get("GSLORA_LOSS_TAIL_ROWS", "32"))
 
 
 def _world():
@@ -193,7 +196,8 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         out_f, emb_f = model(x_f.float(), y_f)
     n_r, n_f = float(x_r.size(0)), float(x_f.size(0))
     if (split is not None and LOSS_TAIL and not _dp_active() and hasattr(backend, "loss_tail") and out.dtype == torch.float32
-            and out.is_contiguous() and out.dim() == 2 and 0 < nr < out.shape[0] <= backend.loss_tail_max_rows()
+            and out.is_contiguous() and out.dim() == 2 and 0 < nr < out.shape[0] <= min(LOSS_TAIL_ROWS, backend.loss_tail_max_rows()) and out.shape[1] <= 1024
+            and (not use_prototype or emb.shape[1] <= 1024)
             and y_all.dtype == torch.int64 and y_all.device == out.device
             and (not use_prototype or (emb.dtype == torch.float32 and emb.is_contiguous() and proto_table is not None))):
         # launch-bound batches, one process: the whole loss section — CE / KL rows and sums of both row ranges, hinges, meters, and the
