@@ -43,10 +43,12 @@ GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
 INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
 INK_SMALL = os.environ.get("GSLORA_INK_SMALL", "1") != "0"      # the in-kernel form on the small-tile kernel (few rows)
-# rows below which the LoRA-gradient reductions of a backward pass are collected and issued as ONE batched pair of launches
-# (gsl_lora_grad_batch) instead of two to three launches each: the launch-bound regime (few-shot batches: 24 reductions, 48 launches).
-# Above it the reductions stay where their operands are produced (most ride in the FFN2-dX epilogue; operands are freed early).
-LGRAD_BATCH_MAX_ROWS = int(os.environ.get("GSLORA_LGRAD_BATCH_MAX_ROWS", "8192"))
+# The LoRA-gradient reductions of a backward pass that do not ride in the FFN2-dX epilogue are collected and issued as ONE batched pair of
+# launches (gsl_lora_grad_batch) instead of two to three launches each; their operands stay alive until the end of the backward (or until
+# the data-parallel hook needs the slice). Measured: few-shot 4+4 1.355 -> 1.155 ms (24 reductions, 48 launches before), ViT-B/16 48+48
+# 11.01 -> 10.64 ms, 512+512 24.83 -> 24.69 ms (+1.2 GB of operands held). GSLORA_LGRAD_BATCH_MAX_ROWS: row count above which the
+# reductions run where their operands are produced instead (0 = always).
+LGRAD_BATCH_MAX_ROWS = int(os.environ.get("GSLORA_LGRAD_BATCH_MAX_ROWS", str(1 << 30)))
 # bf16 stream: the LayerNorm in front of the FFN also emits the FFN1 adapter's down-projection u1 = s * LN(x) A1^T (gsl_layernorm_fwd_lora)
 # instead of a skinny GEMM that re-reads LN(x). Measured time-neutral (profiles/r03_notes.md): off by default, GSLORA_LN_LORA=1 selects it.
 LN_LORA = os.environ.get("GSLORA_LN_LORA", "0") != "0"
