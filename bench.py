@@ -410,6 +410,8 @@ def main():
             "flops_per_image": {"algorithmic_8d": flop_alg, "executed": round(flop_exec)},
             "last_step_meters": {"beta*loss_forget": meters[0], "loss_remain": meters[1], "total": meters[2]},
             "hip_graph": bool(args.graph),
+            "hip_graph_counters": ({"eager_steps": wl.stepper.eager_steps, "captures": wl.stepper.captures, "replays": wl.stepper.replays,
+                                    "failed_keys": len(wl.stepper.failed)} if args.graph and hasattr(wl.stepper, "replays") else None),
             "ms_per_step_events": {"median": round(per_step[len(per_step) // 2], 3), "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
                                    "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
         })
