@@ -818,6 +818,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+#ifndef GSL_P8_AUX_A
+#define GSL_P8_AUX_A 0
+#endif
+#ifndef GSL_P8_AUX_W
+#define GSL_P8_AUX_W 0
+#endif
 struct LoraInk {
   const bf16_t* P; int ldp;
   const bf16_t* Q; int ldq;
@@ -1156,7 +1162,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, 0);
+      // cache policy of the two operand streams (aux: 1 = sc0, 2 = nt, 16 = sc1): measured, profiles/r03_notes.md
+      if constexpr (isA) __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, GSL_P8_AUX_A);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, GSL_P8_AUX_W);
     }
     if constexpr (LORA && PIECE == 0) {
       if (wave < 2) {
