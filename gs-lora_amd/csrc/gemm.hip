@@ -818,6 +818,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+#ifndef GSL_TUPD
+#define GSL_TUPD 0      // 1: fused FFN1 applies its LoRA K segment as a rank-32 update behind the K loop instead of a ninth K tile (measured slower)
+#endif
 #ifndef GSL_P8_AUX_A
 #define GSL_P8_AUX_A 0
 #endif
@@ -1435,6 +1438,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
   }
+  if constexpr (!LORA && epi_is_gelu<EPI>()) {
+    // The LoRA term of the fused FFN1 with t GIVEN (u = s * xn A^T from the skinny GEMM in front, lk.tout [M, >= 32], lk.Q = B [N, >= 32]):
+    // one rank-32 k-step from LDS behind the K loop instead of a ninth K tile of 64 (a whole stage of LDS-DMA and 64 MFMAs per wave for
+    // 8 - 16 live columns). Same products in the same order as the K-segment form (its second k-step multiplies zeros): bit-identical.
+    if (lk.Q) {
+      __builtin_amdgcn_s_barrier();                    // stages are free
+      bf16_t* tbuf = smem;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                    // 256 rows x 32 columns = 1024 16-byte pieces
+        const int piece = tid * 2 + q, row = piece >> 2, c = piece & 3;
+        const int gm = min(m0 + row, e.M - 1);
+        *reinterpret_cast<uint4*>(tbuf + row * 32 + c * 8) = *reinterpret_cast<const uint4*>(lk.tout + (size_t)gm * lk.ldt + c * 8);
+      }
+      bf16x8_t qf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+        qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
   if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_PATCH) {
     if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4 && (EPI != GSL_EPI_PATCH || e.ldo == e.N)) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
@@ -1649,8 +1681,15 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     if (variant == 8) {
       EpiArgs e8 = e;
       e8.mrev = mrev_for(EPI == GSL_EPI_STORE ? (e.N > K1 ? 0 : (e.N < K1 ? 11 : 12)) : EPI);
+      LoraInk lk8{};
+      const bf16_t* a2 = (const bf16_t*)A2; const bf16_t* w2 = (const bf16_t*)W2; int k2 = K2;
+      if (GSL_TUPD && epi_is_gelu<EPI>() && K2 == 64 && A2 && W2 && lda2 >= 32 && ldw2 >= 32 && !e8.krot) {
+        // fused FFN1: the 64-column LoRA K segment (8 - 16 live columns) as a rank-32 update behind the K loop (see the kernel)
+        lk8.Q = w2; lk8.ldq = ldw2; lk8.tout = const_cast<bf16_t*>(a2); lk8.ldt = lda2;
+        a2 = nullptr; w2 = nullptr; k2 = 0;
+      }
       hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e8);
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, a2, lda2, w2, ldw2, k2, lk8, e8);
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else if (variant == 12) {

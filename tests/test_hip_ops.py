@@ -1021,3 +1021,29 @@ def test_loss_tail_equals_the_separate_kernels(ops, N, nr, C, D, proto, struct):
             assert torch.equal(de, de0)
         else:
             assert de is None
+
+
+@pytest.mark.parametrize("r", [8, 16])
+def test_fused_ffn1_rank_update_equals_the_k_segment_form(ops, r):
+    """Fused FFN1 on the 8-phase kernel: a 64-column LoRA K segment is applied as one rank-32 k-step behind the K loop (gemm.hip, GSL_TUPD).
+    The same call with the segment zero-padded to 128 columns takes the K-tile path: both outputs (h and the 8-bit GELU' code) must be
+    bit-identical, and close to torch fp32. (The update form is compiled in with -DGSL_TUPD=1 only: measured slower, profiles/r03_notes.md;
+    with the default build both calls take the K-tile path and the test pins that zero padding changes nothing.)"""
+    from gslora_hip import _lib as L
+    dt = torch.bfloat16
+    M, N, K = 16500, 2048, 512
+    c = lambda t: t.cuda().to(dt)
+    A, W, bias = c(rnd(M, K, seed=1)), c(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3).cuda()
+    u = torch.zeros(M, 128); u[:, :r] = rnd(M, r, seed=4)
+    B = torch.zeros(N, 128); B[:, :r] = rnd(N, r, seed=5, scale=0.3)
+    u, B = c(u), c(B)
+    outs = []
+    for width in (64, 128):
+        h = torch.empty(M, N, device="cuda", dtype=dt); gp = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+        ops.gemm_nt(A, W, h, epilogue=L.EPI_BIAS_GELU_G8, A2=u[:, :width].contiguous(), W2=B[:, :width].contiguous(), bias=bias, out2=gp,
+                    p_drop=0.1, seed=11, site=5)
+        outs.append((h, gp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    keep = ops.dropout_mask(M * N, 0.1, 11, 5, "cuda").view(M, N).float() / 0.9
+    ref = F.gelu(A.float() @ W.float().t() + u.float() @ B.float().t() + bias) * keep
+    assert relerr(outs[0][0].float(), ref) < 1.5e-2
