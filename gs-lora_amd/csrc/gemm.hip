@@ -818,6 +818,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+#ifndef GSL_SMALL_NSTS
+#define GSL_SMALL_NSTS 3      // stages of the 64x64 ring kernel: 3 x 16 KB = three workgroups per CU (4: two; measured, r03_notes.md)
+#endif
 #ifndef GSL_TUPD
 #define GSL_TUPD 0      // 1: fused FFN1 applies its LoRA K segment as a rank-32 update behind the K loop instead of a ninth K tile (measured slower)
 #endif
@@ -838,13 +841,13 @@ struct LoraInk {
 // The launch-bound regime (few-shot batches: M = 1 576 rows; the cls-row tail of the last block: M = batch) has too few 128x128 tiles
 // to occupy the chip — M = 1 576, N = 512 are 52 workgroups, and their K = 2048 loop then runs tile after tile with two barriers
 // each: 32 us where the vendor library needs 11 (tools/probes/small_m_gemm.py). Here: 64x64 tiles (4x the workgroups), four waves
-// (2 x 2, 32x32 each), BK = 64, a ring of four 16 KB stages with the LDS-DMA running three K tiles ahead, counted vmcnt and ONE raw
+// (2 x 2, 32x32 each), BK = 64, a ring of three 16 KB stages (three workgroups per CU) with the LDS-DMA running two K tiles ahead, counted vmcnt and ONE raw
 // barrier per K tile. Same swizzle / fragment layout / epilogues as the kernels above (fragment-path stores: the outputs are small).
 // LORA = true: the in-kernel LoRA form of the 8-phase kernel on this tile — out = epilogue(A W^T + t Q^T) with t = s * A P^T computed
 // here: the 16 rows of P ride along in every stage (one more DMA instruction for waves 0 and 1), wave (wm, wn) owns the row fragment
 // wm * 32 + wn * 16 of t (two extra MFMAs per K tile), and the rank-r update is one more k-step from LDS at the end. In the launch-bound
 // regime this removes the separate skinny GEMM (K = 2048: 12 us on 25 workgroups) per adapted layer and direction.
-constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, STSL = (BMS + BNS + 16) * BK, NSTS = 4;
+constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, STSL = (BMS + BNS + 16) * BK, NSTS = GSL_SMALL_NSTS;
 template <int EPI, bool LORA = false>
 __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
 
   issue(0);
   if (nk > 1) issue(1);
-  if (nk > 2) issue(2);
+  if (NSTS > 3 && nk > 2) issue(2);
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = min(NSTS - 2, nk - 1 - kt);      // K tiles that may still be in flight behind tile kt
     if (LORA && wave < 2) {                             // five DMA instructions per K tile for the two waves that also fetch P
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
-    if (kt + 3 < nk) issue(kt + 3);    // overwrites the stage of tile kt - 1
+    if (kt + NSTS - 1 < nk) issue(kt + NSTS - 1);    // overwrites the stage of tile kt - 1
     const bf16_t* st = smem + (kt % NSTS) * STS;
     bf16x8_t af[2][2], wf[2][2];
 #pragma unroll
