@@ -818,6 +818,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+#ifndef GSL_SMALL_WIDE
+#define GSL_SMALL_WIDE 1      // 64x128 tiles on the ring kernel when the 64x64 grid exceeds the resident workgroups (0: never)
+#endif
 #ifndef GSL_SMALL_NSTS
 #define GSL_SMALL_NSTS 3      // stages of the 64x64 ring kernel: 3 x 16 KB = three workgroups per CU (4: two; measured, r03_notes.md)
 #endif
@@ -847,21 +850,28 @@ struct LoraInk {
 // here: the 16 rows of P ride along in every stage (one more DMA instruction for waves 0 and 1), wave (wm, wn) owns the row fragment
 // wm * 32 + wn * 16 of t (two extra MFMAs per K tile), and the rank-r update is one more k-step from LDS at the end. In the launch-bound
 // regime this removes the separate skinny GEMM (K = 2048: 12 us on 25 workgroups) per adapted layer and direction.
-constexpr int BMS = 64, BNS = 64, STS = (BMS + BNS) * BK, STSL = (BMS + BNS + 16) * BK, NSTS = GSL_SMALL_NSTS;
-template <int EPI, bool LORA = false>
+// NJ = column fragments per wave: 2 = 64x64 tiles, 4 = 64x128 tiles (wide N: M = 1 576, N = 2048 are 800 tiles of 64x64 on 768 resident
+// workgroups — 32 of them start a second round; 400 tiles of 64x128 fit one).
+constexpr int BMS = 64, BNS = 64, NSTS = GSL_SMALL_NSTS;
+#ifndef GSL_SMALL_SLOTS
+#define GSL_SMALL_SLOTS (256L * (NSTS <= 3 ? 3 : 2))      // resident 64x64 workgroups on the chip
+#endif
+constexpr long SMALL_SLOTS = GSL_SMALL_WIDE ? GSL_SMALL_SLOTS : (1L << 40);
+template <int EPI, bool LORA = false, int NJ = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
                                                               const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
   resolve_drop(e.drop);
-  constexpr int STS = LORA ? STSL : ::STS;
+  constexpr int BNT = 32 * NJ;                                   // tile columns
+  constexpr int STS = (BMS + BNT + (LORA ? 16 : 0)) * BK;
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTS * STS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (e.N + BNS - 1) / BNS;
+  const int nbn = (e.N + BNT - 1) / BNT;
   const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int m0 = (tile / nbn) * BMS, n0 = (tile % nbn) * BNS;
+  const int m0 = (tile / nbn) * BMS, n0 = (tile % nbn) * BNT;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
   const int lrow = lane >> 3, lc = lane & 7;
 
@@ -873,68 +883,75 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rb = wave * 2 + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
-      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      const int gm = min(m0 + row, e.M - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 8), (lptr_t)(st + rb * 8 * BK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int rb = wave * NJ + i, row = rb * 8 + lrow, c = lc ^ (row & 7);
+      const int gn = min(n0 + row, e.N - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 8), (lptr_t)(st + BMS * BK + rb * 8 * BK), 16, 0, 0);
     }
     if constexpr (LORA) {
       if (wave < 2) {
         const int row = wave * 8 + lrow, c = lc ^ (row & 7);
         __builtin_amdgcn_global_load_lds((gptr_t)(lk.P + (size_t)row * lk.ldp + k0 + c * 8),
-                                         (lptr_t)(st + (BMS + BNS) * BK + wave * 8 * BK), 16, 0, 0);
+                                         (lptr_t)(st + (BMS + BNT) * BK + wave * 8 * BK), 16, 0, 0);
       }
     }
   };
 
-  f32x4_t acc[2][2];
+  f32x4_t acc[2][NJ];
   f32x4_t accp = f32x4_t{0.f, 0.f, 0.f, 0.f};      // LORA: t[row wm*32 + wn*16 + fr][j = fc*4 + reg]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fc = lane >> 4;
-  int aoff[2][2], boff[2][2];      // fragment read offsets inside a stage (bf16 elements), per k-step
+  int aoff[2][2], boff[NJ][2];      // fragment read offsets inside a stage (bf16 elements), per k-step
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ra = wm * 32 + i * 16 + fr, rb = wn * 32 + i * 16 + fr;
+      const int ra = wm * 32 + i * 16 + fr;
       aoff[i][ks] = ra * BK + (((ks * 4 + fc) ^ (ra & 7)) << 3);
-      boff[i][ks] = BMS * BK + rb * BK + (((ks * 4 + fc) ^ (rb & 7)) << 3);
     }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int rb = wn * 16 * NJ + j * 16 + fr;
+      boff[j][ks] = BMS * BK + rb * BK + (((ks * 4 + fc) ^ (rb & 7)) << 3);
+    }
+  }
 
   issue(0);
   if (nk > 1) issue(1);
   if (NSTS > 3 && nk > 2) issue(2);
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = min(NSTS - 2, nk - 1 - kt);      // K tiles that may still be in flight behind tile kt
-    if (LORA && wave < 2) {                             // five DMA instructions per K tile for the two waves that also fetch P
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // counted wait: 2 + NJ DMA instructions per wave and K tile (+ 1 for the two waves that also fetch P)
+#define GSL_SW(N2, N1) { if (ahead >= 2) asm volatile("s_waitcnt vmcnt(" #N2 ")" ::: "memory"); else if (ahead == 1) asm volatile("s_waitcnt vmcnt(" #N1 ")" ::: "memory"); \
+                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if constexpr (NJ == 2) { if (LORA && wave < 2) GSL_SW(10, 5) else GSL_SW(8, 4) }
+    else { if (LORA && wave < 2) GSL_SW(14, 7) else GSL_SW(12, 6) }
+#undef GSL_SW
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
     if (kt + NSTS - 1 < nk) issue(kt + NSTS - 1);    // overwrites the stage of tile kt - 1
     const bf16_t* st = smem + (kt % NSTS) * STS;
-    bf16x8_t af[2][2], wf[2][2];
+    bf16x8_t af[2][2], wf[NJ][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i][ks]);
-        wf[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + boff[i][ks]);
-      }
+      for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[j][ks] = *reinterpret_cast<const bf16x8_t*>(st + boff[j][ks]);
+    }
     if constexpr (LORA) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         // the wave's own row fragment of A, read again from LDS: selecting af[wn] at run time would index a register array (scratch)
         const int rt = wm * 32 + wn * 16 + fr;
         const bf16x8_t ta = *reinterpret_cast<const bf16x8_t*>(st + rt * BK + (((ks * 4 + fc) ^ (rt & 7)) << 3));
-        const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(st + (BMS + BNS) * BK + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
+        const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(st + (BMS + BNT) * BK + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
         accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ta, accp, 0, 0, 0);
       }
     }
@@ -943,7 +960,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
   }
   if constexpr (LORA) {
@@ -967,8 +984,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = min(n0 + wn * 32 + j * 16 + fr, e.N - 1);
+    for (int j = 0; j < NJ; ++j) {
+      const int n = min(n0 + wn * 16 * NJ + j * 16 + fr, e.N - 1);
       const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -980,9 +997,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4<EPI, bf16_t>(e, m0 + wm * 32 + i * 16 + fr, n0 + wn * 32 + j * 16 + fc * 4, v);
+      epilogue4<EPI, bf16_t>(e, m0 + wm * 32 + i * 16 + fr, n0 + wn * 16 * NJ + j * 16 + fc * 4, v);
     }
 }
 
@@ -1696,8 +1713,13 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else if (variant == 12) {
-      hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+      // more 64x64 tiles than resident workgroups (3 per CU): 64x128 tiles, one round
+      if ((long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) > SMALL_SLOTS)
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 4>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st,
+                           (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+      else
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
+                           (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
     } else {
       GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
     }
@@ -1800,8 +1822,12 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   do {                                                                                                                            \
     GSL_LL_DEV(EPIV)                                                                                                              \
     if (small) {                                                                                                                  \
-      hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \
-                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
+      if ((long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) > SMALL_SLOTS)                                                      \
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 4>), dim3(((M + BMS - 1) / BMS) * ((N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st, \
+                           (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
+      else                                                                                                                        \
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \
+                           (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
       break;                                                                                                                      \
     }                                                                                                                             \
     e.mrev = mrev_for(16 + EPIV);                                                                                                 \
