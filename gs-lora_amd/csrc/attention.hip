@@ -97,8 +97,10 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
 // =====================================================================================
 // forward (bf16)
 // =====================================================================================
-template <int NKT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+// NT = threads per workgroup: 512 (8 waves own two query tiles each), or 1024 when there are fewer (image, head) items than CUs (few-shot
+// batches): 16 waves own one tile each — the item is a latency chain on an otherwise idle CU, half as long with twice the waves.
+template <int NKT, int NT = 512>
+__global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int T, int H, float scale, int abl, int hm) {
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
@@ -535,8 +537,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
 // for key tile NKT - 2 only, and tile NKT - 1 — no valid key / query, probabilities exactly zero — is left out of both phases at
 // compile time (a run-time uniform branch inside the unrolled tile loop makes the compiler sink all exponentials below it and spill
 // the score tiles). Same values in the same order as the generic form: bit-identical.
-template <int NKT, bool FAST>
-__global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+template <int NKT, bool FAST, int NT = 512>      // NT = 1024: sixteen waves, one tile each (fewer items than CUs; see attn_fwd_bf16_kernel)
+__global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                      const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                      bf16_t* __restrict__ dqkv, int T, int H, float scale,
                                                                      unsigned long long* __restrict__ stamps, int hm) {
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_bf16_kernel(const bf16_
   }
   // the K / V fragments of the wave's FIRST key tile come out of the K / V panels that are still in LDS (rows >= T are zero there; such
   // rows are never stored): 8 of the 13 tiles' second read of K and V never leaves the CU (-250 MB per launch at B = 1024)
-  kr = wave * 16 + fr;
+  kr = min(wave * 16 + fr, TP - 1);      // (waves past the last key tile read a valid row and never use it)
   kf[0] = lds_frag_rm(P0, kr, 0, fc); kf[1] = lds_frag_rm(P0, kr, 1, fc);
   vf[0] = lds_frag_rm(P1, kr, 0, fc); vf[1] = lds_frag_rm(P1, kr, 1, fc);
   // (the second tile's fragments — waves 0 .. 4 at T = 197 — stay global loads: holding them across the panel re-staging costs 13
@@ -1131,6 +1133,7 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
       if (T > 192) hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, true>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
       else hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, false>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
     }
+    else if (B * H < attn_num_cus()) hipLaunchKernelGGL((attn_fwd_bf16_kernel<14, 1024>), grid, dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
   } else if (dtype == GSL_F32) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
@@ -1157,7 +1160,11 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
       // (a persistent wave-specialised form like the forward's was measured slower here: 795 vs 736 us at B = 1024 — its four
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       unsigned long long* stp = attn_stamps();
-      if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0));
+      if (B * H < attn_num_cus()) {      // fewer items than CUs: sixteen waves per item
+        if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+        else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+      }
+      else if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0));
       else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
