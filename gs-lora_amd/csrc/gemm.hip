@@ -818,6 +818,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
+#ifndef GSL_SMALL_KSPLIT
+#define GSL_SMALL_KSPLIT 1      // ring kernel: two wave groups split the K tiles when K >= 1024 and the grid is at most one workgroup per CU
+#endif
 #ifndef GSL_SMALL_WIDE
 #define GSL_SMALL_WIDE 1      // 64x128 tiles on the ring kernel when the 64x64 grid exceeds the resident workgroups (0: never)
 #endif
@@ -857,26 +860,35 @@ constexpr int BMS = 64, BNS = 64, NSTS = GSL_SMALL_NSTS;
 #define GSL_SMALL_SLOTS (256L * (NSTS <= 3 ? 3 : 2))      // resident 64x64 workgroups on the chip
 #endif
 constexpr long SMALL_SLOTS = GSL_SMALL_WIDE ? GSL_SMALL_SLOTS : (1L << 40);
-template <int EPI, bool LORA = false, int NJ = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
+// KS = 2: TWO groups of four waves split the K tiles of one output tile between them (group g takes tiles g, g + 2, ...: own stage ring,
+// own accumulators, same barriers) and group 1's accumulators are added to group 0's through LDS at the end, in that fixed order. With
+// at most one workgroup per CU anyway (M = 1 576, N = 512: 200 tiles) the K = 1536 / 2048 loops are a serial latency chain of 24 / 32
+// tile steps: this halves it.
+template <int EPI, bool LORA = false, int NJ = 2, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
                                                               const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
   resolve_drop(e.drop);
   constexpr int BNT = 32 * NJ;                                   // tile columns
   constexpr int STS = (BMS + BNT + (LORA ? 16 : 0)) * BK;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[NSTS * STS];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[KS * NSTS * STS];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KS == 2 ? wave8 >> 2 : 0, wave = wave8 & 3;      // K group, wave inside the group
+  bf16_t* const gsm = smem + grp * (NSTS * STS);                   // this group's stage ring
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + BNT - 1) / BNT;
   const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int m0 = (tile / nbn) * BMS, n0 = (tile % nbn) * BNT;
   const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int nkg = (nk - grp + KS - 1) / KS, nit = (nk + KS - 1) / KS;      // K tiles of this group, loop steps of the workgroup
   const int lrow = lane >> 3, lc = lane & 7;
 
-  auto issue = [&](int kt) {      // 4 DMA instructions per wave and K tile: rows wave*16 .. +15 of the A part and of the W part
-    bf16_t* st = smem + (kt % NSTS) * STS;
+  auto issue = [&](int it) {      // step `it` of this group = K tile it * KS + grp; 2 + NJ DMA instructions per wave
+    if (it >= nkg) return;
+    const int kt = it * KS + grp;
+    bf16_t* st = gsm + (it % NSTS) * STS;
     const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
     if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
     else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
@@ -924,19 +936,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
   }
 
   issue(0);
-  if (nk > 1) issue(1);
-  if (NSTS > 3 && nk > 2) issue(2);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(NSTS - 2, nk - 1 - kt);      // K tiles that may still be in flight behind tile kt
+  issue(1);
+  if (NSTS > 3) issue(2);
+  for (int kt = 0; kt < nit; ++kt) {      // (kt counts this group's steps)
+    const bool live = kt < nkg;             // the last step of an odd tile count belongs to group 0 alone: group 1 only keeps the barrier
+    const int ahead = min(NSTS - 2, nkg - 1 - kt);      // K tiles that may still be in flight behind this step's tile
     // counted wait: 2 + NJ DMA instructions per wave and K tile (+ 1 for the two waves that also fetch P)
 #define GSL_SW(N2, N1) { if (ahead >= 2) asm volatile("s_waitcnt vmcnt(" #N2 ")" ::: "memory"); else if (ahead == 1) asm volatile("s_waitcnt vmcnt(" #N1 ")" ::: "memory"); \
                          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    if constexpr (NJ == 2) { if (LORA && wave < 2) GSL_SW(10, 5) else GSL_SW(8, 4) }
-    else { if (LORA && wave < 2) GSL_SW(14, 7) else GSL_SW(12, 6) }
+    if (live) {
+      if constexpr (NJ == 2) { if (LORA && wave < 2) GSL_SW(10, 5) else GSL_SW(8, 4) }
+      else { if (LORA && wave < 2) GSL_SW(14, 7) else GSL_SW(12, 6) }
+    }
 #undef GSL_SW
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
-    if (kt + NSTS - 1 < nk) issue(kt + NSTS - 1);    // overwrites the stage of tile kt - 1
-    const bf16_t* st = smem + (kt % NSTS) * STS;
+    issue(kt + NSTS - 1);    // overwrites the stage of step kt - 1
+    if (!live) continue;
+    const bf16_t* st = gsm + (kt % NSTS) * STS;
     bf16x8_t af[2][2], wf[NJ][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -963,17 +979,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
   }
+  if constexpr (KS == 2) {      // group 1 hands its accumulators to group 0: f32, [wave][fragment][lane] behind the t buffer, fixed order 0 + 1
+    __builtin_amdgcn_s_barrier();                      // the stages are free
+    float* red = reinterpret_cast<float*>(smem + 64 * 32);
+    float* mine = red + (wave * (2 * NJ + 1)) * 256 + lane * 4;
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(mine + (i * NJ + j) * 256) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if constexpr (LORA) *reinterpret_cast<float4*>(mine + 2 * NJ * 256) = make_float4(accp[0], accp[1], accp[2], accp[3]);
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(mine + (i * NJ + j) * 256);
+          acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+        }
+      if constexpr (LORA) {
+        const float4 v = *reinterpret_cast<const float4*>(mine + 2 * NJ * 256);
+        accp[0] += v.x; accp[1] += v.y; accp[2] += v.z; accp[3] += v.w;
+      }
+    }
+  }
+  const bool lead = grp == 0;      // the group that finishes the tile (barriers below are still taken by every wave)
   if constexpr (LORA) {
     // t -> LDS [64][32] bf16 (columns 16..31 zero), stored once (N-tile 0) for the gradient reductions, then the rank-r update
     __builtin_amdgcn_s_barrier();                      // the stages are free
     bf16_t* tbuf = smem;
-    {
+    if (lead) {
       bf16_t* d = tbuf + (wm * 32 + wn * 16 + fr) * 32 + fc * 4;
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[0], lk.s * accp[1]), pack2bf(lk.s * accp[2], lk.s * accp[3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
     __builtin_amdgcn_s_barrier();
-    if (n0 == 0 && lk.tout) {                          // 64 rows x 64 columns = 512 16-byte pieces, two per thread
+    if (lead && n0 == 0 && lk.tout) {                  // 64 rows x 64 columns = 512 16-byte pieces, two per thread of group 0
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int piece = tid * 2 + q, row = piece >> 3, c = piece & 7;
@@ -983,6 +1026,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
         }
       }
     }
+    if (lead) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n = min(n0 + wn * 16 * NJ + j * 16 + fr, e.N - 1);
@@ -993,7 +1037,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(const bf16_t* __re
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, tf, acc[i][j], 0, 0, 0);
       }
     }
+    }
   }
+  if (!lead) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1717,6 +1763,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       if ((long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) > SMALL_SLOTS)
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 4>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
+      else if (GSL_SMALL_KSPLIT && (K1 + K2) >= 1024 && (long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) <= 256)      // a serial K chain on <= one workgroup per CU
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(512), 0, st,
+                           (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
       else
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
@@ -1824,6 +1873,9 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
     if (small) {                                                                                                                  \
       if ((long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) > SMALL_SLOTS)                                                      \
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 4>), dim3(((M + BMS - 1) / BMS) * ((N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st, \
+                           (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
+      else if (GSL_SMALL_KSPLIT && K >= 1024 && (long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) <= 256)                         \
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(512), 0, st, \
                            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
       else                                                                                                                        \
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \

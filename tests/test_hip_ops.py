@@ -61,7 +61,7 @@ def test_gemm_store_asymmetric(ops, dt):
 # tile choice by shape (bf16): the first four run the 64x64 ring kernel (<= 256 tiles of 128x128), (2600, 2048) the 128x128 kernel,
 # (9000, 64) the 256x128 ring, the 33 490-row shapes the 256x256 8-phase kernel
 # ((1576, 2048, ..): 800 tiles of 64x64 exceed the resident workgroups -> the 64x128 form of the ring kernel)
-@pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64), (1576, 2048, 512, 64),
+@pytest.mark.parametrize("M,N,K1,K2", [(591, 192, 128, 64), (130, 64, 64, 0), (257, 2048, 512, 64), (788, 512, 2048, 64), (1576, 2048, 512, 64), (1576, 512, 1536, 0), (900, 512, 1088, 64),
                                        (2600, 2048, 512, 64), (9000, 64, 512, 0), (33490, 512, 192, 0), (33490, 2048, 512, 64)])
 def test_gemm_epilogues(ops, dt, M, N, K1, K2):
     from gslora_hip import _lib as L
@@ -372,7 +372,7 @@ def test_layernorm_bwd_strided_inplace(ops, dt):
 
 
 # (the first four shapes run on the 64x64 ring kernel, the last two on the 256x256 8-phase kernel: the tile rule of gsl_gemm_nt_lora)
-@pytest.mark.parametrize("M,N,K,r", [(2100, 512, 2048, 8), (1300, 2048, 512, 8), (1111, 768, 256, 16), (300, 256, 64, 4), (1576, 2048, 512, 8), (1600, 3072, 768, 16),
+@pytest.mark.parametrize("M,N,K,r", [(2100, 512, 2048, 8), (1300, 2048, 512, 8), (1111, 768, 256, 16), (300, 256, 64, 4), (1576, 2048, 512, 8), (1600, 3072, 768, 16), (1576, 512, 2048, 8), (700, 768, 3136, 16), (1000, 512, 1088, 8),
                                      (20000, 512, 1024, 8), (16500, 2048, 512, 16)])
 def test_gemm_nt_lora_in_kernel(ops, M, N, K, r):
     """out = epilogue(A W^T + t Q^T), t = s*(A P^T) computed inside the kernel; t is also returned (bf16, padded to 64)."""
