@@ -819,7 +819,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 // operands of the in-kernel LoRA forms: P [16, K] (rows j < r = the adapter's down-projection), Q [N, >= 32] (columns j < r = its
 // up-projection), t = s * A P^T is written to tout [M, ldt >= 64] (zero padded) by the N-tile 0 workgroups
 #ifndef GSL_SMALL_KSPLIT
-#define GSL_SMALL_KSPLIT 1      // ring kernel: two wave groups split the K tiles when K >= 1024 and the grid is at most one workgroup per CU
+#define GSL_SMALL_KSPLIT 1      // ring kernel: two wave groups split the K tiles when K >= GSL_SMALL_KSPLIT_MINK and the grid is at most one workgroup per CU
+#endif
+#ifndef GSL_SMALL_KSPLIT_MINK
+#define GSL_SMALL_KSPLIT_MINK 1024      // (512 is 1.4 % faster on the few-shot step, but FFN1 (N = 2048, K = 512) would then split at 512 rows and not at 1024: the fused two-batch forward must stay bit-identical to two forwards, tests/test_hip_fullsize.py)
 #endif
 #ifndef GSL_SMALL_WIDE
 #define GSL_SMALL_WIDE 1      // 64x128 tiles on the ring kernel when the 64x64 grid exceeds the resident workgroups (0: never)
@@ -1763,7 +1766,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       if ((long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) > SMALL_SLOTS)
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 4>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
-      else if (GSL_SMALL_KSPLIT && (K1 + K2) >= 1024 && (long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) <= 256)      // a serial K chain on <= one workgroup per CU
+      else if (GSL_SMALL_KSPLIT && (K1 + K2) >= GSL_SMALL_KSPLIT_MINK && (long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) <= 256)      // a serial K chain on <= one workgroup per CU
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(512), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
       else
@@ -1874,7 +1877,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
       if ((long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) > SMALL_SLOTS)                                                      \
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 4>), dim3(((M + BMS - 1) / BMS) * ((N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st, \
                            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
-      else if (GSL_SMALL_KSPLIT && K >= 1024 && (long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) <= 256)                         \
+      else if (GSL_SMALL_KSPLIT && K >= GSL_SMALL_KSPLIT_MINK && (long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) <= 256)                         \
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(512), 0, st, \
                            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
       else                                                                                                                        \
