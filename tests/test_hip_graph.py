@@ -226,3 +226,34 @@ def test_alternative_launch_forms_compute_the_same_step(monkeypatch, knob):
     assert torch.allclose(p0, p1, rtol=tol, atol=tol), (p0.tolist(), p1.tolist())
     assert (g0 - g1).abs().max() <= tol * g0.abs().max(), ((g0 - g1).abs().max().item(), g0.abs().max().item())
     assert g0.abs().max() > 0
+
+
+def test_replay_from_caller_filled_static_inputs_equals_replay_with_staging_copies():
+    """GraphedStep.static_inputs(): a caller that writes the batch into the graph's static buffers and passes those buffers back skips the
+    four staging copies of a replay; the steps are bit-identical to the ones that copy."""
+    from gslora_hip.optim import FusedAdamW
+    from gslora_hip.step import GraphedStep
+    cfg, b = recipe.cfg_small2(), 6
+    m1 = build(cfg, "bf16", 0.1)
+    m2 = copy.deepcopy(m1)
+    mk_opt = lambda m: FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    o1, o2 = mk_opt(m1), mk_opt(m2)
+    crit = torch.nn.CrossEntropyLoss()
+    kw = dict(beta=0.15, alpha=1e-2, BND=105.0, use_structure=True, group_type="block")
+    g1, g2 = GraphedStep(m1, o1, crit), GraphedStep(m2, o2, crit)
+    bufs = None
+    for s in range(6):
+        data = batch(cfg, b, s)
+        p1 = g1(*data, **kw)
+        if bufs is None:
+            p2 = g2(*data, **kw)
+            bufs = g2.static_inputs(*data, **kw)          # None until the second sighting has captured the graph
+        else:
+            for dst, src in zip(bufs, data):
+                dst.copy_(src)
+            p2 = g2(*bufs, **kw)
+        assert torch.equal(p1, p2), s
+    assert bufs is not None and g2.replays == 5
+    for (n, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()):
+        if a.requires_grad:
+            assert torch.equal(a, c), n
