@@ -34,6 +34,16 @@ def _dp_active():
     return _world() > 1
 
 
+def _cat_labels(y_r, y_f):
+    """torch.cat((y_r, y_f)) — or, when the two are adjacent views of one buffer (GraphedStep lays its static label buffers out that way),
+    a view over both: one launch less per replayed step."""
+    if (y_r.dim() == 1 and y_f.dim() == 1 and y_r.dtype == y_f.dtype and y_r.device == y_f.device and y_r.is_contiguous() and y_f.is_contiguous()
+            and y_r.untyped_storage().data_ptr() == y_f.untyped_storage().data_ptr()
+            and y_f.storage_offset() == y_r.storage_offset() + y_r.numel()):
+        return y_r.as_strided((y_r.numel() + y_f.numel(),), (1,))
+    return torch.cat((y_r, y_f), 0)
+
+
 def _plain_ce(criterion):
     return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
             and getattr(criterion, "label_smoothing", 0.0) == 0.0 and criterion.ignore_index == -100)
@@ -183,7 +193,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         # every operation of the network is per-sample (no BatchNorm), so one forward over the concatenated batch is
         # arithmetically identical to the reference's two forwards and halves the number of kernel launches / tile tails
         nr = x_r.size(0)
-        y_all = torch.cat((y_r, y_f), 0)
+        y_all = _cat_labels(y_r, y_f)
         # (the HIP model takes the two image batches as a tuple and patchifies each into its row range: no 2 x 77 MB concatenated
         #  copy at batch 512 + 512; any other module gets the concatenated tensor)
         both = (x_r, x_f) if getattr(net, "accepts_batch_tuple", False) and x_r.shape[1:] == x_f.shape[1:] else torch.cat((x_r.float(), x_f.float()), 0)
@@ -413,7 +423,12 @@ class GraphedStep:
 
     def _capture(self, x_r, y_r, x_f, y_f, kw):
         r = self.net.runner()
-        static = [x_r.clone(), y_r.clone(), x_f.clone(), y_f.clone(), None]
+        if y_r.dim() == 1 and y_f.dim() == 1 and y_r.dtype == y_f.dtype:      # one label buffer, two adjacent views (see _cat_labels)
+            y_both = torch.cat((y_r, y_f), 0)
+            y_r_s, y_f_s = y_both[:y_r.numel()], y_both[y_r.numel():]
+        else:
+            y_r_s, y_f_s = y_r.clone(), y_f.clone()
+        static = [x_r.clone(), y_r_s, x_f.clone(), y_f_s, None]
         if self.seed_dev is None:
             self.seed_dev = torch.zeros(1, device=x_r.device, dtype=torch.int64)
         self._seed_val = None
