@@ -821,9 +821,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 #ifndef GSL_SMALL_KSPLIT
 #define GSL_SMALL_KSPLIT 1      // ring kernel: two wave groups split the K tiles when K >= GSL_SMALL_KSPLIT_MINK and the grid is at most one workgroup per CU
 #endif
-#ifndef GSL_SMALL_DEEP
-#define GSL_SMALL_DEEP 0      // 1: deeper rings (4 stages per K group, 6 without K split) when the grid is at most one workgroup per CU (measured 1 % slower)
-#endif
 #ifndef GSL_SMALL_KSPLIT_MINK
 #define GSL_SMALL_KSPLIT_MINK 1024      // (512 is 1.4 % faster on the few-shot step, but FFN1 (N = 2048, K = 512) would then split at 512 rows and not at 1024: the fused two-batch forward must stay bit-identical to two forwards, tests/test_hip_fullsize.py)
 #endif
@@ -859,18 +856,6 @@ struct LoraInk {
 // here: the 16 rows of P ride along in every stage (one more DMA instruction for waves 0 and 1), wave (wm, wn) owns the row fragment
 // wm * 32 + wn * 16 of t (two extra MFMAs per K tile), and the rank-r update is one more k-step from LDS at the end. In the launch-bound
 // regime this removes the separate skinny GEMM (K = 2048: 12 us on 25 workgroups) per adapted layer and direction.
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant: one uniform jump table)
-__device__ __forceinline__ void vm_wait(int n) {
-#define GSL_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n) {
-    GSL_VMC(0) GSL_VMC(1) GSL_VMC(2) GSL_VMC(3) GSL_VMC(4) GSL_VMC(5) GSL_VMC(6) GSL_VMC(7) GSL_VMC(8) GSL_VMC(9) GSL_VMC(10) GSL_VMC(11)
-    GSL_VMC(12) GSL_VMC(13) GSL_VMC(14) GSL_VMC(15) GSL_VMC(16) GSL_VMC(17) GSL_VMC(18) GSL_VMC(19) GSL_VMC(20) GSL_VMC(21) GSL_VMC(22)
-    GSL_VMC(23) GSL_VMC(24) GSL_VMC(25) GSL_VMC(26) GSL_VMC(27) GSL_VMC(28) GSL_VMC(29) GSL_VMC(30) GSL_VMC(31) GSL_VMC(32) GSL_VMC(33)
-    GSL_VMC(34) GSL_VMC(35)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef GSL_VMC
-}
 // NJ = column fragments per wave: 2 = 64x64 tiles, 4 = 64x128 tiles (wide N: M = 1 576, N = 2048 are 800 tiles of 64x64 on 768 resident
 // workgroups — 32 of them start a second round; 400 tiles of 64x128 fit one).
 constexpr int BMS = 64, BNS = 64, NSTS = GSL_SMALL_NSTS;
@@ -882,9 +867,7 @@ constexpr long SMALL_SLOTS = GSL_SMALL_WIDE ? GSL_SMALL_SLOTS : (1L << 40);
 // own accumulators, same barriers) and group 1's accumulators are added to group 0's through LDS at the end, in that fixed order. With
 // at most one workgroup per CU anyway (M = 1 576, N = 512: 200 tiles) the K = 1536 / 2048 loops are a serial latency chain of 24 / 32
 // tile steps: this halves it.
-// NST = stages of a group's ring: 3 by default (48 KB: three workgroups per CU); with at most one workgroup per CU anyway the whole LDS goes
-// into prefetch depth (a step of the serial K chain costs ~ memory latency / (NST - 1)).
-template <int EPI, bool LORA = false, int NJ = 2, int KS = 1, int NST = NSTS>
+template <int EPI, bool LORA = false, int NJ = 2, int KS = 1>
 __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t* __restrict__ A1, int lda1,
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
@@ -892,11 +875,11 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
   resolve_drop(e.drop);
   constexpr int BNT = 32 * NJ;                                   // tile columns
   constexpr int STS = (BMS + BNT + (LORA ? 16 : 0)) * BK;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[KS * NST * STS];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[KS * NSTS * STS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = KS == 2 ? wave8 >> 2 : 0, wave = wave8 & 3;      // K group, wave inside the group
-  bf16_t* const gsm = smem + grp * (NST * STS);                   // this group's stage ring
+  bf16_t* const gsm = smem + grp * (NSTS * STS);                   // this group's stage ring
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (e.N + BNT - 1) / BNT;
   const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -908,7 +891,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
   auto issue = [&](int it) {      // step `it` of this group = K tile it * KS + grp; 2 + NJ DMA instructions per wave
     if (it >= nkg) return;
     const int kt = it * KS + grp;
-    bf16_t* st = gsm + (it % NST) * STS;
+    bf16_t* st = gsm + (it % NSTS) * STS;
     const bf16_t* Ab; const bf16_t* Wb; int lda, ldw, k0;
     if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * BK; }
     else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * BK; }
@@ -955,17 +938,24 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
     }
   }
 
-#pragma unroll
-  for (int p = 0; p < NST - 1; ++p) issue(p);
+  issue(0);
+  issue(1);
+  if (NSTS > 3) issue(2);
   for (int kt = 0; kt < nit; ++kt) {      // (kt counts this group's steps)
     const bool live = kt < nkg;             // the last step of an odd tile count belongs to group 0 alone: group 1 only keeps the barrier
-    const int ahead = min(NST - 2, nkg - 1 - kt);      // K tiles that may still be in flight behind this step's tile
-    // counted wait: `ahead` younger tiles of 2 + NJ DMA instructions per wave (+ 1 for the two waves that also fetch P) may stay in flight
-    if (live) vm_wait(ahead * (2 + NJ + ((LORA && wave < 2) ? 1 : 0)));
+    const int ahead = min(NSTS - 2, nkg - 1 - kt);      // K tiles that may still be in flight behind this step's tile
+    // counted wait: 2 + NJ DMA instructions per wave and K tile (+ 1 for the two waves that also fetch P)
+#define GSL_SW(N2, N1) { if (ahead >= 2) asm volatile("s_waitcnt vmcnt(" #N2 ")" ::: "memory"); else if (ahead == 1) asm volatile("s_waitcnt vmcnt(" #N1 ")" ::: "memory"); \
+                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (live) {
+      if constexpr (NJ == 2) { if (LORA && wave < 2) GSL_SW(10, 5) else GSL_SW(8, 4) }
+      else { if (LORA && wave < 2) GSL_SW(14, 7) else GSL_SW(12, 6) }
+    }
+#undef GSL_SW
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; compute(kt - 1) finished everywhere
-    issue(kt + NST - 1);    // overwrites the stage of step kt - 1
+    issue(kt + NSTS - 1);    // overwrites the stage of step kt - 1
     if (!live) continue;
-    const bf16_t* st = gsm + (kt % NST) * STS;
+    const bf16_t* st = gsm + (kt % NSTS) * STS;
     bf16x8_t af[2][2], wf[NJ][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1777,10 +1767,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 4>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
       else if (GSL_SMALL_KSPLIT && (K1 + K2) >= GSL_SMALL_KSPLIT_MINK && (long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) <= 256)      // a serial K chain on <= one workgroup per CU
-        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2, 2, GSL_SMALL_DEEP ? 4 : NSTS>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(512), 0, st,
-                           (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
-      else if (GSL_SMALL_DEEP && (K1 + K2) >= 512 && (long)((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS) <= 256)      // one workgroup per CU at most: six stages
-        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2, 1, 6>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(512), 0, st,
                            (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e);
       else
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPI, false, 2>), dim3(((e.M + BMS - 1) / BMS) * ((e.N + BNS - 1) / BNS)), dim3(256), 0, st,
@@ -1891,10 +1878,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 4>), dim3(((M + BMS - 1) / BMS) * ((N + 2 * BNS - 1) / (2 * BNS))), dim3(256), 0, st, \
                            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
       else if (GSL_SMALL_KSPLIT && K >= GSL_SMALL_KSPLIT_MINK && (long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) <= 256)                         \
-        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2, 2, GSL_SMALL_DEEP ? 4 : NSTS>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(512), 0, st, \
-                           (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
-      else if (GSL_SMALL_DEEP && K >= 512 && (long)((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS) <= 256)                           \
-        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2, 1, 6>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(512), 0, st, \
                            (const bf16_t*)A, lda, (const bf16_t*)W, ldw, K, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0, 0, lk, e); \
       else                                                                                                                        \
         hipLaunchKernelGGL((gemm_bf16_small_kernel<EPIV, true, 2>), dim3(((M + BMS - 1) / BMS) * ((N + BNS - 1) / BNS)), dim3(256), 0, st, \
