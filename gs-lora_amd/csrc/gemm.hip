@@ -91,6 +91,30 @@ __device__ __forceinline__ void g8_unpack4(uint32_t w, float sq, float g[4]) {
   g[3] = fmaf((float)(w >> 24), sq, o);
 }
 
+// ---- GELU / GELU' of the 8-phase kernel's BIAS_GELU_G8 epilogue as ONE table gather per element (round 4). The epilogue was bound by
+// VALU issue (profiles/r03_h_wg_timeline.md: 30 k cycles per 256x256 tile with the matrix pipe idle; ~27 instructions per element, 14 of
+// them the A&S erf / exp / rcp pair, computed to 1.5e-7 for a value that is stored as bf16 and an 8-bit code). tools/gen_gelu_table.py:
+// entry i = { f32 bits of Phi(a_i) with a 16-bit mantissa | 8-bit GELU'(a_i) code }, a_i = -4.5 + i * 9 / 4095. The workgroup copies the
+// 16 KB table into LDS behind the K-loop stages (16 LDS-DMA pieces in front of the prologue), the epilogue clamps, scales and truncates
+// the pre-activation into a byte address (v_med3, v_fma, v_cvt_u32, v_and), gathers with ds_read_b32, applies the dropout mask to the
+// ENTRY (one v_cndmask for both outputs: a dropped element takes {Phi = 0, code 26}) and multiplies a / (1 - p) with the entry read as a
+// float (the code byte is < 2^-15 relative noise). Error of Phi at the nearest grid point <= phi(0) * 0.0011 = 4.5e-4 (a quarter of the bf16
+// half-ulp of h around a = 0), of GELU' <= 9e-4 + half a code step. profiles/r04_valu_rate.md prices the instruction classes.
+constexpr int GT_N = 4096;                       // entries
+constexpr float GT_R = 4.5f;                     // table range [-R, R]
+constexpr float GT_K4 = 4.0f * (GT_N - 1) / (2.0f * GT_R);      // byte-address scale: 4 / D = 1820
+constexpr float GT_C4 = (GT_R * (GT_N - 1) / (2.0f * GT_R) + 0.5f) * 4.0f;      // (R / D + 1/2) * 4 = 8192
+constexpr uint32_t GT_DROPPED = 0x0000001Au;     // {Phi = 0, code G8_O}
+__device__ __attribute__((aligned(16))) const uint32_t GELU_G8_TAB[GT_N] = {
+#include "gelu_g8_table.inc"
+};
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32p_t;
+// tab_c4 = GT_C4 + LDS byte address of the table (exact in f32: < 2^24)
+__device__ __forceinline__ uint32_t gelu_tab_entry(float a, float tab_c4) {
+  const float t = fmaf(__builtin_amdgcn_fmed3f(a, -GT_R, GT_R), GT_K4, tab_c4);
+  return *(lds_u32p_t)(uintptr_t)(((uint32_t)t) & ~3u);
+}
+
 // ---- epilogue, split in two: the arithmetic on one (row m, 4 consecutive columns n..n+3) fragment, and the store.
 // N % 4 == 0 is enforced by the host wrapper. v = primary output, g = second output (GELU' of BIAS_GELU).
 // bp: the 4 bias values of columns n..n+3 already in registers (the staged epilogues load them once per wave: a per-fragment
@@ -210,9 +234,11 @@ constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-
 // the second output waits in registers and is staged after the first was copied out (half the LDS: two workgroups per CU).
 // bias_lds: this wave's 64 bias values staged in LDS by the caller (the 128-register SEQ kernel cannot afford 16 more VGPRs), or
 // nullptr: the lane's 16 values are loaded into registers once.
-template <int EPI, int NI, bool SEQ, bool FULL>
+template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false>
 __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
-                                                          const float* bias_lds) {
+                                                          const float* bias_lds, uint32_t tab_lds = 0u) {
+  static_assert(!TAB || EPI == GSL_EPI_BIAS_GELU_G8, "the GELU table serves the 8-bit-code epilogue");
+  const float tab_c4 = GT_C4 + (float)tab_lds;
   constexpr int NOUT = epi_is_gelu<EPI>() ? 2 : 1;
   constexpr bool G8 = (EPI == GSL_EPI_BIAS_GELU_G8);      // second output as the 8-bit GELU' code: staged as bytes (80-byte rows: conflict-free
   static_assert(!(G8 && SEQ), "the 8-bit GELU' output is staged beside the first one");      // dword writes), copied out as 64-byte row segments
@@ -264,6 +290,30 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         const int i = ib + ii;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
         const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
+        if constexpr (TAB) {      // (rows / columns outside the matrix run the same arithmetic on finite values and are not copied out)
+          uint32_t ent[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q] += bj[j][q];
+            ent[q] = gelu_tab_entry(v[q], tab_c4);
+          }
+          if (e.drop.thr) {
+            const uint32_t w0 = wbase + ((uint32_t)i * rowstep + (uint32_t)(j * 8) * DROP_PHI);
+            const uint32_t h0 = drop_finish(w0), h1 = drop_finish(w0 + DROP_PHI);
+            ent[0] = ((h0 & 0xffffu) < e.drop.thr) ? GT_DROPPED : ent[0];
+            ent[1] = ((h0 >> 16) < e.drop.thr) ? GT_DROPPED : ent[1];
+            ent[2] = ((h1 & 0xffffu) < e.drop.thr) ? GT_DROPPED : ent[2];
+            ent[3] = ((h1 >> 16) < e.drop.thr) ? GT_DROPPED : ent[3];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (v[q] * e.drop.scale) * __uint_as_float(ent[q]);
+          bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
+          *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          // the four code bytes: v_perm_b32 x 2 + v_or
+          *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) =
+              __builtin_amdgcn_perm(ent[1], ent[0], 0x0c0c0400u) | __builtin_amdgcn_perm(ent[3], ent[2], 0x04000c0cu);
+          continue;
+        }
         if (FULL || (m < e.M && n < e.N)) {
           const uint32_t w0 = wbase + ((uint32_t)i * rowstep + (uint32_t)(j * 8) * DROP_PHI);
           if (bias_lds) {
@@ -333,14 +383,14 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   }
 }
 // tiles completely inside the matrix (all of them when M % 256 == 0, N % 128 == 0) skip every per-fragment bounds test
-template <int EPI, int NI, bool SEQ = false>
+template <int EPI, int NI, bool SEQ = false, bool TAB = false>
 __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
-                                                     const float* bias_lds = nullptr) {
+                                                     const float* bias_lds = nullptr, uint32_t tab_lds = 0u) {
   if constexpr (SEQ) {      // the 128-register kernel: two inlined copies of the epilogue make the allocator spill (measured: 81 VGPRs)
     epilogue_staged_bf16_impl<EPI, NI, SEQ, false>(e, acc, cst, mw, nw, lane, bias_lds);
   } else {
-    if (mw + NI * 16 <= e.M && nw + 64 <= e.N) epilogue_staged_bf16_impl<EPI, NI, SEQ, true>(e, acc, cst, mw, nw, lane, bias_lds);
-    else epilogue_staged_bf16_impl<EPI, NI, SEQ, false>(e, acc, cst, mw, nw, lane, bias_lds);
+    if (mw + NI * 16 <= e.M && nw + 64 <= e.N) epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
+    else epilogue_staged_bf16_impl<EPI, NI, SEQ, false, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
   }
 }
 // MUL epilogue (dX * GELU'): the aux operand is as large as the output. Loading it in fragment layout has the same partial-line
@@ -711,6 +761,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
 }
 constexpr int CST_WAVE = 2 * 64 * CLD;            // bf16 elements of staging per wave (two outputs)
 constexpr int CST_BLOCK8 = 8 * CST_WAVE;          // 8 waves: 147 456 bytes
+constexpr int CST_WAVE_G8 = 64 * CLD + 64 * 80 / 2;  // BIAS_GELU_G8: 64 bf16 rows (144 B) + 64 code rows (80 B) = 14 336 bytes per wave
 
 // bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
 // range of logical tile ids so neighbouring tiles (same A row-panel) share one L2.
@@ -1196,7 +1247,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   constexpr int STG = LORA ? ST4L : ST4;
   static_assert(!GRAD || (LORA && epi_is_mul<EPI>()), "GRAD is the gradient-fused form of the in-kernel-LoRA MUL GEMM");
   static_assert(!GRAD || 2 * STG * 2 <= 8 * GF_WAVE_B, "t16 must lie behind the K-loop stages");
-  constexpr int SMEM_E = GRAD ? GF_BLOCK_B / 2 : ((2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8);
+  // BIAS_GELU_G8: the GELU table (GT_N x 4 B) sits behind the K-loop stages, and the C staging of this epilogue needs 64 x (144 + 80) B per
+  // wave only (bf16 rows + code rows), so the block does not grow: 2 x 64 KB of stages + 16 KB of table = the 144 KB of the other epilogues
+  constexpr bool TAB = (EPI == GSL_EPI_BIAS_GELU_G8);
+  constexpr int CSTW = TAB ? CST_WAVE_G8 : CST_WAVE;
+  constexpr int SMEM_E = GRAD ? GF_BLOCK_B / 2 : (TAB ? 2 * STG + GT_N * 2 : ((2 * STG > CST_BLOCK8) ? 2 * STG : CST_BLOCK8));
+  static_assert(!TAB || 8 * CST_WAVE_G8 <= 2 * STG, "the G8 staging must end before the table");
   __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_E];   // stages, then C staging
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1281,6 +1337,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   constexpr unsigned long long* dbg8 = nullptr;
 #endif
   if (dbg8) dbg8[0] = __builtin_readcyclecounter();
+  if constexpr (TAB) {      // the GELU table: 16 pieces of 1 KB, two per wave, in front of the prologue (retired by its counted wait, seen by every wave behind the K loop's barriers)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(GELU_G8_TAB + piece * 256 + lane * 4), (lptr_t)(smem + 2 * STG + piece * 512), 16, 0, 0);
+    }
+  }
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
   stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
@@ -1562,7 +1625,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
           return;
         }
       }
-      epilogue_staged_bf16<EPI, 8>(e, acc, smem + wave * CST_WAVE, m0 + wm * 128, n0 + wn * 64, lane);
+      epilogue_staged_bf16<EPI, 8, false, TAB>(e, acc, smem + wave * CSTW, m0 + wm * 128, n0 + wn * 64, lane, nullptr,
+                                               (uint32_t)(uintptr_t)(lptr_t)(smem + 2 * STG));
       if (dbg8) dbg8[3] = __builtin_readcyclecounter();
       return;
     }

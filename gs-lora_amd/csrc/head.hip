@@ -275,8 +275,11 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   if (r >= B) return;
   float mx, lse; int am;
   row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
-  const int y = (int)labels[r];
-  if (lane == 0) { rows[2 * r] = lse - logits[(size_t)r * C + y]; rows[2 * r + 1] = (am == y) ? 1.f : 0.f; }
+  // a label outside [0, C) (the reference's CrossEntropyLoss raises): NaN loss, no out-of-bounds read; the deferred meter read stops the run
+  const long yl = (long)labels[r];
+  const bool ok = yl >= 0 && yl < C;
+  const int y = ok ? (int)yl : -1;
+  if (lane == 0) { rows[2 * r] = ok ? lse - logits[(size_t)r * C + y] : __int_as_float(0x7fc00000); rows[2 * r + 1] = (am == y) ? 1.f : 0.f; }
 }
 // deterministic: lane-strided partial sums in a fixed order, fixed-order cross-wave combine
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ rows, float* __restrict__ out, int B, int ncol) {
@@ -304,9 +307,11 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   float mx, lse; int am;
   row_softmax_stats(logits + (size_t)r * C, C, lane, mx, lse, am);
   const float k = coef[0] * scale;
-  const int y = (int)labels[r];
+  const long yl = (long)labels[r];
+  const bool ok = yl >= 0 && yl < C;      // out-of-range label: NaN gradient row (see ce_rows_kernel)
+  const int y = ok ? (int)yl : -1;
   for (int c = lane; c < C; c += 64) {
-    const float g = k * (expf(logits[(size_t)r * C + c] - lse) - (c == y ? 1.f : 0.f));
+    const float g = ok ? k * (expf(logits[(size_t)r * C + c] - lse) - (c == y ? 1.f : 0.f)) : __int_as_float(0x7fc00000);
     float* d = dlogits + (size_t)r * C + c;
     *d = accumulate ? (*d + g) : g;
   }
@@ -508,10 +513,11 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict
     for (int i = 0; i < LT_V; ++i) if (lane + 64 * i < C) se += expf(lg[i] - m);
     se = wave_sum(se);
     const float lse = m + logf(se);
-    const int y = (int)labels[r];
-    if (lane == 0) { ce_s[r] = lse - logits[(size_t)r * C + y]; hit_s[r] = (mi == y) ? 1.f : 0.f; lse_s[r] = lse; }
+    const long yl = (long)labels[r];
+    const bool y_ok = yl >= 0 && yl < C;      // out-of-range label: NaN loss / gradient row, no out-of-bounds read (see ce_rows_kernel)
+    const int y = y_ok ? (int)yl : -1;
+    if (lane == 0) { ce_s[r] = y_ok ? lse - logits[(size_t)r * C + y] : __int_as_float(0x7fc00000); hit_s[r] = (mi == y) ? 1.f : 0.f; lse_s[r] = lse; }
     if (emb) {
-      const long yl = (long)labels[r];
       if (yl < 0 || yl >= Cp) { if (lane == 0) kl_s[r] = __int_as_float(0x7fc00000); continue; }
       float a[LT_V], t[LT_V];
       lt_load(emb + (size_t)r * D, D, lane, a);
@@ -562,14 +568,15 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict
   __syncthreads();
   for (int r = wave; r < N; r += 16) {      // gsl_ce_bwd / gsl_proto_kl_bwd with the coefficients above (upstream gradient 1)
     const float k = coef_s[r < nr ? 0 : 1] * 1.0f;
-    const int y = (int)labels[r];
+    const long yl = (long)labels[r];
+    const bool y_ok = yl >= 0 && yl < C;
+    const int y = y_ok ? (int)yl : -1;
     const float lse = lse_s[r];
     float lg[LT_V];
     lt_load(logits + (size_t)r * C, C, lane, lg);
 #pragma unroll
-    for (int i = 0; i < LT_V; ++i) { const int c = lane + 64 * i; if (c < C) dlogits[(size_t)r * C + c] = k * (expf(lg[i] - lse) - (c == y ? 1.f : 0.f)); }
+    for (int i = 0; i < LT_V; ++i) { const int c = lane + 64 * i; if (c < C) dlogits[(size_t)r * C + c] = y_ok ? k * (expf(lg[i] - lse) - (c == y ? 1.f : 0.f)) : __int_as_float(0x7fc00000); }
     if (emb) {
-      const long yl = (long)labels[r];
       if (yl < 0 || yl >= Cp) {
         for (int d = lane; d < D; d += 64) demb[(size_t)r * D + d] = __int_as_float(0x7fc00000);
         continue;

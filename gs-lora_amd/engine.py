@@ -120,10 +120,11 @@ def evaluate(model, testloader_forget, testloader_remain, device, batch, epoch, 
             _eval_data_cl(m, testloader_open, device, "open", batch)
         forget_drop = forget_acc_before - forget_acc
         Hmean = 2 * forget_drop * remain_acc / (forget_drop + remain_acc)
+        from engine_cl import collective_hmean, save_barrier, save_rank
+        Hmean, highest_H_mean = collective_hmean(Hmean, highest_H_mean, device)      # rank 0's values decide for every rank (the branch holds a barrier)
         if Hmean > highest_H_mean:
             highest_H_mean = Hmean
             net = m.module if cfg["MULTI_GPU"] else m
-            from engine_cl import save_barrier, save_rank
             if save_rank():      # one process per GPU: one writer / pruner of the shared work directory (see engine_cl.evaluate)
                 torch.save(net.state_dict(), os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
                     cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time())))

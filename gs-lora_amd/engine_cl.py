@@ -117,6 +117,21 @@ def save_barrier():
         dist.barrier()
 
 
+def collective_hmean(Hmean: float, highest_H_mean: float, device=None):
+    """The (H-mean, best H-mean so far) pair of evaluate() as ONE pair for the whole process group: rank 0's values are broadcast, so
+    every rank takes the same "new best" branch and returns the same best value. The branch holds a barrier: ranks that disagreed — test
+    loaders sharded by a DistributedSampler, an eval dtype set on some ranks only, a per-rank `highest_H_mean` after a resume — would
+    otherwise hang there or mismatch the next training collective. A single process keeps its own values."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return Hmean, highest_H_mean
+    dev = (device if device is not None else "cuda") if dist.get_backend() == "nccl" else "cpu"
+    pair = torch.tensor([Hmean, highest_H_mean], dtype=torch.float64, device=dev)
+    dist.broadcast(pair, src=0)
+    h, best = pair.tolist()
+    return h, best
+
+
 def evaluate(model, testloader_forget, testloader_remain, device, batch: int, epoch: int, forget_acc_before: float,
              highest_H_mean: float, cfg: dict, optimizer, task_i: str, testloader_open=None):
     """Eval-mode accuracies, H-mean, best-checkpoint save + prune to two (reference :247-315)."""
@@ -130,11 +145,12 @@ def evaluate(model, testloader_forget, testloader_remain, device, batch: int, ep
         eval_data(model, testloader_open, device, "open-{}".format(task_i), batch)
     forget_drop = forget_acc_before - forget_acc
     Hmean = 2 * forget_drop * remain_acc / (forget_drop + remain_acc + 1e-8)
+    Hmean, highest_H_mean = collective_hmean(Hmean, highest_H_mean, device)      # rank 0's values decide for every rank
     if Hmean > highest_H_mean:
         highest_H_mean = Hmean
         net = model.module if cfg["MULTI_GPU"] else model
-        # one process per GPU: every rank evaluates the (replicated) test loaders and reaches the same decision; ONE rank writes and
-        # prunes the shared work directory, the others wait (concurrent writers corrupt the file, the second pruner finds it gone)
+        # one process per GPU: every rank evaluates the (replicated) test loaders; ONE rank writes and prunes the shared work
+        # directory, the others wait (concurrent writers corrupt the file, the second pruner finds it gone)
         if save_rank():
             path = os.path.join(cfg["WORK_PATH"], "Backbone_{}_Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(
                 cfg["BACKBONE_NAME"], epoch + 1, batch + 1, get_time()))

@@ -86,8 +86,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self.state.clear()
         # Flat groups that exist keep their buffers — captured HIP graphs hold the addresses of m / v / step_dev / lr_dev — and take the
         # loaded moments and step count IN PLACE; graph_sync() then brings the device counters in line before the next replay.
+        # A parameter without an entry in the loaded state (an empty or partial checkpoint, e.g. one saved from a fresh optimizer) restarts
+        # from zero moments and step 0, as torch.optim does: reset first, then apply what was loaded.
         for ent in self._flat.values():
             if ent.get("ok"):
+                ent["m"].zero_()
+                ent["v"].zero_()
+                ent["step"] = 0
                 self._apply_loaded(ent)
         for gi in [gi for gi, ent in self._flat.items() if not ent.get("ok")]:
             del self._flat[gi]

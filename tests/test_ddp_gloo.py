@@ -207,3 +207,49 @@ def test_two_ranks_evaluate_into_one_work_directory(tmp_path):
     new = [f for f in files if "_old_" not in f]
     assert len(new) == 2 and any("_Batch_100_" in f for f in new) and any("_Batch_200_" in f for f in new)      # one file per evaluate(), not per rank
     assert len(files) == 2, files          # both engines pruned down to two checkpoints, once
+
+
+def _eval_disagree_worker(rank, world, port, work, ret):
+    sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-lora_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import engine
+    import engine_cl
+    # rank 1 sees other accuracies (a sharded test loader) AND carries a higher best-so-far (a per-rank value after a resume):
+    # on its own it would NOT take the save branch, rank 0 would
+    accs = iter(([40.0, 70.0] if rank == 0 else [90.0, 20.0]) * 8)
+    engine_cl.eval_data = lambda *a, **k: next(accs)
+    engine._eval_data_cl = lambda *a, **k: next(accs)
+    model = nn.Linear(4, 4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    cfg = {"MULTI_GPU": False, "WORK_PATH": work, "BACKBONE_NAME": "VIT"}
+    best = 0.0 if rank == 0 else 99.0
+    h = engine_cl.evaluate(model, None, None, "cpu", batch=99, epoch=0, forget_acc_before=100.0, highest_H_mean=best, cfg=cfg,
+                           optimizer=opt, task_i="0")
+    h2 = engine.evaluate(model, None, None, "cpu", batch=199, epoch=0, forget_acc_before=100.0, highest_H_mean=best, cfg=cfg, optimizer=opt)
+    t = torch.ones(1)
+    dist.all_reduce(t)            # the next collective of the run still lines up
+    ret[rank] = (h, h2, float(t))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_that_disagree_on_the_best_hmean_still_take_one_decision(tmp_path):
+    """the save branch of evaluate() holds a barrier, so the "new best H-mean" decision must be the GROUP's, not each rank's:
+    rank 0's (H-mean, best so far) pair is broadcast. Ranks with different accuracies / different best-so-far values neither hang nor
+    desynchronise, and return the same best value."""
+    work = str(tmp_path)
+    open(os.path.join(work, "config.txt"), "w").write("cfg\n")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_eval_disagree_worker, args=(r, 2, port, work, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    alive = [p.is_alive() for p in procs]
+    [p.terminate() for p in procs if p.is_alive()]
+    assert not any(alive), "a rank hung in evaluate()"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ret[0] == ret[1] and ret[0][0] > 0 and ret[0][2] == 2.0
+    new = [f for f in os.listdir(work) if f.endswith(".pth")]
+    # rank 0 saved once per evaluate(); engine.evaluate prunes at three directory entries (config.txt + two checkpoints): the newer one is left
+    assert len(new) == 1 and "_Batch_200_" in new[0], new

@@ -857,7 +857,8 @@ def _slab(q):
 @pytest.mark.parametrize("M,N,K1,K2,p", [(130, 128, 64, 0, 0.1), (591, 256, 128, 64, 0.0), (788, 2048, 512, 64, 0.1), (33490, 2048, 512, 64, 0.1),
                                          (2600, 2048, 512, 0, 0.25), (33490, 2112, 512, 0, 0.25)])
 def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
-    """GSL_EPI_BIAS_GELU_G8: the first output h is bit-identical to BIAS_GELU's; the second is the 8-bit fixed-point code of
+    """GSL_EPI_BIAS_GELU_G8: the first output h equals BIAS_GELU's (bit for bit on the fragment-path kernels, within the table band on the
+    8-phase kernel); the second is the 8-bit fixed-point code of
     gelu'(a) * keep — q = round(gelu' keep 200 + 26), decoded (q - 26) 0.005 / (1 - p): within half a step (0.0025 / (1 - p)) of the
     bf16 kernel's own f32 value (compared through BIAS_GELU's bf16 output: + its rounding), a dropped element decodes to exactly 0,
     and the code error has no bias. The code tensor is slab-major [N/64][M][64]. Fragment paths (64x64 and 128x128 kernels) and the 8-phase
@@ -875,15 +876,23 @@ def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
     h1 = torch.empty(M, N, device="cuda", dtype=dt); q = torch.full((M, N), 255, device="cuda", dtype=torch.uint8)
     ops.gemm_nt(A1, W1, h0, epilogue=L.EPI_BIAS_GELU, A2=A2, W2=W2, bias=bias, out2=g0, p_drop=p, seed=7, site=5)
     ops.gemm_nt(A1, W1, h1, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q, p_drop=p, seed=7, site=5)
-    assert torch.equal(h0, h1)
+    # h: the fragment-path kernels share BIAS_GELU's arithmetic (bit-identical); the 8-phase kernel (round 4) takes Phi(a) from the 4096-entry
+    # LDS table instead of the A&S erf: |a| * |Phi_tab - Phi| <= max|a phi(a)| * D / 2 = 0.242 * 0.0011 + rounding = 2.8e-4 (x 1 / (1 - p)) on top of
+    # one bf16 rounding of each of the two values compared
+    tab = 2.8e-4 / (1 - p)
+    dh = (h1.float() - h0.float()).abs()
+    assert (dh - 2.0 ** -7 * h0.float().abs()).max() <= tab * 1.05
+    assert (h1 != h0).float().mean() < 0.2          # (most elements still agree bit for bit)
     qs, q = q, _unslab(q)          # the code tensor is slab-major [N/64][M][64]
     assert int(q.max()) <= 252
     dec = (q.float() - 26.0) * (0.005 / (1 - p))
     keep = ops.dropout_mask(M * N, p, 7, 5, "cuda").reshape(M, N).bool() if p > 0 else torch.ones(M, N, device="cuda", dtype=torch.bool)
     assert (q[~keep] == 26).all() and (dec[~keep] == 0).all()
+    assert (h1[~keep] == 0).all()
     err = dec - g0.float()
     half = 0.0025 / (1 - p)
-    assert (err.abs() - 2.0 ** -8 * g0.float().abs()).max() <= half * 1.02
+    gtab = 0.8 * 0.0011 / (1 - p)                   # table path: GELU' at the nearest grid point, |GELU''| <= 0.8, D / 2 = 0.0011
+    assert (err.abs() - 2.0 ** -8 * g0.float().abs()).max() <= (half + gtab) * 1.02
     assert abs(err[keep].mean().item()) < 0.1 * half                       # round-to-nearest: no bias beyond the saturated tails (gelu' -> 0-, 1-)
     # MUL_G8 decodes it: (A W^T) * decode(q) in f32, one bf16 rounding
     acc = torch.empty(M, N, device="cuda", dtype=torch.float32)

@@ -399,6 +399,49 @@ def test_meter_queue_stops_on_non_finite_meters():
     assert q.pending == []
 
 
+def test_fused_adamw_loading_an_empty_state_resets_a_stepped_optimizer_like_torch(monkeypatch):
+    """a checkpoint with an EMPTY (or partial) `state` — e.g. saved from a fresh optimizer — loaded into an optimizer that
+    has already stepped must restart the moments and the step count from zero, as torch.optim.AdamW does; the flat buffers stay where
+    they are (captured graphs hold their addresses)."""
+    from gslora_hip import ops
+    from gslora_hip.optim import FusedAdamW
+
+    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.mul_(1 - lr * wd).addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+    monkeypatch.setattr(ops, "adamw_flat", adamw_flat)
+    torch.manual_seed(3)
+    flat, gflat = torch.randn(24), torch.randn(24)
+    ps = [torch.nn.Parameter(flat[:16].view(4, 4)), torch.nn.Parameter(flat[16:].view(2, 4))]
+    ps[0].grad, ps[1].grad = gflat[:16].view(4, 4), gflat[16:].view(2, 4)
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for rp, p in zip(ref_ps, ps):
+        rp.grad = p.grad.clone()
+    opt, ref = FusedAdamW(ps, lr=1e-2, weight_decay=0.05), torch.optim.AdamW(ref_ps, lr=1e-2, weight_decay=0.05)
+    empty = FusedAdamW(ps, lr=1e-2, weight_decay=0.05).state_dict()      # a fresh optimizer's checkpoint: no per-parameter state
+    assert empty["state"] == {}
+    for _ in range(3):
+        opt.step(); ref.step()
+    ent = opt._flat[0]
+    ptr_m = ent["m"].data_ptr()
+    assert ent["step"] == 3 and float(ent["m"].abs().sum()) > 0
+    opt.load_state_dict(empty)
+    ref.load_state_dict(torch.optim.AdamW(ref_ps, lr=1e-2, weight_decay=0.05).state_dict())
+    assert opt._flat[0] is ent and ent["m"].data_ptr() == ptr_m
+    assert ent["step"] == 0 and float(ent["m"].abs().sum()) == 0.0 and float(ent["v"].abs().sum()) == 0.0
+    opt.step(); ref.step()
+    assert ent["step"] == 1
+    for p, rp in zip(ps, ref_ps):
+        assert torch.allclose(p, rp, atol=1e-6, rtol=1e-6)
+    # partial state: the parameter without an entry restarts from zero moments
+    sd = opt.state_dict()
+    part = {"state": {0: sd["state"][0]}, "param_groups": sd["param_groups"]}
+    opt.step()
+    opt.load_state_dict(part)
+    assert torch.equal(ent["m"][:16], sd["state"][0]["exp_avg"].reshape(-1)) and float(ent["m"][16:].abs().sum()) == 0.0
+
+
 def test_fused_adamw_load_state_dict_keeps_the_buffers_captured_graphs_point_at(monkeypatch):
     """load_state_dict() with live flat buffers copies the loaded moments / step IN PLACE (captured HIP graphs hold the addresses of
     m / v / step_dev / lr_dev), and a state_dict() taken before the next step() still carries the loaded state."""
@@ -433,3 +476,38 @@ def test_fused_adamw_load_state_dict_keeps_the_buffers_captured_graphs_point_at(
     opt2.load_state_dict(other)
     st = opt2.state_dict()["state"]
     assert float(st[0]["step"]) == 7.0 and torch.equal(st[1]["exp_avg"], torch.full((2, 4), -0.5))
+
+
+def test_gelu_table_is_the_generated_one_and_as_accurate_as_declared():
+    """csrc/gelu_g8_table.inc (the LDS table of the fused FFN1 epilogue, GSL_EPI_BIAS_GELU_G8 on the 8-phase kernel) is exactly what
+    tools/gen_gelu_table.py emits, and its entries hold Phi(a_i) / the 8-bit GELU'(a_i) code of the exact-erf GELU (vit_face.py:331) to the
+    declared accuracy: Phi to a 16-bit mantissa, the code = rne(GELU' * 200 + 26); a lookup at the NEAREST grid point is within 4.5e-4 of
+    Phi(a) and within 9e-4 + half a code step of GELU'(a) for every a."""
+    import math
+    import struct
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.call([_sys.executable, os.path.join(root, "tools", "gen_gelu_table.py"), "--check"]) == 0, "regenerate the table"
+    txt = open(os.path.join(root, "gs-lora_amd", "csrc", "gelu_g8_table.inc")).read()
+    words = [int(w.strip().rstrip("u"), 16) for line in txt.splitlines() if not line.startswith("//") for w in line.split(",") if w.strip()]
+    N, R = 4096, 4.5
+    assert len(words) == N and words[0] == 0x1A and words[-1] == 0x3F8000E2
+    d = 2 * R / (N - 1)
+    phi = np.array([struct.unpack("<f", struct.pack("<I", w & 0xFFFFFF00))[0] for w in words])
+    code = np.array([w & 0xFF for w in words])
+    a = -R + d * np.arange(N)
+    Phi = np.array([0.5 * math.erfc(-x / math.sqrt(2)) for x in a])
+    gp = Phi + a * np.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+    assert (np.abs(phi - Phi) <= 2.0 ** -16 * Phi * 1.01)[1:-1].all() and abs(phi[0]) == 0 and phi[-1] == 1.0      # 15 explicit mantissa bits
+    assert np.abs((code - 26) / 200.0 - gp)[1:-1].max() <= 0.0025 + 1e-12 and code.max() <= 252 and code.min() >= 0
+    # the kernel's index: trunc(med3(a, -R, R) * 1820 + 8192) & ~3 -> nearest grid point; scan a fine grid incl. beyond the range
+    x = np.linspace(-6.0, 6.0, 200001).astype(np.float32)
+    t = np.clip(x, -R, R).astype(np.float32) * np.float32(1820.0) + np.float32(8192.0)
+    idx = (t.astype(np.int64) & ~3) // 4
+    assert idx.min() == 0 and idx.max() == N - 1
+    Phix = np.array([0.5 * math.erfc(-float(v) / math.sqrt(2)) for v in x])
+    gpx = Phix + x * np.exp(-0.5 * x.astype(np.float64) ** 2) / math.sqrt(2 * math.pi)
+    assert np.abs(phi[idx] - Phix).max() <= 4.5e-4
+    assert np.abs(x * (phi[idx] - Phix)).max() <= 2.8e-4          # error of h = a * Phi
+    assert np.abs((code[idx] - 26) / 200.0 - gpx).max() <= 0.0025 + 9e-4
