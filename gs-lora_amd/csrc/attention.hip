@@ -90,6 +90,17 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) 
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * mul, v[1] * mul), pack2bf(v[2] * mul, v[3] * mul));
 }
 
+// Item order (round 4): hardware places workgroup w on XCD w % 8, and the tensors o / dO / dqkv are TOKEN-major — the H heads of an image own
+// adjacent 128-byte segments of the same rows. With items in plain (image, head) order the heads of one image are spread over all 8
+// XCDs (8 L2s each see one 128-byte piece of every row). item_remap() hands the 8 consecutive workgroups of ONE XCD the heads of ONE image
+// (B % 8 == 0; otherwise the plain order): rows are then read / written whole by one L2 within a short window.
+// seq = position in dispatch order (blockIdx, or blockIdx + k * gridDim of a persistent kernel with gridDim % 8 == 0)
+__device__ __forceinline__ int item_remap(int seq, int H, int on) {
+  if (!on) return seq;
+  const int x = seq & 7, j = seq >> 3;
+  return ((j / H) * 8 + x) * H + (j % H);
+}
+
 // hm (layout of the qkv INPUT of the bf16 kernels): 0 = token-major [B*T, 3*H*64] (row stride 3*H*64; the three panels of a head are 64
 // columns wide at column offsets h*64, (H+h)*64, (2H+h)*64), 1 = head-major [B][H][3][T][64] (each (image, head) item is one contiguous
 // block of three [T, 64] panels: every panel row is a full 128-byte line next to its neighbours instead of a 128-byte segment every
@@ -199,7 +210,7 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // is empty for every T this kernel accepts (T <= 208) and is not computed at all. Same values, same order: bit-identical.
 template <int NKT, bool FAST>
 __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                                  float* __restrict__ lse, int T, int H, float scale, int nitems, int hm) {
+                                                                  float* __restrict__ lse, int T, int H, float scale, int nitems, int hm, int imap) {
   constexpr int TP = NKT * 16;
   constexpr int NCW = 13;                 // compute waves = query tiles (host: T <= 208)
   constexpr int NST = 9;                  // loader steps per panel: 24 rows x 8 chunks per step, 9 * 24 = 216 >= 208 rows
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
   const long ld = hm ? (long)HD : 3L * H * HD, ko = hm ? (long)T * HD : (long)H * HD;      // row stride / K-panel offset of the qkv input
-  auto item_base = [&](int it) { return qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)(it / H) * T * ld + (it % H) * HD); };
+  auto item_base = [&](int seq) { const int it = item_remap(seq, H, imap); return qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)(it / H) * T * ld + (it % H) * HD); };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fc = lane >> 4;
   // rows >= T of the panels are zero for every item: written once
   for (int idx = threadIdx.x; idx < (TP - T) * 8; idx += 1024) {
@@ -275,7 +286,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
   const float c2 = scale * 1.4426950408889634f;
   const int qr = wave * 16 + fr;
   wg_barrier_lds();
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  for (int seq = blockIdx.x; seq < nitems; seq += gridDim.x) {
+    const int item = item_remap(seq, H, imap);
     const int b = item / H, h = item % H;
     const bf16x8_t qf0 = lds_frag_rm(Qs, qr, 0, fc), qf1 = lds_frag_rm(Qs, qr, 1, fc);
     constexpr int NKV = NKT - 1;          // key tiles that can hold a valid key (host: T <= (NKT - 1) * 16)
@@ -541,7 +553,7 @@ template <int NKT, bool FAST, int NT = 512>      // NT = 1024: sixteen waves, on
 __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                      const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                      bf16_t* __restrict__ dqkv, int T, int H, float scale,
-                                                                     unsigned long long* __restrict__ stamps, int hm) {
+                                                                     unsigned long long* __restrict__ stamps, int hm, int imap) {
   constexpr int TP = NKT * 16;
   // development (GSL_ATTN_STAMPS = device address of 256 x 8 u64): cycle stamps of every 64th workgroup
   unsigned long long* dbg = (stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0) ? stamps + (blockIdx.x / 64) * 8 : nullptr;   // uniform
@@ -551,7 +563,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
   __shared__ __attribute__((aligned(16))) bf16_t P1[TP * KLD];   // phase A: V, phase B: dO
   __shared__ __attribute__((aligned(16))) float lse_s[TP];       // log2 units; padded queries 1e30 -> p = 0
   __shared__ __attribute__((aligned(16))) float del_s[TP];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int item = item_remap(blockIdx.x, H, imap);
+  const int b = item / H, h = item % H;
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const bool nostore = hm & 2;      // development ablation (GSL_ATTN_ABL=4): no output stores
   hm &= 1;
@@ -1126,12 +1139,14 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
   GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
+  // (item_remap for the forward: measured +1 % — 212 -> 215 us at B = 1024 —, so the plain order stays; the backward gains 2.3 %: profiles/r04_notes.md)
+  const int imap = (B % 8 == 0 && attn_num_cus() % 8 == 0) ? attn_env("GSL_ATTN_ITEM_REMAP_FWD", 0) : 0;
   if (dtype == GSL_BF16) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else if (attn_persistent() && T <= 208 && B * H >= 2 * attn_num_cus())
     {
-      if (T > 192) hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, true>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
-      else hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, false>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm);
+      if (T > 192) hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, true>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm, imap);
+      else hipLaunchKernelGGL((attn_fwd_bf16_pers_kernel<14, false>), dim3(attn_num_cus()), dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, B * H, hm, imap);
     }
     else if (B * H < attn_num_cus()) hipLaunchKernelGGL((attn_fwd_bf16_kernel<14, 1024>), grid, dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
@@ -1153,6 +1168,7 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
   if (dtype == GSL_BF16) {
     const bf16_t* q = (const bf16_t*)qkv; const bf16_t* oo = (const bf16_t*)o; const bf16_t* g = (const bf16_t*)d_o;
     bf16_t* dq = (bf16_t*)dqkv;
+    const int imap = (B % 8 == 0) ? attn_env("GSL_ATTN_ITEM_REMAP", 1) : 0;      // heads of an image on one XCD (item_remap)
     if (T <= 64) {
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
       hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 2>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
@@ -1161,11 +1177,11 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       unsigned long long* stp = attn_stamps();
       if (B * H < attn_num_cus()) {      // fewer items than CUs: sixteen waves per item
-        if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
-        else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+        if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);
+        else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);
       }
-      else if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0));
-      else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm);
+      else if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm | (attn_abl() == 4 ? 2 : 0), imap);
+      else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false>), grid, dim3(512), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);
     } else {        // development knob GSL_ATTN_BWD_SPLIT=1: the two-kernel form
       hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<14>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale, attn_abl(), hm);
       {       // measured at B = 1024, T = 197: NT = 1 (two workgroups per CU) 410 us, NT = 2 480 us

@@ -17,44 +17,46 @@ from . import ops
 
 PADK = 64                                  # LoRA K-segment width fed to the GEMM (r zero-padded to 64)
 SITE_EMB = 1_000_000
-# development knob: 0 = the two [M, mlp] LoRA-gradient reductions run as separate gsl_lora_grad launches instead of inside the FFN2-dX epilogue
-FUSE_LORA_GRAD = os.environ.get("GSL_FUSE_LORA_GRAD", "1") != "0"
-# bf16 speed mode carries the residual-GRADIENT stream (the f32 [M, dim] tensor every LayerNorm backward re-reads and re-writes) in bf16:
-# -25 % of the bytes of each LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32 (the parity mode always does).
+# ---- numeric form of the bf16 speed mode: the three PRODUCT knobs (read once from the environment; module attributes, so a caller /
+# tools/precision_ablation.py / the tests can also set them in-process). The f32 parity mode ignores them. README.md documents them.
+# Residual-GRADIENT stream (the [M, dim] tensor every LayerNorm backward re-reads and re-writes) in bf16: -25 % of the bytes of each
+# LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32.
 GRAD_STREAM_BF16 = os.environ.get("GSLORA_GRAD_STREAM", "bf16").lower() != "f32"
-# bf16 speed mode also carries the FORWARD residual stream x (read by every LayerNorm forward, read + written by the out-proj / FFN2
-# epilogues, re-read by every LayerNorm backward) in bf16: f32 accumulate in the producing epilogue, one rounding on store.
-# GSLORA_FWD_STREAM=f32 keeps it in f32 (the parity mode always does).
+# FORWARD residual stream x (read by every LayerNorm forward, read + written by the out-proj / FFN2 epilogues, re-read by every LayerNorm
+# backward) in bf16: f32 accumulate in the producing epilogue, one rounding on store. GSLORA_FWD_STREAM=f32 keeps it in f32.
 FWD_STREAM_BF16 = os.environ.get("GSLORA_FWD_STREAM", "bf16").lower() != "f32"
+# g' = GELU'(.) * dropmask / (1 - p) — written by the fused FFN1 epilogue, read once by the FFN2-dX epilogue — as an 8-bit fixed-point
+# code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN. GSLORA_GP8=0: bf16.
+GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
+
+# ---- decided schedule choices (A/B'd in rounds 2 - 3, profiles/r03_notes.md). Plain constants: no environment reads; the tests that pin a
+# form against the one it replaced (tests/test_hip_graph.py, tests/test_hip_model.py) patch the module attribute.
+# The two [M, mlp] LoRA-gradient reductions of a block ride in the FFN2-dX epilogue (False: separate gsl_lora_grad launches).
+FUSE_LORA_GRAD = True
 # pool='cls' (vit_face.py:540): the head reads token 0 only and everything after a block's attention is token-wise, so in the LAST block
 # only the cls query's attention output, its out-proj / LayerNorm / FFN rows are ever consumed — forward and backward of that block's
-# tail run on B rows instead of B*T (exact: the skipped rows influence no output of the model). GSLORA_TAIL_CLS=0 keeps the dense forward
-# (the backward then still runs on the cls rows).
-TAIL_CLS = os.environ.get("GSLORA_TAIL_CLS", "1") != "0"
+# tail run on B rows instead of B*T (exact: the skipped rows influence no output of the model). False keeps the dense forward (the
+# backward then still runs on the cls rows).
+TAIL_CLS = True
 # ... and of that block's QKV projection only K and V are needed for every token: Q is projected for the cls rows alone (kv [M, 2*inner]
 # + q_cls [B, inner]; the backward's dX GEMM contracts over 2*inner and the cls rows get their dQ term from a [B, inner] GEMM).
-# GSLORA_QSPLIT=0 keeps the full projection.
-QSPLIT = os.environ.get("GSLORA_QSPLIT", "1") != "0"
-# bf16 speed mode stores g' = GELU'(.) * dropmask / (1 - p) — written by the fused FFN1 epilogue, read once by the FFN2-dX epilogue — as an
-# 8-bit fixed-point code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN.
-# GSLORA_GP8=0 keeps it in bf16 (the parity mode always keeps it in f32).
-GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
+QSPLIT = True
 # rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
-INK_MIN_ROWS = int(os.environ.get("GSLORA_INK_MIN_ROWS", "8192"))
-INK_SMALL = os.environ.get("GSLORA_INK_SMALL", "1") != "0"      # the in-kernel form on the small-tile kernel (few rows)
+INK_MIN_ROWS = 8192
+INK_SMALL = True      # the in-kernel form on the small-tile kernel (few rows)
 # The LoRA-gradient reductions of a backward pass that do not ride in the FFN2-dX epilogue are collected and issued as ONE batched pair of
 # launches (gsl_lora_grad_batch) instead of two to three launches each; their operands stay alive until the end of the backward (or until
 # the data-parallel hook needs the slice). Measured: few-shot 4+4 1.355 -> 1.155 ms (24 reductions, 48 launches before), ViT-B/16 48+48
-# 11.01 -> 10.64 ms, 512+512 24.83 -> 24.69 ms (+1.2 GB of operands held). GSLORA_LGRAD_BATCH_MAX_ROWS: row count above which the
-# reductions run where their operands are produced instead (0 = always).
-LGRAD_BATCH_MAX_ROWS = int(os.environ.get("GSLORA_LGRAD_BATCH_MAX_ROWS", str(1 << 30)))
-# bf16 stream: the LayerNorm in front of the FFN also emits the FFN1 adapter's down-projection u1 = s * LN(x) A1^T (gsl_layernorm_fwd_lora)
-# instead of a skinny GEMM that re-reads LN(x). Measured time-neutral (profiles/r03_notes.md): off by default, GSLORA_LN_LORA=1 selects it.
-LN_LORA = os.environ.get("GSLORA_LN_LORA", "0") != "0"
-# layout of the stashed qkv tensor in bf16 mode: "hm" = head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
-# read contiguous per-head panels), "tm" = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
-QKV_HEAD_MAJOR = os.environ.get("GSLORA_QKV_LAYOUT", "hm").lower() == "hm"
+# 11.01 -> 10.64 ms, 512+512 24.83 -> 24.69 ms (+1.2 GB of operands held). Row count above which the reductions run where their operands
+# are produced instead (0 = always):
+LGRAD_BATCH_MAX_ROWS = 1 << 30
+# bf16 stream: the LayerNorm in front of the FFN can also emit the FFN1 adapter's down-projection u1 = s * LN(x) A1^T
+# (gsl_layernorm_fwd_lora) instead of a skinny GEMM that re-reads LN(x). Measured time-neutral (profiles/r03_notes.md): off.
+LN_LORA = False
+# layout of the stashed qkv tensor in bf16 mode: head-major [B][H][3][T][64] (the QKV GEMM's store permutes, the attention kernels
+# read contiguous per-head panels); False = token-major [B*T, 3*H*64] as the reference's to_qkv output (always used in f32 mode)
+QKV_HEAD_MAJOR = True
 
 
 class BlockSpec:

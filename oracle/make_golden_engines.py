@@ -229,6 +229,87 @@ def gen_acc(out):
     print("[golden] engine_cl_acc:", {k: float(v) for k, v in res.items() if k.startswith("acc_")})
 
 
+def gen_acc_stat(out, only=None):
+    """tests/golden/engine_cl_acc_stat.npz: the statistical accuracy evidence (scenarios.ACC_STAT x scenarios.ACC_SEEDS) — per scenario and
+    data seed: the four accuracies of the REAL eval_data (engine_cl.py:318-346) before / after training with the REAL
+    engine_cl.train_one_epoch, per-sample predictions and decision margins; per scenario the two frozen head tensors (data)."""
+    import engine_cl
+    from util import utils as rutil
+    cfg = recipe.cfg_full()
+    path = os.path.join(out, "engine_cl_acc_stat.npz")
+    res = dict(np.load(path)) if os.path.exists(path) else {}
+    traj = np.load(os.path.join(out, "engine_cl_traj.npz"))
+    dev = torch.device("cpu")
+    for name, sc in S.ACC_STAT.items():
+        if only and name not in only:
+            continue
+        base = recipe.make_state(cfg)
+        if name == "harsh":
+            hb, lw = traj["head_bias"], traj["loss_weight"]
+        else:
+            def emb_fn(st, x):
+                m = build_reference_model(cfg, st).train()
+                with torch.no_grad():
+                    return torch.cat([m(x[i:i + 20]) for i in range(0, x.shape[0], 20)])
+            hb, lw = S.discriminative_head(emb_fn, base, cfg, (S.acc_stat_head_set(cfg, sc["noise"]),), common=sc["common"])
+            res[f"{name}::head_bias"], res[f"{name}::loss_weight"] = hb, lw
+        for seed in S.ACC_SEEDS:
+            if only and f"s{seed}" not in only and any(o.startswith("s") for o in only):
+                continue
+            t0 = time.time()
+            state = dict(base)
+            state["mlp_head.0.bias"], state["loss.weight"] = hb, lw
+            model = build_reference_model(cfg, state)
+            rem, forg, big_rem, big_forg = S.acc_stat_loaders(cfg, name, seed)
+            proto = S.prototypes(cfg)
+            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=sc["lr"], weight_decay=sc["wd"], eps=1e-8)
+            crit = torch.nn.CrossEntropyLoss()
+            key = f"{name}::s{seed}::"
+
+            def snapshot(tag):
+                # ONE pass per split: the real eval_data computes the accuracy, a forward hook records the logits it saw (the margin
+                # logits, labels passed: engine_cl.py:336) for the per-sample predictions and decision margins
+                seen = []
+                hook = model.register_forward_hook(lambda mod, args, outp: seen.append(outp[0].detach().clone()))
+                try:
+                    with torch.no_grad():
+                        for kind, ld in (("forget", big_forg), ("remain", big_rem)):
+                            seen.clear()
+                            res[key + f"acc_{kind}_{tag}"] = np.float64(engine_cl.eval_data(model, ld, dev, kind, 0))
+                            lo = torch.cat(seen)
+                            assert lo.shape[0] == sc["n_per_split"]
+                            res[key + f"pred_{kind}_{tag}"] = lo.argmax(1).numpy().astype(np.int16)
+                            top2 = lo.topk(2, dim=1).values
+                            res[key + f"margin_{kind}_{tag}"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+                finally:
+                    hook.remove()
+                model.train()
+            snapshot("before")
+            cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": sc["BND_pro"], "MULTI_GPU": False, "WORK_PATH": "/tmp", "BACKBONE_NAME": "VIT"}
+            meters, batch_ctr = fresh_meters(rutil), 0
+            for epoch in range(sc["epochs"]):
+                for gq in opt.param_groups:
+                    gq["lr"] = S.cosine_lr(epoch, sc["epochs"], sc["lr"], sc["lr_min"])
+                ret = engine_cl.train_one_epoch(
+                    model=model, dataloader_forget=forg, dataloader_remain=rem, device=dev, criterion=crit, optimizer=opt, epoch=epoch,
+                    beta=sc["beta"], alpha=sc["alpha"], BND=sc["BND"], batch=batch_ctr, testloader_forget=None, testloader_remain=None,
+                    forget_acc_before=sc["forget_acc_before"], highest_H_mean=0.0, cfg=cfgd, task_i="0", use_prototype=True,
+                    prototype_dict=proto, prototype_weight_forget=sc["pro_f_weight"], prototype_weight_remain=sc["pro_r_weight"], **meters)
+                batch_ctr = ret[0]
+                meters = dict(losses_forget=ret[2], losses_remain=ret[3], top1_forget=ret[4], top1_remain=ret[5], losses_total=ret[6],
+                              losses_structure=ret[7], losses_prototype_forget=ret[8], losses_prototype_remain=ret[9])
+            snapshot("after")
+            print(f"[golden] acc_stat {name} seed {seed}: " + " ".join(f"{k}={float(res[key + k]):.2f}" for k in
+                  ("acc_forget_before", "acc_remain_before", "acc_forget_after", "acc_remain_after")) + f" ({time.time() - t0:.0f} s)", flush=True)
+            np.savez_compressed(path + f".part_{name}.npz", **{k: v for k, v in res.items() if k.startswith(name + "::")})
+    # (the two scenarios can be generated by two processes — `acc_stat harsh` / `acc_stat real` — each leaving its .part file; any call merges)
+    for name in S.ACC_STAT:
+        part = path + f".part_{name}.npz"
+        if os.path.exists(part):
+            res.update({k: v for k, v in np.load(part).items()})
+    np.savez_compressed(path, **res)
+
+
 def gen_single(out):
     import engine as eng
     from util import utils as rutil
@@ -504,7 +585,7 @@ def gen_protoaug(out):
 def main():
     install_shims()
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
     out = os.path.join(ROOT, "tests", "golden")
     only = sys.argv[1:]
     if not only or "single" in only:
@@ -515,6 +596,8 @@ def main():
         gen_traj(out)
     if not only or "acc" in only:
         gen_acc(out)
+    if not only or "acc_stat" in only:
+        gen_acc_stat(out, [a for a in only if a in S.ACC_STAT])
     if not only or "chain4" in only:
         gen_chain4(out)
     if not only or "poolmean" in only:

@@ -572,7 +572,7 @@ def test_prototype_label_outside_table_is_loud():
 
 @pytest.mark.parametrize("cfgname", ["small2", "full"])
 def test_bf16_step_identical_in_both_qkv_layouts(monkeypatch, cfgname):
-    """The head-major qkv stash (default in bf16 mode) and the token-major one (GSLORA_QKV_LAYOUT=tm) run the same arithmetic in the same
+    """The head-major qkv stash (default in bf16 mode) and the token-major one (vit_runner.QKV_HEAD_MAJOR = False) run the same arithmetic in the same
     order — the QKV GEMM's store only permutes, the attention kernels only address differently: logits, embeddings, loss and every
     LoRA gradient of a training step with dropout are BIT-IDENTICAL."""
     from gslora_hip import vit_runner
@@ -590,3 +590,33 @@ def test_bf16_step_identical_in_both_qkv_layouts(monkeypatch, cfgname):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
     for k, v in res[True][3].items():
         assert np.array_equal(v, res[False][3][k]), k
+
+
+@pytest.mark.parametrize("knob,value,exact", [("TAIL_CLS", False, False), ("QSPLIT", False, False), ("GP8", False, False),
+                                              ("FWD_STREAM_BF16", False, False), ("GRAD_STREAM_BF16", False, False)])
+def test_bf16_step_under_every_remaining_runner_knob(monkeypatch, knob, value, exact):
+    """every switch left in gslora_hip/vit_runner.py is exercised. The decided schedule forms (the last block's tail on
+    the cls rows, Q projected for the cls rows only) are EXACT re-arrangements: against the forms they replaced the same bf16 step agrees to
+    accumulation-order noise. The three precision knobs of the speed mode (8-bit GELU', bf16 forward / gradient residual streams) against
+    their wider forms: inside the declared bf16 band (logits 0.25 abs at scale 64, LoRA gradients 6 % relative Frobenius / cosine 0.995)."""
+    from gslora_hip import vit_runner
+    cfg, b = recipe.cfg_small2(), 6
+    proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
+    xr, yr, xf, yf = batches(cfg, b)
+    res = {}
+    for alt in (False, True):
+        if alt:
+            monkeypatch.setattr(vit_runner, knob, value)
+        torch.manual_seed(7)
+        m = build(cfg, "bf16", dropout=0.0).train()
+        total, aux = total_loss(m, xr, yr, xf, yf, HYPER, proto)
+        total.backward()
+        res[alt] = (aux["logits_r"].detach().float().clone(), total.detach().clone(), lora_grads(m))
+    schedule = knob in ("TAIL_CLS", "QSPLIT")
+    assert (res[False][0] - res[True][0]).abs().max().item() <= (0.05 if schedule else 0.25)      # (scale-64 logits: 0.05 = 8e-4 on the cosine)
+    g0 = np.concatenate([v.ravel() for v in res[False][2].values()]).astype(np.float64)
+    g1 = np.concatenate([v.ravel() for v in res[True][2].values()]).astype(np.float64)
+    rel = np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
+    cos = float(g0 @ g1) / (np.linalg.norm(g0) * np.linalg.norm(g1))
+    print(f"[knob {knob}] logits max|d| {(res[False][0] - res[True][0]).abs().max().item():.4f}, LoRA-gradient rel. Frobenius {rel:.5f}, cosine {cos:.6f}")
+    assert rel < (0.01 if schedule else 0.06) and cos > (0.9999 if schedule else 0.995)

@@ -107,3 +107,47 @@ def test_vit_b16_geometry_known_answers():
     assert sum(int(np.prod(s)) for s in sh.values()) == 86_567_656
     sh100 = recipe.tv_param_shapes(recipe.cfg_vitb(lora_rank=0, num_class=100))
     assert sum(int(np.prod(s)) for s in sh100.values()) == 85_875_556
+
+
+def test_encoder_restatement_against_an_independent_second_restatement():
+    """VERDICT r03 (missing #3): torchvision is installable in neither container, so the torchvision-0.15.1 encoder composition under
+    oracle/tv_vit.py stays "parity unpinned" against torchvision's own code. What CAN be cross-checked is done here: an INDEPENDENT second
+    restatement of the published architecture — explicit tensor algebra, no nn.MultiheadAttention / nn.LayerNorm / nn.Conv2d modules —
+    reading the SAME state dict by torchvision's parameter names (packed `self_attention.in_proj_weight` [3d, d] in q | k | v row order,
+    `in_proj_bias`, `out_proj`, `ln_1`/`ln_2` eps 1e-6, conv patch embedding as an unfold + matmul over (c, p1, p2), class token first,
+    learned positions added before the blocks, final `encoder.ln`, `heads.head`) must reproduce tv_vit.VisionTransformer's logits to f64
+    round-off. torch's nn.MultiheadAttention (which tv_vit uses, and which IS torchvision's operator) thereby pins the packed in_proj
+    convention of the restatement the HIP path is tested against (gs-lora_amd/vit_pytorch_face/modified_VIT.py)."""
+    import math
+    cfg = recipe.cfg_vitb_small2()
+    st = {k: torch.tensor(v).double() for k, v in recipe.make_tv_state(cfg).items() if "lora_" not in k}
+    vit = T.VisionTransformer(cfg).double()
+    missing = vit.load_state_dict(st, strict=True)
+    x = torch.tensor(recipe.make_images(cfg, 3, seed=11, tag="x2")).double()
+    with torch.no_grad():
+        want = vit(x)
+
+    def ln(t, w, b):
+        mu = t.mean(-1, keepdim=True)
+        var = ((t - mu) ** 2).mean(-1, keepdim=True)
+        return (t - mu) / torch.sqrt(var + 1e-6) * w + b
+
+    p, d, H = cfg["patch_size"], cfg["dim"], cfg["heads"]
+    n, c, hh, ww = x.shape
+    patches = x.reshape(n, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(n, (hh // p) * (ww // p), c * p * p)
+    tok = patches @ st["conv_proj.weight"].reshape(d, -1).t() + st["conv_proj.bias"]
+    seq = torch.cat([st["class_token"].expand(n, -1, -1), tok], dim=1) + st["encoder.pos_embedding"]
+    for i in range(cfg["depth"]):
+        pre = f"encoder.layers.encoder_layer_{i}."
+        y = ln(seq, st[pre + "ln_1.weight"], st[pre + "ln_1.bias"])
+        qkv = y @ st[pre + "self_attention.in_proj_weight"].t() + st[pre + "self_attention.in_proj_bias"]
+        q, k, v = (t.reshape(n, -1, H, d // H).transpose(1, 2) for t in qkv.split(d, dim=-1))
+        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d // H), dim=-1) @ v
+        att = att.transpose(1, 2).reshape(n, -1, d) @ st[pre + "self_attention.out_proj.weight"].t() + st[pre + "self_attention.out_proj.bias"]
+        seq = seq + att
+        y = ln(seq, st[pre + "ln_2.weight"], st[pre + "ln_2.bias"])
+        h1 = y @ st[pre + "mlp.0.weight"].t() + st[pre + "mlp.0.bias"]
+        h1 = 0.5 * h1 * (1.0 + torch.erf(h1 / math.sqrt(2.0)))
+        seq = seq + h1 @ st[pre + "mlp.3.weight"].t() + st[pre + "mlp.3.bias"]
+    got = ln(seq, st["encoder.ln.weight"], st["encoder.ln.bias"])[:, 0] @ st["heads.head.weight"].t() + st["heads.head.bias"]
+    assert (got - want).abs().max().item() < 1e-10 * max(1.0, want.abs().max().item())
