@@ -466,6 +466,24 @@ constexpr int GF_BLOCK_B = 8 * GF_WAVE_B + GF_T16_B;            // 159744 of the
 typedef short gf_v4s_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) gf_v4s_t* gf_lds_v4s_p;
 union GfFrag { gf_v4s_t h[2]; bf16x8_t v; };
+#ifndef GSL_GF_NT
+#define GSL_GF_NT 1
+#endif
+template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {
+  if constexpr (GSL_GF_NT) {
+    if constexpr (sizeof(V) == 16) {
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+      return make_uint4(t[0], t[1], t[2], t[3]);
+    } else {
+      typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+      return make_uint2(t[0], t[1]);
+    }
+  } else {
+    return *reinterpret_cast<const V*>(p);
+  }
+}
 // global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
 struct GfOperands { uint4 ax[4], hx[4], u1a, u1b; };
 template <bool G8>
@@ -476,13 +494,16 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
+    // g' and h are read exactly once by exactly one workgroup: non-temporal loads (GSL_GF_NT), so that these 1.2 GB per launch do not
+    // push the dY row panel — which the 8 N-tiles of a row panel share through the XCD's L2 — out between sibling tiles
+    // (calibrated FETCH_SIZE: 2.0 GB fetched per launch against 1.45 GB of operands, profiles/r04_pmc_calibration.md)
     if constexpr (G8) {      // 8-bit GELU' codes: 8 bytes per lane and row (only .x / .y of the slot are live)
-      const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(e.aux) + g8_off(e.M, m, ncl));
+      const uint2 t = gf_ld<uint2>(reinterpret_cast<const uint8_t*>(e.aux) + g8_off(e.M, m, ncl));
       g.ax[r].x = t.x; g.ax[r].y = t.y;
     } else {
-      g.ax[r] = *reinterpret_cast<const uint4*>(aux + (size_t)m * e.ldo + ncl);
+      g.ax[r] = gf_ld<uint4>(aux + (size_t)m * e.ldo + ncl);
     }
-    g.hx[r] = *reinterpret_cast<const uint4*>(e.gy2 + (size_t)m * e.ldo + ncl);
+    g.hx[r] = gf_ld<uint4>(e.gy2 + (size_t)m * e.ldo + ncl);
   }
   const bf16_t* up = e.gu1 + (size_t)min(mw + ic * 32 + (lane & 31), e.M - 1) * e.ldgu1;
   g.u1a = *reinterpret_cast<const uint4*>(up);
@@ -708,7 +729,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int m = min(mw + q * 64 + r * 8 + crow, e.M - 1);
-        rs[r] = *reinterpret_cast<const uint4*>(res + (size_t)m * e.ldo + ncl);
+        rs[r] = gf_ld<uint4>(res + (size_t)m * e.ldo + ncl);      // the residual stream is read once, by this workgroup (see gf_request)
       }
     }
   };
@@ -1689,11 +1710,90 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   for (int i = 0; i < 4; ++i) epilogue4<EPI, float>(e, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
 }
 
+// ------------------------------------------------------------------ f32 kernel on the matrix cores (parity mode, round 4)
+// v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate, and — MI355X_MICROARCH.md / cdna_hip_programming.md section 3 — bit for bit a
+// k-ordered fmaf chain, i.e. exactly what gemm_f32_kernel computes per output element (acc = 0; k ascending over [A1 | A2]): the two
+// kernels are interchangeable bit for bit (tests/test_hip_ops.py::test_f32_gemm_mfma_equals_valu_bitwise), so every f32 golden test holds
+// on either. What changes is the rate: 64 FLOP/clk/SIMD without occupying the VALU (the VALU kernel ran at 57 TF/s on the FFN1 shape).
+// 128x128 tile, 4 waves of 64x64 (4 x 4 fragments), BK = 32 floats (128-byte rows: the LDS-DMA staging, 16-byte-chunk XOR swizzle and
+// double buffering of gemm_bf16_glds_kernel, byte for byte), operands swapped (mfma(W, A)) so that a lane owns 4 consecutive output
+// columns of one row — the epilogue code of the bf16 kernels (epi_math / epilogue4) serves unchanged. Fragment reads are ds_read_b32
+// (lane (fr, fc): row fr, k = 4 ks + fc — ascending k inside every MFMA): 8 reads per 16 MFMAs of 32 cycles, nowhere near a limit.
+constexpr int FBK = 32;                 // floats per K tile (= BK bf16 in bytes)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A1, int lda1,
+                                                            const float* __restrict__ W1, int ldw1, int K1,
+                                                            const float* __restrict__ A2, int lda2,
+                                                            const float* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  resolve_drop(e.drop);
+  __shared__ __attribute__((aligned(16))) float smem[2][2][BM * FBK];      // [buffer][A | W][128 rows x 32 floats] = 64 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (e.N + BN - 1) / BN;
+  const int tile = e.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+  const int nk1 = K1 / FBK, nk = nk1 + K2 / FBK;
+  const int lrow = lane >> 3, lc = lane & 7;
+  auto issue = [&](int kt, int buf) {
+    const float* Ab; const float* Wb; int lda, ldw, k0;
+    if (kt < nk1) { Ab = A1; Wb = W1; lda = lda1; ldw = ldw1; k0 = kt * FBK; }
+    else { Ab = A2; Wb = W2; lda = lda2; ldw = ldw2; k0 = (kt - nk1) * FBK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wave * 4 + i;                 // 8-row block: one 1 KB DMA per wave-instruction
+      const int row = rb * 8 + lrow;
+      const int c = lc ^ (row & 7);
+      const int gm = min(m0 + row, e.M - 1), gn = min(n0 + row, e.N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)gm * lda + k0 + c * 4), (lptr_t)(&smem[buf][0][rb * 8 * FBK]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)gn * ldw + k0 + c * 4), (lptr_t)(&smem[buf][1][rb * 8 * FBK]), 16, 0, 0);
+    }
+  };
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) { issue(kt + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* As = smem[buf][0];
+    const float* Ws = smem[buf][1];
+#pragma unroll
+    for (int ks = 0; ks < FBK / 4; ++ks) {
+      float af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + fr; af[i] = As[row * FBK + ((ks ^ (row & 7)) << 2) + fc]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int row = wn * 64 + j * 16 + fr; wf[j] = Ws[row * FBK + ((ks ^ (row & 7)) << 2) + fc]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();      // every wave is done with this buffer before the next iteration's DMA overwrites it
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4<EPI, float>(e, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fc * 4, v);
+    }
+}
+
 // Launch knobs. The product library has none: block-id remap on, K rotation off, non-temporal output stores, no stamps, and the
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
+#ifndef GSL_STMODE
+#define GSL_STMODE 1      // output stores of the staged epilogues: 0 plain, 1 non-temporal, 2 sc1 (store_stream16)
+#endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = 1; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
+  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
@@ -1841,9 +1941,19 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     }
 #undef GSL_LAUNCH
   } else {
-    const int nblk = ((e.M + 63) / 64) * ((e.N + 63) / 64);
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,
-                       ldw1, K1, (const float*)A2, lda2, (const float*)W2, ldw2, K2, e);
+    // parity mode: the matrix-core kernel wherever its 128x128 tiles are not mostly padding (skinny N = 64 LoRA projections, a handful of
+    // rows: the 64x64 VALU kernel); the two are bit-identical, the choice is speed only
+    if (e.N >= 128 && e.M >= 64) {
+      EpiArgs ef = e;
+      ef.remap = 1;
+      const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
+      hipLaunchKernelGGL(gemm_f32_mfma_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,
+                         ldw1, K1, (const float*)A2, lda2, (const float*)W2, ldw2, K2, ef);
+    } else {
+      const int nblk = ((e.M + 63) / 64) * ((e.N + 63) / 64);
+      hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nblk), dim3(256), 0, st, (const float*)A1, lda1, (const float*)W1,
+                         ldw1, K1, (const float*)A2, lda2, (const float*)W2, ldw2, K2, e);
+    }
   }
   return check_launch("gsl_gemm_nt");
 }

@@ -138,11 +138,12 @@ ACC = dict(n_per_split=1000, batch=40)
 #            forgetting task that drives the forget accuracy down while the remain accuracy stays high. lr 1e-3 instead of the scripts'
 #            1e-2: the stand-in backbone is random, its class signal is a small part of the feature, and at 1e-2 the 160-step trajectory is
 #            chaotic (remain accuracy swings 25 <-> 90 % between epochs in the REFERENCE itself) — no yardstick for a precision comparison.
+#            6 epochs x 16 steps = 96 steps: below the engines' VER_FREQ = 100 (no evaluate() / checkpoint inside the run).
 # A data seed selects the training batches (labels and noise) and the held-out evaluation samples; the frozen head is one per scenario.
 ACC_SEEDS = (0, 1, 2, 3, 4)
 ACC_STAT = {
     "harsh": dict(TRAJ, common=1.17, noise=0.08, n_per_split=2000, eval_batch=40, train_labels="traj"),
-    "real": dict(batch=16, n_remain=16, n_forget=8, epochs=10, lr=1e-3, lr_min=1e-5, wd=0.05, beta=0.3, alpha=1e-2, BND=105.0, BND_pro=2.0,
+    "real": dict(batch=16, n_remain=16, n_forget=8, epochs=6, lr=1e-3, lr_min=1e-5, wd=0.05, beta=0.3, alpha=1e-2, BND=105.0, BND_pro=2.0,
                  pro_f_weight=0.05, pro_r_weight=0.1, forget_acc_before=100.0, common=0.8, noise=0.08, n_per_split=2000, eval_batch=40),
 }
 

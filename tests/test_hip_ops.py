@@ -1057,3 +1057,37 @@ def test_fused_ffn1_rank_update_equals_the_k_segment_form(ops, r):
     keep = ops.dropout_mask(M * N, 0.1, 11, 5, "cuda").view(M, N).float() / 0.9
     ref = F.gelu(A.float() @ W.float().t() + u.float() @ B.float().t() + bias) * keep
     assert relerr(outs[0][0].float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,N,K1,K2,epi", [(300, 512, 192, 0, "store"), (1576, 2048, 512, 64, "gelu"), (1000, 512, 2048, 64, "res"), (197 * 3, 1536, 512, 0, "store")])
+def test_f32_gemm_mfma_equals_valu_bitwise(ops, M, N, K1, K2, epi):
+    """Parity mode, round 4: gemm_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, N >= 128) against gemm_f32_kernel (VALU fmaf, taken for N = 64):
+    an f32 MFMA is a k-ordered fmaf chain, so the two kernels must agree BIT FOR BIT. The same product is computed once as one N-wide GEMM
+    (matrix cores) and once as N / 64 column slices (VALU kernel); also against torch in f64 to f32 round-off."""
+    from gslora_hip import _lib as L
+    A1, W1 = rnd(M, K1, seed=1).cuda(), rnd(N, K1, seed=2, scale=K1 ** -0.5).cuda()
+    A2 = W2 = None
+    if K2:
+        A2, W2 = rnd(M, K2, seed=3).cuda(), rnd(N, K2, seed=4, scale=0.1).cuda()
+    bias = rnd(N, seed=5).cuda()
+    res = rnd(M, N, seed=6).cuda()
+
+    def call(w1, w2, b, r, out, out2):
+        if epi == "store":
+            ops.gemm_nt(A1, w1, out, A2=A2, W2=w2)
+        elif epi == "gelu":
+            ops.gemm_nt(A1, w1, out, epilogue=L.EPI_BIAS_GELU, A2=A2, W2=w2, bias=b, out2=out2)
+        else:
+            ops.gemm_nt(A1, w1, out, epilogue=L.EPI_BIAS_RES_F32, A2=A2, W2=w2, bias=b, res=r)
+    full, full2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    call(W1, W2, bias, res, full, full2)
+    for c0 in range(0, N, 64):
+        sl = slice(c0, c0 + 64)
+        part, part2 = torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")
+        call(W1[sl].contiguous(), None if W2 is None else W2[sl].contiguous(), bias[sl].contiguous(), res[:, sl].contiguous(), part, part2)
+        assert torch.equal(part, full[:, sl]), c0
+        if epi == "gelu":
+            assert torch.equal(part2, full2[:, sl]), c0
+    acc = A1.double() @ W1.double().t() + (A2.double() @ W2.double().t() if K2 else 0)
+    want = acc if epi == "store" else (torch.nn.functional.gelu(acc + bias.double()) if epi == "gelu" else acc + bias.double() + res.double())
+    assert (full.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())

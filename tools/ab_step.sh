@@ -4,8 +4,8 @@
 out=$1; a=$2; b=$3; n=${4:-2}; shift 4
 mkdir -p $out
 for i in $(seq 1 $n); do
-  env $a python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 > $out/A_$i.json
-  env $b python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 > $out/B_$i.json
+  env $a python bench.py --no-cpu-baseline --no-eval --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 > $out/A_$i.json
+  env $b python bench.py --no-cpu-baseline --no-eval --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 > $out/B_$i.json
 done
 python - <<PY
 import json,glob
