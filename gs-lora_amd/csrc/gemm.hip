@@ -43,6 +43,7 @@ struct EpiArgs {
   int pf;      // 8-phase kernel: after its K loop a workgroup touches the first A lines of the tile that takes a slot of its XCD next (see the kernel)
   int mrev;    // 8-phase kernel: tiles in reverse order (the consumer starts on the rows its producer wrote last: still in the 256 MB Infinity Cache)
   int stmode;  // output store flavour of the staged bf16 epilogue (development knob GSL_STORE_MODE, see store_stream16)
+  int f16;     // BIAS_RES_BF16 / PATCH_BF16 templates: the residual stream (res in, out) is IEEE fp16 instead of bf16 (GSL_EPI_BIAS_RES_F16 / PATCH_F16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
   // gradient-fused MUL epilogue (gsl_gemm_nt_lora_mulgrad): operands of the two LoRA-gradient reductions that consume this tile
   const bf16_t* gu1; int ldgu1;   // U1 [M, >= 16]: G1[n, j] = sum_m out[m, n] * U1[m, j]
@@ -150,9 +151,12 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
-  } else if constexpr (EPI == GSL_EPI_BIAS_RES_BF16) {      // the residual stream in the operand dtype: f32 arithmetic, one rounding on store
+  } else if constexpr (EPI == GSL_EPI_BIAS_RES_BF16) {      // the residual stream in 2 bytes per element (bf16, or fp16 with e.f16): f32 arithmetic, one rounding on store
     float r[4], dm[4];
-    Elem<T>::ld4(reinterpret_cast<const T*>(e.res) + off, r);
+    {
+      const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(e.res) + off);
+      unpack2s(t.x, e.f16, r[0], r[1]); unpack2s(t.y, e.f16, r[2], r[3]);
+    }
     drop_mul4(e.drop, lin, dm);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (v[i] + bq[i]) * dm[i] + r[i];
@@ -208,7 +212,10 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   if constexpr (epi_out_is_f32<EPI>()) {
     Elem<float>::st4(reinterpret_cast<float*>(e.out) + off, v);
   } else {
-    Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
+    if constexpr (EPI == GSL_EPI_BIAS_RES_BF16 || EPI == GSL_EPI_PATCH_BF16)      // the stream output: bf16 or fp16
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.out) + off) = make_uint2(pack2s(v[0], v[1], e.f16), pack2s(v[2], v[3], e.f16));
+    else
+      Elem<T>::st4(reinterpret_cast<T*>(e.out) + off, v);
     if constexpr (EPI == GSL_EPI_BIAS_GELU) { if (e.out2) Elem<T>::st4(reinterpret_cast<T*>(e.out2) + off, g); }
     if constexpr (EPI == GSL_EPI_BIAS_GELU_G8) { if (e.out2) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(e.out2) + g8_off(e.M, m, n)) = g8_pack4(g, G8_K / e.drop.scale); }
   }
@@ -325,7 +332,8 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           }
         }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
-        *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        if constexpr (EPI == GSL_EPI_BIAS_RES_BF16 || EPI == GSL_EPI_PATCH_BF16) *reinterpret_cast<uint2*>(d) = make_uint2(pack2s(v[0], v[1], e.f16), pack2s(v[2], v[3], e.f16));
+        else *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         if constexpr (G8) {
           *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) = g8_pack4(g, kq8);
         } else if constexpr (NOUT == 2) {
@@ -771,12 +779,14 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
         const uint32_t a[4] = {rs[r].x, rs[r].y, rs[r].z, rs[r].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          o[2 * k] = (c[2 * k] + b8[2 * k]) * dm[2 * k] + __uint_as_float(a[k] << 16);
-          o[2 * k + 1] = (c[2 * k + 1] + b8[2 * k + 1]) * dm[2 * k + 1] + __uint_as_float(a[k] & 0xffff0000u);
+          float r0, r1;
+          unpack2s(a[k], e.f16, r0, r1);
+          o[2 * k] = (c[2 * k] + b8[2 * k]) * dm[2 * k] + r0;
+          o[2 * k + 1] = (c[2 * k + 1] + b8[2 * k + 1]) * dm[2 * k + 1] + r1;
         }
       }
       if (m < e.M && n < e.N)
-        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])), e.stmode);
+        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2s(o[0], o[1], e.f16), pack2s(o[2], o[3], e.f16), pack2s(o[4], o[5], e.f16), pack2s(o[6], o[7], e.f16)), e.stmode);
     }
   }
 }
@@ -1793,7 +1803,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 #define GSL_STMODE 1      // output stores of the staged epilogues: 0 plain, 1 non-temporal, 2 sc1 (store_stream16)
 #endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
+  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
@@ -1986,9 +1996,15 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
     case GSL_EPI_BIAS_RES_F32:
       GSL_CHECK_ARG(bias && res, "bias/res required");
       return launch_gemm<GSL_EPI_BIAS_RES_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_BIAS_RES_F16:      // the same kernels with the stream element type switched at run time (EpiArgs::f16)
+      e.f16 = 1;
+      [[fallthrough]];
     case GSL_EPI_BIAS_RES_BF16:
       GSL_CHECK_ARG(bias && res && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/res required, bf16 only");
       return launch_gemm<GSL_EPI_BIAS_RES_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_PATCH_F16:
+      e.f16 = 1;
+      [[fallthrough]];
     case GSL_EPI_PATCH_BF16:
       GSL_CHECK_ARG(bias && pos && cls && T > 0 && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/pos/cls/T required, bf16 only");
       return launch_gemm<GSL_EPI_PATCH_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
@@ -2066,6 +2082,7 @@ extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, 
   switch (epilogue) {
     case GSL_EPI_STORE: GSL_LL(GSL_EPI_STORE); break;
     case GSL_EPI_BIAS_RES_F32: GSL_CHECK_ARG(bias && res, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_F32); break;
+    case GSL_EPI_BIAS_RES_F16: e.f16 = 1; [[fallthrough]];
     case GSL_EPI_BIAS_RES_BF16: GSL_CHECK_ARG(bias && res && (ldo % 8) == 0, "bias/res required"); GSL_LL(GSL_EPI_BIAS_RES_BF16); break;
     case GSL_EPI_BIAS_GELU: GSL_CHECK_ARG(bias, "bias required"); GSL_LL(GSL_EPI_BIAS_GELU); break;
     case GSL_EPI_MUL: GSL_CHECK_ARG(aux, "aux required"); GSL_LL(GSL_EPI_MUL); break;

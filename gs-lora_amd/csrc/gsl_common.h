@@ -66,6 +66,38 @@ template <> struct Elem<bf16_t> {
   }
 };
 
+// ---- fp16 (IEEE binary16): element type of the FORWARD residual stream in speed mode (round 4). The stream is only ever read by
+// LayerNorm kernels and residual-add epilogues — never a matrix-core operand — so it does not need bf16's exponent range, and fp16's 11-bit
+// significand rounds each of the 13 stream tensors of a forward 8x finer than bf16's 8 bits at the same 2 bytes per element
+// (profiles/r04_b_precision_ablation.md: the bf16 stream was 3/4 of the speed mode's logit error). Values are clamped to +-65504 on store.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 gsl_f16x2;
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  const gsl_f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, gsl_f16x2));      // round to nearest even
+}
+__device__ __forceinline__ void unpack2h(uint32_t u, float& lo, float& hi) {
+  const gsl_f32x2 v = __builtin_convertvector(__builtin_bit_cast(gsl_f16x2, u), gsl_f32x2);
+  lo = v[0]; hi = v[1];
+}
+// two stream elements <-> one dword, the element type chosen at run time (wave-uniform): 0 = bf16, 1 = fp16
+__device__ __forceinline__ uint32_t pack2s(float lo, float hi, int f16) { return f16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+__device__ __forceinline__ void unpack2s(uint32_t u, int f16, float& lo, float& hi) {
+  if (f16) unpack2h(u, lo, hi);
+  else { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+}
+template <> struct Elem<f16_t> {
+  static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+  static __device__ __forceinline__ void ld4(const f16_t* p, float v[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    unpack2h(t.x, v[0], v[1]); unpack2h(t.y, v[2], v[3]);
+  }
+  static __device__ __forceinline__ void st4(f16_t* p, const float v[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+  }
+};
+
 // ------------------------------------------------------------------ wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -126,12 +126,15 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(const X* __restrict__ x,
 extern "C" int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamma, const float* beta, float eps, const float* Wn,
                             const int64_t* label, float* emb, float* mean, float* rstd, float* logits, int B, int D, int C,
                             float cos_s, float cos_m, const float* head_bias, int linear_head, int pool_mean, gsl_stream_t s) {
-  GSL_CHECK_ARG(x_dtype == GSL_F32 || x_dtype == GSL_BF16, "x dtype");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || x_dtype == GSL_BF16 || x_dtype == GSL_F16, "x dtype");
   GSL_CHECK_ARG(x && gamma && beta && emb && mean && rstd && B > 0 && T > 0, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0, "D <= 1024, D%4==0");
   GSL_CHECK_ARG(!logits || (Wn && C > 0), "Wn required for logits");
   const int nthr = B <= 128 ? 1024 : 256;      // one workgroup per image: with few images give each one 16 waves (100 class rows in two rounds)
-  if (x_dtype == GSL_BF16)
+  if (x_dtype == GSL_F16)
+    hipLaunchKernelGGL(head_fwd_kernel<f16_t>, dim3(B), dim3(nthr), 0, as_stream(s), (const f16_t*)x, T, gamma, beta, eps, Wn, label, emb,
+                       mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
+  else if (x_dtype == GSL_BF16)
     hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(nthr), 0, as_stream(s), (const bf16_t*)x, T, gamma, beta, eps, Wn, label, emb,
                        mean, rstd, logits, D, C, cos_s, cos_m, head_bias, linear_head, pool_mean);
   else
@@ -238,11 +241,13 @@ extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const void*
   GSL_CHECK_ARG(!(compact && pool_mean), "compact cls-row gradients need pool = 'cls'");
   const DropCfg drop = make_drop(p_drop, seed, site);
   GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
-  GSL_CHECK_ARG(x_dtype == GSL_F32 || (x_dtype == GSL_BF16 && dtype == GSL_BF16), "x dtype (bf16 only in bf16 mode)");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16), "x dtype (bf16 / fp16 only in bf16 mode)");
 #define GSL_HB(T_, S_, X_)                                                                                                          \
   hipLaunchKernelGGL((head_bwd_kernel<T_, S_, X_>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, (const X_*)x, T, gamma, mean, \
                      rstd, emb, Wn, (S_*)dx, (T_*)dxb, D, C, cos_s, drop, linear_head, pool_mean, compact)
-  if (dtype == GSL_BF16 && stream_dtype == GSL_BF16 && x_dtype == GSL_BF16) GSL_HB(bf16_t, bf16_t, bf16_t);
+  if (dtype == GSL_BF16 && stream_dtype == GSL_BF16 && x_dtype == GSL_F16) GSL_HB(bf16_t, bf16_t, f16_t);
+  else if (dtype == GSL_BF16 && x_dtype == GSL_F16) GSL_HB(bf16_t, float, f16_t);
+  else if (dtype == GSL_BF16 && stream_dtype == GSL_BF16 && x_dtype == GSL_BF16) GSL_HB(bf16_t, bf16_t, bf16_t);
   else if (dtype == GSL_BF16 && stream_dtype == GSL_BF16) GSL_HB(bf16_t, bf16_t, float);
   else if (dtype == GSL_BF16 && x_dtype == GSL_BF16) GSL_HB(bf16_t, float, bf16_t);
   else if (dtype == GSL_BF16) GSL_HB(bf16_t, float, float);

@@ -16,9 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSLORA_HIP_LIB") or os.path.join(_HERE, "libgslora_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libgslora_hip_dev.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2      # F16: the x_dtype of a forward residual stream carried in IEEE fp16 (bf16 speed mode only)
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM, EPI_BIAS_RES_BF16, EPI_PATCH_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
-EPI_MUL_G8, EPI_BIAS_GELU_G8 = 9, 10
+EPI_MUL_G8, EPI_BIAS_GELU_G8, EPI_BIAS_RES_F16, EPI_PATCH_F16 = 9, 10, 11, 12
 NORM_SPLIT = 8
 SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 
-DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}      # (fp16: element type of the forward residual stream only)
 
 
 def _p(t):

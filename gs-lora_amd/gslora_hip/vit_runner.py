@@ -23,8 +23,13 @@ SITE_EMB = 1_000_000
 # LayerNorm backward. GSLORA_GRAD_STREAM=f32 keeps it in f32.
 GRAD_STREAM_BF16 = os.environ.get("GSLORA_GRAD_STREAM", "bf16").lower() != "f32"
 # FORWARD residual stream x (read by every LayerNorm forward, read + written by the out-proj / FFN2 epilogues, re-read by every LayerNorm
-# backward) in bf16: f32 accumulate in the producing epilogue, one rounding on store. GSLORA_FWD_STREAM=f32 keeps it in f32.
-FWD_STREAM_BF16 = os.environ.get("GSLORA_FWD_STREAM", "bf16").lower() != "f32"
+# backward) in 2 bytes per element: f32 accumulate in the producing epilogue, one rounding on store. "f16" (default, round 4): IEEE fp16 —
+# the stream is never a matrix-core operand, so it can spend its 16 bits on significand instead of exponent range: 8x finer rounding than
+# bf16 at the same bytes (values clamp at +-65504; ViT residual streams are O(1 .. 100)); "bf16": round 3's form; "f32": 4 bytes
+# (+9.7 GB per step). GSLORA_FWD_STREAM selects. profiles/r04_acc_stat.md has what each buys in trajectory fidelity.
+FWD_STREAM = os.environ.get("GSLORA_FWD_STREAM", "f16").lower()
+if FWD_STREAM not in ("f16", "bf16", "f32"):
+    raise ValueError(f"GSLORA_FWD_STREAM must be f16, bf16 or f32, not {FWD_STREAM!r}")
 # g' = GELU'(.) * dropmask / (1 - p) — written by the fused FFN1 epilogue, read once by the FFN2-dX epilogue — as an 8-bit fixed-point
 # code (include/gslora_hip.h, GSL_EPI_BIAS_GELU_G8): half the bytes of one of the two [M, mlp] tensors of the FFN. GSLORA_GP8=0: bf16.
 GP8 = os.environ.get("GSLORA_GP8", "1") != "0"
@@ -373,12 +378,13 @@ class ViTRunner:
         eps = sp.ln_eps
 
         patches = ops.patchify(parts, sp.patch_size, dt)
-        xbf = dt == torch.bfloat16 and FWD_STREAM_BF16
-        xdt = torch.bfloat16 if xbf else torch.float32            # dtype of the residual stream
-        epi_res = L.EPI_BIAS_RES_BF16 if xbf else L.EPI_BIAS_RES_F32
+        xbf = dt == torch.bfloat16 and FWD_STREAM != "f32"        # the residual stream in 2 bytes per element
+        xf16 = xbf and FWD_STREAM == "f16"
+        xdt = (torch.float16 if xf16 else torch.bfloat16) if xbf else torch.float32            # dtype of the residual stream
+        epi_res = (L.EPI_BIAS_RES_F16 if xf16 else L.EPI_BIAS_RES_BF16) if xbf else L.EPI_BIAS_RES_F32
         x = torch.empty(M, D, device=img.device, dtype=xdt)
         pw = self.w_conv("pe", sp.patch_w, dt) if sp.patch_is_conv else self.w("pe", sp.patch_w, dt)
-        ops.gemm_nt(patches, pw, x, epilogue=L.EPI_PATCH_BF16 if xbf else L.EPI_PATCH, bias=sp.patch_b.detach(),
+        ops.gemm_nt(patches, pw, x, epilogue=(L.EPI_PATCH_F16 if xf16 else L.EPI_PATCH_BF16) if xbf else L.EPI_PATCH, bias=sp.patch_b.detach(),
                     pos=sp.pos.detach()[0, :T].contiguous(), cls=sp.cls.detach().reshape(-1), T=T,
                     p_drop=p_emb, seed=seed, site=SITE_EMB | sflag)
         del patches

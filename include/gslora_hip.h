@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* gsl_stream_t;
 
-enum gsl_dtype { GSL_F32 = 0, GSL_BF16 = 1 };
+enum gsl_dtype { GSL_F32 = 0, GSL_BF16 = 1, GSL_F16 = 2 /* x_dtype ONLY: the forward residual stream of the bf16 speed mode as IEEE fp16 (round 4) */ };
 
 enum gsl_status {
   GSL_OK = 0,
@@ -54,6 +54,8 @@ enum gsl_epilogue {
   GSL_EPI_PATCH_BF16 = 8,   /* bf16 only: PATCH with a bf16 output */
   GSL_EPI_MUL_G8 = 9,       /* bf16 only: MUL with aux = the 8-bit GELU' code tensor (slab-major, see below) written by BIAS_GELU_G8;
                                p_drop = the dropout rate of the forward that wrote it (decode scale 1/(1-p); no mask is applied here) */
+  GSL_EPI_BIAS_RES_F16 = 11,/* bf16 only: BIAS_RES_BF16 with the forward residual stream (res in, out) in IEEE fp16 (clamped to +-65504 on store) */
+  GSL_EPI_PATCH_F16 = 12,   /* bf16 only: PATCH with an fp16 output */
   GSL_EPI_BIAS_GELU_G8 = 10 /* bf16 only: BIAS_GELU whose second output is the 8-bit fixed-point code of gelu'(acc+bias)*dropmask:
                                q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p); gelu' lies in [-0.129, 1.129]:
                                absolute error <= 0.0025/(1-p), a dropped element decodes to exactly 0. out2 is M*N bytes in SLAB-MAJOR

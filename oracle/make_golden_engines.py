@@ -238,6 +238,10 @@ def gen_acc_stat(out, only=None):
     cfg = recipe.cfg_full()
     path = os.path.join(out, "engine_cl_acc_stat.npz")
     res = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in S.ACC_STAT:      # resume: cells already generated by an interrupted run (python ... acc_stat real s3 s4 adds the missing seeds)
+        part = path + f".part_{name}.npz"
+        if os.path.exists(part):
+            res.update({k: v for k, v in np.load(part).items()})
     traj = np.load(os.path.join(out, "engine_cl_traj.npz"))
     dev = torch.device("cpu")
     for name, sc in S.ACC_STAT.items():
@@ -597,7 +601,7 @@ def main():
     if not only or "acc" in only:
         gen_acc(out)
     if not only or "acc_stat" in only:
-        gen_acc_stat(out, [a for a in only if a in S.ACC_STAT])
+        gen_acc_stat(out, [a for a in only if a in S.ACC_STAT or (a[:1] == "s" and a[1:].isdigit())])
     if not only or "chain4" in only:
         gen_chain4(out)
     if not only or "poolmean" in only:

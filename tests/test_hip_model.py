@@ -593,12 +593,12 @@ def test_bf16_step_identical_in_both_qkv_layouts(monkeypatch, cfgname):
 
 
 @pytest.mark.parametrize("knob,value,exact", [("TAIL_CLS", False, False), ("QSPLIT", False, False), ("GP8", False, False),
-                                              ("FWD_STREAM_BF16", False, False), ("GRAD_STREAM_BF16", False, False)])
+                                              ("FWD_STREAM", "bf16", False), ("FWD_STREAM", "f32", False), ("GRAD_STREAM_BF16", False, False)])
 def test_bf16_step_under_every_remaining_runner_knob(monkeypatch, knob, value, exact):
     """every switch left in gslora_hip/vit_runner.py is exercised. The decided schedule forms (the last block's tail on
     the cls rows, Q projected for the cls rows only) are EXACT re-arrangements: against the forms they replaced the same bf16 step agrees to
     accumulation-order noise. The three precision knobs of the speed mode (8-bit GELU', bf16 forward / gradient residual streams) against
-    their wider forms: inside the declared bf16 band (logits 0.25 abs at scale 64, LoRA gradients 6 % relative Frobenius / cosine 0.995)."""
+    their other forms (fp16 / bf16 / f32 forward stream): inside the declared bf16 band (logits 0.25 abs at scale 64, LoRA gradients 6 % relative Frobenius / cosine 0.995)."""
     from gslora_hip import vit_runner
     cfg, b = recipe.cfg_small2(), 6
     proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
@@ -618,5 +618,5 @@ def test_bf16_step_under_every_remaining_runner_knob(monkeypatch, knob, value, e
     g1 = np.concatenate([v.ravel() for v in res[True][2].values()]).astype(np.float64)
     rel = np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
     cos = float(g0 @ g1) / (np.linalg.norm(g0) * np.linalg.norm(g1))
-    print(f"[knob {knob}] logits max|d| {(res[False][0] - res[True][0]).abs().max().item():.4f}, LoRA-gradient rel. Frobenius {rel:.5f}, cosine {cos:.6f}")
+    print(f"[knob {knob}={value}] logits max|d| {(res[False][0] - res[True][0]).abs().max().item():.4f}, LoRA-gradient rel. Frobenius {rel:.5f}, cosine {cos:.6f}")
     assert rel < (0.01 if schedule else 0.06) and cos > (0.9999 if schedule else 0.995)

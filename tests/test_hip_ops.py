@@ -702,13 +702,15 @@ def test_attention_head_major_input_bit_identical_to_token_major(ops, B, T, H):
 
 
 # ---------------------------------------------------------------------------------------------------------------- bf16 forward stream
+@pytest.mark.parametrize("sdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K1,K2,T", [(591, 192, 128, 64, 197), (257, 512, 512, 0, 257), (788, 512, 2048, 64, 197),
                                          (33490, 512, 512, 0, 197), (33490, 512, 192, 0, 197)])
-def test_gemm_bf16_stream_epilogues_equal_the_rounded_f32_stream_epilogues(ops, M, N, K1, K2, T):
+def test_gemm_bf16_stream_epilogues_equal_the_rounded_f32_stream_epilogues(ops, M, N, K1, K2, T, sdt):
     """BIAS_RES_BF16 / PATCH_BF16 (bf16 speed mode, forward residual stream in bf16): with a residual that is exactly representable in
     bf16 both epilogues compute the same f32 value — the bf16-stream output must be its one-time rounding, bit for bit, and the dropout
     mask the same. Small shapes run the 128x128 kernel's fragment path, the 33 490-row shapes the 8-phase kernel's staged full-row
-    epilogue (ragged last M tile)."""
+    epilogue (ragged last M tile). sdt = the stream's element type: bf16 (round 3) or IEEE fp16 (round 4: GSL_EPI_BIAS_RES_F16 /
+    PATCH_F16, the same kernels with the conversion switched at run time; round to nearest even, clamped at +-65504)."""
     from gslora_hip import _lib as L
     dt = torch.bfloat16
     c = lambda t: None if t is None else t.cuda().to(dt)
@@ -717,18 +719,23 @@ def test_gemm_bf16_stream_epilogues_equal_the_rounded_f32_stream_epilogues(ops, 
     if K2:
         a2 = rnd(M, K2, seed=3); a2[:, 8:] = 0
         A2, W2 = c(a2), c(rnd(N, K2, seed=4, scale=0.1))
-    bias, res = rnd(N, seed=5).cuda(), c(rnd(M, N, seed=6))
+    bias, res = rnd(N, seed=5).cuda(), rnd(M, N, seed=6).cuda().to(sdt)
+    epi_res, epi_patch = (L.EPI_BIAS_RES_F16, L.EPI_PATCH_F16) if sdt == torch.float16 else (L.EPI_BIAS_RES_BF16, L.EPI_PATCH_BF16)
     for p in (0.0, 0.1):
         o32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
-        o16 = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+        o16 = torch.full((M, N), 7.0, device="cuda", dtype=sdt)
         ops.gemm_nt(A1, W1, o32, epilogue=L.EPI_BIAS_RES_F32, A2=A2, W2=W2, bias=bias, res=res.float(), p_drop=p, seed=11, site=3)
-        ops.gemm_nt(A1, W1, o16, epilogue=L.EPI_BIAS_RES_BF16, A2=A2, W2=W2, bias=bias, res=res, p_drop=p, seed=11, site=3)
-        assert torch.equal(o16, o32.to(dt)), p
+        ops.gemm_nt(A1, W1, o16, epilogue=epi_res, A2=A2, W2=W2, bias=bias, res=res, p_drop=p, seed=11, site=3)
+        assert torch.equal(o16, o32.to(sdt)), p
         pos, cls = rnd(T, N, seed=8).cuda(), rnd(N, seed=9).cuda()
         if M % T == 0:
             ops.gemm_nt(A1, W1, o32, epilogue=L.EPI_PATCH, A2=A2, W2=W2, bias=bias, pos=pos, cls=cls, T=T, p_drop=p, seed=12, site=1_000_000)
-            ops.gemm_nt(A1, W1, o16, epilogue=L.EPI_PATCH_BF16, A2=A2, W2=W2, bias=bias, pos=pos, cls=cls, T=T, p_drop=p, seed=12, site=1_000_000)
-            assert torch.equal(o16, o32.to(dt)), p
+            ops.gemm_nt(A1, W1, o16, epilogue=epi_patch, A2=A2, W2=W2, bias=bias, pos=pos, cls=cls, T=T, p_drop=p, seed=12, site=1_000_000)
+            assert torch.equal(o16, o32.to(sdt)), p
+    if sdt == torch.float16:      # beyond fp16's range the stream saturates at +-65504 instead of turning into inf
+        big = torch.full((M, N), 60000.0, device="cuda", dtype=sdt)
+        ops.gemm_nt(A1, W1, o16, epilogue=epi_res, A2=A2, W2=W2, bias=bias + 30000.0, res=big)
+        assert torch.isfinite(o16.float()).all() and float(o16.float().max()) == 65504.0
 
 
 def test_gemm_nt_lora_bf16_stream_epilogue(ops):
@@ -740,20 +747,23 @@ def test_gemm_nt_lora_bf16_stream_epilogue(ops):
     A, W = c(rnd(M, K, seed=1)), c(rnd(N, K, seed=2, scale=K ** -0.5))
     P = torch.zeros(16, K); P[:r] = rnd(r, K, seed=3, scale=K ** -0.5)
     Q = torch.zeros(N, 32); Q[:, :r] = rnd(N, r, seed=4, scale=0.3)
-    bias, res = rnd(N, seed=5).cuda(), c(rnd(M, N, seed=6))
-    t32 = torch.empty(M, 64, device="cuda", dtype=dt); t16 = torch.empty(M, 64, device="cuda", dtype=dt)
-    o32 = torch.empty(M, N, device="cuda", dtype=torch.float32); o16 = torch.empty(M, N, device="cuda", dtype=dt)
-    ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t32, o32, epilogue=L.EPI_BIAS_RES_F32, bias=bias, res=res.float(), p_drop=0.1, seed=5, site=2)
-    ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t16, o16, epilogue=L.EPI_BIAS_RES_BF16, bias=bias, res=res, p_drop=0.1, seed=5, site=2)
-    assert torch.equal(o16, o32.to(dt)) and torch.equal(t16, t32)
+    bias = rnd(N, seed=5).cuda()
+    for sdt, epi in ((dt, L.EPI_BIAS_RES_BF16), (torch.float16, L.EPI_BIAS_RES_F16)):      # the stream in bf16 / in fp16
+        res = rnd(M, N, seed=6).cuda().to(sdt)
+        t32 = torch.empty(M, 64, device="cuda", dtype=dt); t16 = torch.empty(M, 64, device="cuda", dtype=dt)
+        o32 = torch.empty(M, N, device="cuda", dtype=torch.float32); o16 = torch.empty(M, N, device="cuda", dtype=sdt)
+        ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t32, o32, epilogue=L.EPI_BIAS_RES_F32, bias=bias, res=res.float(), p_drop=0.1, seed=5, site=2)
+        ops.gemm_nt_lora(A, W, c(P), c(Q), 1.0 / r, t16, o16, epilogue=epi, bias=bias, res=res, p_drop=0.1, seed=5, site=2)
+        assert torch.equal(o16, o32.to(sdt)) and torch.equal(t16, t32)
 
 
+@pytest.mark.parametrize("sdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("D", [128, 512, 768])
-def test_layernorm_with_a_bf16_residual_stream(ops, D):
-    """LayerNorm forward / backward reading the residual stream x in bf16 == the same kernels on the widened f32 copy of that tensor."""
+def test_layernorm_with_a_bf16_residual_stream(ops, D, sdt):
+    """LayerNorm forward / backward reading the residual stream x in bf16 / fp16 == the same kernels on the widened f32 copy of that tensor."""
     dt = torch.bfloat16
     M = 301
-    x = (rnd(M, D, seed=41, scale=2.0) + 0.5).cuda().to(dt)
+    x = (rnd(M, D, seed=41, scale=2.0) + 0.5).cuda().to(sdt)
     g, b = (1 + 0.1 * rnd(D, seed=42)).cuda(), (0.1 * rnd(D, seed=43)).cuda()
     y16, m16, r16 = ops.layernorm_fwd(x, D, M, D, g, b, 1e-5, dt)
     y32, m32, r32 = ops.layernorm_fwd(x.float(), D, M, D, g, b, 1e-5, dt)
@@ -1091,3 +1101,23 @@ def test_f32_gemm_mfma_equals_valu_bitwise(ops, M, N, K1, K2, epi):
     acc = A1.double() @ W1.double().t() + (A2.double() @ W2.double().t() if K2 else 0)
     want = acc if epi == "store" else (torch.nn.functional.gelu(acc + bias.double()) if epi == "gelu" else acc + bias.double() + res.double())
     assert (full.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_head_with_an_fp16_residual_stream(ops):
+    """gsl_head_fwd / gsl_head_bwd reading the forward residual stream in fp16 (x_dtype = GSL_F16) == the same kernels on the widened f32
+    copy of that tensor, bit for bit (the stream is converted on load; nothing else changes)."""
+    B, T, D, C = 6, 9, 128, 10
+    dt = torch.bfloat16
+    x = rnd(B * T, D, seed=1, scale=1.5).cuda().to(torch.float16)
+    g, b = (1 + 0.1 * rnd(D, seed=2)).cuda(), (0.1 * rnd(D, seed=3)).cuda()
+    Wn = ops.cosface_prep(rnd(C, D, seed=4).cuda())
+    label = (torch.arange(B) % C).cuda()
+    l16, e16, m16, r16 = ops.head_fwd(x, B, T, D, g, b, 1e-5, Wn, label, 64.0, 0.35)
+    l32, e32, m32, r32 = ops.head_fwd(x.float(), B, T, D, g, b, 1e-5, Wn, label, 64.0, 0.35)
+    assert torch.equal(l16, l32) and torch.equal(e16, e32) and torch.equal(m16, m32) and torch.equal(r16, r32)
+    dl, de = rnd(B, C, seed=5).cuda(), rnd(B, D, seed=6).cuda()
+    for sdt in (torch.bfloat16, torch.float32):
+        kw = dict(p_drop=0.3, seed=21, site=6, stream_dtype=sdt, compact=True)
+        a = ops.head_bwd(dl, de, x, B, T, D, g, m16, r16, e16, Wn, 64.0, dt, **kw)
+        c = ops.head_bwd(dl, de, x.float(), B, T, D, g, m16, r16, e16, Wn, 64.0, dt, **kw)
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])

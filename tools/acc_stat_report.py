@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Accuracy deltas of the HIP path against the REAL reference (tests/golden/engine_cl_acc_stat.npz) as a table: scenarios x data seeds x
 numeric configurations of the speed mode. The cells are tests/test_hip_engines.py::run_acc_stat (the same code the GPU test asserts on).
-Usage (GPU box): python tools/acc_stat_report.py [config ...] > gpurun_out/acc_stat.md        configs: see CONFIGS
+Usage (GPU box): python tools/acc_stat_report.py [--scenarios harsh,real] [config ...] > gpurun_out/acc_stat.md        configs: see CONFIGS
 """
 import os
 import sys
@@ -15,12 +15,13 @@ import io
 import numpy as np  # noqa: E402
 
 CONFIGS = {      # name -> (training dtype, vit_runner attributes, engine_cl.EVAL_DTYPE)
-    "bf16 (default)": ("bf16", {}, "fp32"),
+    "bf16 (default: fp16 forward stream)": ("bf16", {}, "fp32"),
     "bf16, evaluation in bf16 too": ("bf16", {}, "model"),
-    "bf16, f32 forward stream": ("bf16", {"FWD_STREAM_BF16": False}, "fp32"),
+    "bf16, bf16 forward stream (round 3)": ("bf16", {"FWD_STREAM": "bf16"}, "fp32"),
+    "bf16, f32 forward stream": ("bf16", {"FWD_STREAM": "f32"}, "fp32"),
     "bf16, f32 gradient stream": ("bf16", {"GRAD_STREAM_BF16": False}, "fp32"),
     "bf16, bf16 GELU' (no 8-bit code)": ("bf16", {"GP8": False}, "fp32"),
-    "bf16, all three wide": ("bf16", {"FWD_STREAM_BF16": False, "GRAD_STREAM_BF16": False, "GP8": False}, "fp32"),
+    "bf16, all three wide": ("bf16", {"FWD_STREAM": "f32", "GRAD_STREAM_BF16": False, "GP8": False}, "fp32"),
     "fp32 (parity mode)": ("fp32", {}, "fp32"),
 }
 
@@ -31,7 +32,12 @@ def main():
     from gslora_hip import vit_runner as R
     from oracle import scenarios as S
     golden = os.path.join(ROOT, "tests", "golden")
-    names = sys.argv[1:] or list(CONFIGS)
+    args = sys.argv[1:]
+    scen = None
+    if "--scenarios" in args:
+        i = args.index("--scenarios")
+        scen, args = args[i + 1].split(","), args[:i] + args[i + 2:]
+    names = args or list(CONFIGS)
     print("| configuration | scenario | split | reference accuracy % | delta pp: mean +- std over seeds | worst cell pp | predictions that differ |")
     print("|---|---|---|---|---|---|---|")
     for cname in names:
@@ -42,9 +48,10 @@ def main():
             setattr(R, k, v)
         engine_cl.EVAL_DTYPE = ev
         try:
-            for sname in S.ACC_STAT:
+            for sname in (scen or S.ACC_STAT):
                 t0 = time.time()
-                seeds = S.ACC_SEEDS if dtype == "bf16" else S.ACC_SEEDS[:2]
+                seeds = tuple(int(v) for v in os.environ["GSL_ACC_SEEDS"].split(",")) if os.environ.get("GSL_ACC_SEEDS") else S.ACC_SEEDS
+                seeds = seeds if dtype == "bf16" else seeds[:2]
                 with contextlib.redirect_stdout(io.StringIO()):
                     stat, cells = T.acc_stat_table(dtype, sname, golden, seeds)
                 n = len(cells) * S.ACC_STAT[sname]["n_per_split"]

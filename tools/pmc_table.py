@@ -18,16 +18,20 @@ def parse(path, counter):
 def main():
     tag, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3
     f, w = parse(f"{tag}/pmc_fetch.txt", "FETCH_SIZE"), parse(f"{tag}/pmc_write.txt", "WRITE_SIZE")
+    # MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (kernel cycles x 1024); kernel cycles = GRBM_GUI_ACTIVE / 8 (the
+    # counter comes back summed over the 8 XCDs). north_star: "rocprof must show ... MFMA utilisation on the fused FFN+LoRA GEMM".
+    busy, act = parse(f"{tag}/pmc_write.txt", "SQ_VALU_MFMA_BUSY_CYCLES"), parse(f"{tag}/pmc_write.txt", "GRBM_GUI_ACTIVE")
     rows, tot = [], 0.0
     for k in sorted(f):
         fe, n = f[k]
         mbf, mbw = 2 * fe * 1024 / 1e6, w.get(k, (0, 0))[0] * 1024 / 1e6
         tot += (mbf + mbw) * n / steps
         if mbf + mbw > 50:
-            rows.append((k, n, mbf, mbw))
-    print(f"| kernel | launches in {steps} steps | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | sum |\n|---|---|---|---|---|")
-    for k, n, a, b in rows:
-        print(f"| `{k[:80]}` | {n} | {a:.0f} | {b:.0f} | {a + b:.0f} |")
+            mf = 100.0 * busy[k][0] / (act[k][0] / 8.0 * 1024.0) if k in busy and k in act and act[k][0] > 0 else float("nan")
+            rows.append((k, n, mbf, mbw, mf))
+    print(f"| kernel | launches in {steps} steps | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | sum | MFMA busy % |\n|---|---|---|---|---|---|")
+    for k, n, a, b, mf in rows:
+        print(f"| `{k[:80]}` | {n} | {a:.0f} | {b:.0f} | {a + b:.0f} | {mf:.1f} |")
     print(f"\nsum over all kernels: **{tot / 1e3:.1f} GB per step**")
 
 

@@ -49,11 +49,12 @@ def run(mode, attrs):
 
 
 ref = run("fp32", {})
-CONFIGS = [("bf16 (default: bf16 streams, 8-bit GELU')", {}),
-           ("f32 forward residual stream", {"FWD_STREAM_BF16": False}),
+CONFIGS = [("bf16 (default: fp16 forward stream, bf16 gradient stream, 8-bit GELU')", {}),
+           ("bf16 forward residual stream (round 3)", {"FWD_STREAM": "bf16"}),
+           ("f32 forward residual stream", {"FWD_STREAM": "f32"}),
            ("f32 gradient residual stream", {"GRAD_STREAM_BF16": False}),
            ("bf16 GELU' instead of the 8-bit code", {"GP8": False}),
-           ("all three wide (round-2 precision)", {"FWD_STREAM_BF16": False, "GRAD_STREAM_BF16": False, "GP8": False}),
+           ("all three wide (round-2 precision)", {"FWD_STREAM": "f32", "GRAD_STREAM_BF16": False, "GP8": False}),
            ("dense last block (TAIL_CLS off)", {"TAIL_CLS": False})]
 print(f"FULL ViT-P8S8, batch {B}+{B}, against the f32 parity mode of the same path (loss {ref[3]:.5f})\n")
 print("| configuration | logits max abs (scale 64) | emb max abs | loss | LoRA grad rel. Frobenius | cosine | worst tensor rel. | dA1 / dB1 / dA2 / dB2 rel. |")
