@@ -1671,6 +1671,183 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
 }
 
+// The persistent form of the 8-phase kernel below is a MEASURED ALTERNATIVE, compiled only with -DGSL_P8_PERSISTENT=1 (python -m gslora_hip.build
+// --variant p8p -DGSL_P8_PERSISTENT=1): bit-identical to the per-tile kernel, and no faster — out-proj dX 137 -> 132 us, QKV 406 -> 420 us,
+// FFN1-dX 493 -> 507 us, step 23.29 -> 23.26 ms on the same box (profiles/r04_notes.md). What the prefetch under the epilogue and the
+// missing relaunch save comes back inside the K loop and the epilogue, whose stores share the CU's memory path with the prefetch.
+#ifndef GSL_P8_PERSISTENT
+#define GSL_P8_PERSISTENT 0
+#endif
+#if GSL_P8_PERSISTENT
+// One 1 KB LDS-DMA piece (global_load_lds_dwordx4: lane l's 16 bytes land at lds + 16 l) as inline assembly. The persistent kernel keeps
+// LDS-DMA requests in flight ACROSS its epilogue; with the builtin the compiler's waitcnt pass sees "an LDS-DMA may be pending" in front of
+// every ds_write of the epilogue staging (same __shared__ object: may alias) and inserts s_waitcnt vmcnt(0) there — which also waits for the
+// epilogue's own global stores, 64 times per tile. Behind inline assembly the requests are invisible to that pass; every wait on them in
+// this kernel is a hand-counted s_waitcnt anyway. (The pass's own vmcnt waits for the loads it does track can only wait for MORE than it
+// meant to: unknown younger requests add to the outstanding count.)
+__device__ __forceinline__ void lds_dma16(const void* g, const void* lds) {
+  const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)lds);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+
+// ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 8-phase schedule, PERSISTENT (round 4)
+// gemm_bf16_p8_kernel pays per tile: a workgroup launch behind the previous tile's store drain (2.4 - 4.8 k cycles), a prologue in which
+// the first seven half-tiles arrive with nothing to compute on (2.7 - 6 k), and an epilogue (7 - 25 k) during which the CU's LDS-DMA path —
+// the resource that bounds the K loop, profiles/r04_dma_ceiling.md — idles. Here one workgroup per CU walks tiles seq = blockIdx + i * grid
+// (xcd_remap(seq): the N-tiles of one A row panel still meet on one XCD) and, as soon as the K loop of a tile is done, requests K tile 0 of
+// the NEXT tile into stage A while the epilogue of the current tile runs out of the LDS above it (stage B's bytes + 9.7 KB: the staged
+// bf16 epilogue needs 73.7 KB); K tile 1's first three half-tiles follow once the staging is free. Same K loop, same fragments, same
+// epilogue code: bit-identical to gemm_bf16_p8_kernel. EPI: the staged bf16-output epilogues without a second LDS consumer (STORE incl.
+// the head-major QKV store).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(const bf16_t* __restrict__ A1, int lda1,
+                                                            const bf16_t* __restrict__ W1, int ldw1, int K1,
+                                                            const bf16_t* __restrict__ A2, int lda2,
+                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, int ntiles, EpiArgs e) {
+  resolve_drop(e.drop);
+  constexpr int STG = ST4;
+  constexpr int EOFF = STG;                                    // epilogue staging starts at stage B
+  constexpr int SMEM_E = EOFF + 8 * (CST_WAVE / 2);            // one bf16 output: 64 rows x 144 B per wave
+  static_assert(SMEM_E * 2 <= 163840, "LDS");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_E];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = (e.N + BN4 - 1) / BN4;
+  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
+  const int lrow = lane >> 3, lc = lane & 7;
+  constexpr int HT = 128 * BK;
+  int m0 = 0, n0 = 0;
+  int arow[2], brow[2], csw[2];
+  auto set_tile = [&](int seq) {
+    const int tile = xcd_remap(seq, ntiles);
+    m0 = (tile / nbn) * BM4; n0 = (tile % nbn) * BN4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wave * 2 + i) * 8 + lrow;
+      arow[i] = m0 + (r >> 6) * 128 + (r & 63);
+      brow[i] = n0 + (r >> 5) * 64 + (r & 31);
+      csw[i] = (lc ^ (r & 7)) * 8;
+    }
+  };
+  auto stage = [&](int kt, auto piece_c) {
+    constexpr int PIECE = decltype(piece_c)::value;
+    if (kt >= nk) return;
+    constexpr bool isA = PIECE & 1;
+    constexpr int half = PIECE >> 1;
+    bf16_t* dst = smem + (kt & 1) * STG + (isA ? 0 : BM4 * BK) + half * HT;
+    const bf16_t* base; int ld, k0;
+    if (kt < nk1) { base = isA ? A1 : W1; ld = isA ? lda1 : ldw1; k0 = kt * BK; }
+    else { base = isA ? A2 : W2; ld = isA ? lda2 : ldw2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
+      lds_dma16(base + (size_t)g * ld + k0 + csw[i], dst + (wave * 2 + i) * 8 * BK);
+    }
+  };
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
+  const int fr = lane & 15, fc = lane >> 4;
+  int aoff[4][2], boff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + fr; aoff[i][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int row = wn * 32 + j * 16 + fr; boff[j][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
+  }
+#define GSL_P8P_MFMA(RH, CH, BF)                                                                             \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+        acc[(RH) * 4 + i][(CH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+
+  constexpr int P8P_NST = 16;      // global stores per wave of the FULL staged bf16 epilogue: 2 rounds of 64 rows x 8 row groups
+  bool prev_full = false;
+  int seq = blockIdx.x;
+  if (seq >= ntiles) return;
+  set_tile(seq);
+  stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
+  for (; seq < ntiles; seq += gridDim.x) {
+    // K tile 0 of this tile is in flight (or landed); the first three half-tiles of K tile 1 follow now that stage B is free
+    stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
+    // K tile 0 must have landed. vmcnt retires in order and the previous tile's epilogue stores were issued BEHIND the K-tile-0 requests:
+    // waiting for "<= 6 outstanding" would also wait for the store drain (2 - 3 k cycles: the launch gap of the per-tile kernel in another
+    // place). A wave whose previous sub-tile was complete issued exactly P8P_NST stores (the FULL instance of the staged epilogue has no
+    // predication), so "<= 6 + P8P_NST outstanding" is the exact condition; everything else takes the conservative wait.
+    if (nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + P8P_NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    for (int kt = 0; kt < nk; ++kt) {
+      const bf16_t* As0 = smem + (kt & 1) * STG;
+      const bf16_t* As1 = As0 + HT;
+      const bf16_t* Bs0 = As0 + BM4 * BK;
+      const bf16_t* Bs1 = Bs0 + HT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf0[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs0 + boff[j][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(kt + 1, P3{});
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      GSL_P8P_MFMA(0, 0, bf0)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(kt + 2, P0{});
+      GSL_P8P_MFMA(0, 1, bf1)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(kt + 2, P1{});
+      GSL_P8P_MFMA(1, 1, bf1)
+      stage(kt + 2, P2{});
+      if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      GSL_P8P_MFMA(1, 0, bf0)
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
+    __builtin_amdgcn_s_barrier();                  // every wave is done with both stages
+    const int em0 = m0, en0 = n0;
+    const int nxt = seq + (int)gridDim.x;
+    if (nxt < ntiles) {                            // K tile 0 of the next tile streams into stage A under this tile's epilogue
+      set_tile(nxt);
+      stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
+    }
+    epilogue_staged_bf16<EPI, 8>(e, acc, smem + EOFF + wave * (CST_WAVE / 2), em0 + wm * 128, en0 + wn * 64, lane);
+    prev_full = (em0 + wm * 128 + 128 <= e.M) && (en0 + wn * 64 + 64 <= e.N) && e.out != nullptr;      // (the condition epilogue_staged_bf16 takes its FULL instance on)
+    __builtin_amdgcn_s_barrier();                  // the staging (stage B's bytes) is free again: every wave has READ its rows (stores may still be in flight)
+  }
+#undef GSL_P8P_MFMA
+}
+
+#endif  // GSL_P8_PERSISTENT
+
 #ifdef GSL_DEV
 #include "gemm_dev_b.inc"
 #endif
@@ -1828,6 +2005,18 @@ static inline int mrev_for(int key) {
 #endif
 }
 
+// workgroups of the persistent kernels: one per CU
+static inline int p8p_grid() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    n -= n % 8;      // xcd_remap of the sequence numbers assumes seq % 8 = blockIdx % 8
+    if (n < 8) n = 8;
+  }
+  return n;
+}
+
 template <int EPI>
 static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e_in, hipStream_t st) {
@@ -1918,6 +2107,17 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
           default: GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 11>), nb3, 512);
         }
         return check_launch("gsl_gemm_nt(ring3 ablation)");
+      }
+    }
+#endif
+#if GSL_P8_PERSISTENT
+    if constexpr (EPI == GSL_EPI_STORE) {
+      // plain-store GEMMs (QKV, out-proj dX, QKV dX, LoRA-free dX) with at least two rounds of tiles: the persistent form (see the kernel)
+      const int nt8 = ((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4);
+      if (variant == 8 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && nt8 >= 2 * p8p_grid()) {
+        hipLaunchKernelGGL((gemm_bf16_p8p_kernel<EPI>), dim3(p8p_grid()), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
+                           (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, nt8, e);
+        return check_launch("gsl_gemm_nt(p8p)");
       }
     }
 #endif
