@@ -63,6 +63,30 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
     *reinterpret_cast<uint4*>(dst + lds_off(t, c * 8)) = v;
   }
 }
+// two panels at once, every global load issued before the first LDS store: the rolled loop above waits for each 16-byte load before it
+// stores it (load, s_waitcnt vmcnt(0), ds_write per iteration: 8 serialised HBM round trips for a K + V pair, ~14 k of the 57 k cycles
+// a fused-backward workgroup lives — profiles/r04_notes.md). NT = threads of the workgroup.
+template <int TP, int NT>
+__device__ __forceinline__ void stage_rowmajor2(bf16_t* d0, const bf16_t* s0, bf16_t* d1, const bf16_t* s1, long ld, int T) {
+  constexpr int NIT = (TP * 8 + NT - 1) / NT;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t v0[NIT], v1[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * NT, t = min(idx >> 3, T - 1), c = idx & 7;
+    v0[it] = *reinterpret_cast<const u32x4_t*>(s0 + (size_t)t * ld + c * 8);
+    v1[it] = *reinterpret_cast<const u32x4_t*>(s1 + (size_t)t * ld + c * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * NT, t = idx >> 3, c = idx & 7;
+    if (idx < TP * 8) {
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4_t*>(d0 + lds_off(t, c * 8)) = (t < T) ? v0[it] : z;
+      *reinterpret_cast<u32x4_t*>(d1 + lds_off(t, c * 8)) = (t < T) ? v1[it] : z;
+    }
+  }
+}
 __device__ __forceinline__ bf16x8_t lds_frag_rm(const bf16_t* base, int row, int ks, int fc) {
   return *reinterpret_cast<const bf16x8_t*>(base + lds_off(row, ks * 32 + fc * 8));
 }
@@ -590,11 +614,11 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
       of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
     };
     load_tile(wave);
-    stage_rowmajor<TP>(P0, qb + ko, ldi, T);
-    stage_rowmajor<TP>(P1, qb + 2 * ko, ldi, T);
-    for (int t = threadIdx.x; t < TP; t += blockDim.x) {
-      lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;
-      del_s[t] = 0.f;
+    const float lse_v = (threadIdx.x < TP && (int)threadIdx.x < T) ? lse[((size_t)b * H + h) * T + threadIdx.x] : 0.f;      // (requested with the panels)
+    stage_rowmajor2<TP, NT>(P0, qb + ko, P1, qb + 2 * ko, ldi, T);
+    if (threadIdx.x < TP) {
+      lse_s[threadIdx.x] = ((int)threadIdx.x < T) ? lse_v * 1.4426950408889634f : 1.0e30f;
+      del_s[threadIdx.x] = 0.f;
     }
     __syncthreads();
     GSL_ATTN_STAMP(1);
@@ -807,39 +831,92 @@ __device__ __forceinline__ float dot64(const float a[64], const float* b) {
   return s;
 }
 
+// f32 forward on the matrix cores (round 4: the engines evaluate in f32 by default, and the thread-per-query kernel this replaces —
+// q in registers, sequential fmaf over d, two passes over the keys — was 31 % of an f32 evaluation batch: 13.3 ms per layer at 2 560 images). v_mfma_f32_16x16x4_f32 is an exact-f32 k-ordered fmaf chain, so the scores
+// S = q . k are BIT-IDENTICAL to a sequential fmaf over d (dot64() above, which the f32 backward kernels use), and so are the row maximum and every expf argument; the sums over the
+// keys (l and the P V accumulation) run in a different — still exact f32 — order. Same structure as the bf16 kernels: scores transposed
+// (S^T = K Q^T: a lane owns one query column), all key tiles of a query tile in registers, two-pass softmax, O^T = V^T P^T with the
+// k-slot permutation slot g <-> key 4 g + r so that register r of a score tile IS the B operand of step r. K / V panels row-major in LDS
+// with 68-float rows (both fragment reads conflict-free). 8 waves, one workgroup per (image, head).
+constexpr int FLD = 68;
 template <int TP>
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                           float* __restrict__ lse, int T, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[TP * HD];
-  __shared__ __attribute__((aligned(16))) float Vs[TP * HD];
+__global__ __launch_bounds__(512) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                float* __restrict__ lse, int T, int H, float scale) {
+  constexpr int NKT = TP / 16;
+  __shared__ __attribute__((aligned(16))) float Ks[TP * FLD];
+  __shared__ __attribute__((aligned(16))) float Vs[TP * FLD];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long ld = 3L * H * HD;
   const float* qb = qkv + (size_t)b * T * ld + h * HD;
-  stage_f32<TP>(Ks, qb + H * HD, ld, T);
-  stage_f32<TP>(Vs, qb + 2 * H * HD, ld, T);
-  __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= T) return;
-  float q[64], acc[64];
-  load_row64(qb + (size_t)i * ld, q);
-  // pass 1: row max (plain two-pass softmax, as torch computes it)
-  float m = -3.0e38f;
-  for (int j = 0; j < T; ++j) m = fmaxf(m, dot64(q, Ks + j * HD) * scale);
-  float l = 0.f;
+  {      // both panels, every load in flight before the first LDS store; rows >= T are zero
+    constexpr int NIT = (TP * 16 + 511) / 512;
+    float4 kv[NIT], vv[NIT];
 #pragma unroll
-  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
-  for (int j = 0; j < T; ++j) {
-    const float p = expf(dot64(q, Ks + j * HD) * scale - m);
-    l += p;
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = threadIdx.x + it * 512, t = min(idx >> 4, T - 1), c = idx & 15;
+      kv[it] = *reinterpret_cast<const float4*>(qb + (size_t)t * ld + H * HD + c * 4);
+      vv[it] = *reinterpret_cast<const float4*>(qb + (size_t)t * ld + 2 * H * HD + c * 4);
+    }
 #pragma unroll
-    for (int d = 0; d < 64; ++d) acc[d] = fmaf(p, Vs[j * HD + d], acc[d]);
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = threadIdx.x + it * 512, t = idx >> 4, c = idx & 15;
+      if (idx < TP * 16) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Ks + t * FLD + c * 4) = (t < T) ? kv[it] : z;
+        *reinterpret_cast<float4*>(Vs + t * FLD + c * 4) = (t < T) ? vv[it] : z;
+      }
+    }
   }
-  const float inv = 1.0f / l;
-  float* orow = o + ((size_t)b * T + i) * (H * HD) + h * HD;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+  const int nqt = (T + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 8) {
+    const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
+    float q[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
-    *reinterpret_cast<float4*>(orow + c * 4) = make_float4(acc[c * 4] * inv, acc[c * 4 + 1] * inv, acc[c * 4 + 2] * inv, acc[c * 4 + 3] * inv);
-  lse[((size_t)b * H + h) * T + i] = m + logf(l);
+    for (int st = 0; st < 16; ++st) q[st] = qb[(size_t)qrc * ld + 4 * st + g];
+    f32x4_t sc[NKT];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      const float* kp = Ks + (kt * 16 + fr) * FLD + g;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * st], q[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[r] = (kt * 16 + 4 * g + r < T) ? acc[r] * scale : -3.0e38f;      // (dot * scale, as the f32 backward kernels recompute it)
+        m = fmaxf(m, acc[r]);
+      }
+      sc[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = (kt * 16 + 4 * g + r < T) ? expf(sc[kt][r] - m) : 0.f;
+        sc[kt][r] = pv; l += pv;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * FLD + dt * 16 + fr], sc[kt][r], oacc, 0, 0, 0);
+      if (qr < T)
+        *reinterpret_cast<float4*>(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + 4 * g) =
+            make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
+    }
+    if (g == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m + logf(l);
+  }
 }
 
 template <int TP>
@@ -1151,8 +1228,8 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
     else if (B * H < attn_num_cus()) hipLaunchKernelGGL((attn_fwd_bf16_kernel<14, 1024>), grid, dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
   } else if (dtype == GSL_F32) {
-    if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
-    else hipLaunchKernelGGL(attn_fwd_f32_kernel<224>, grid, blk, 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
+    if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel<64>, grid, dim3(512), 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel<224>, grid, dim3(512), 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
   } else return fail(GSL_ERR_ARG, "gsl_attention_fwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_fwd");
 }

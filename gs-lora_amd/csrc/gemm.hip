@@ -169,7 +169,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
       const float a = v[i] + bq[i];
       float ga, gpa;
       if constexpr (sizeof(T) == 2) gelu_pair_fast(a, ga, gpa);      // bf16 speed mode
-      else { ga = gelu_f(a); gpa = gelu_grad_f(a); }                  // f32 parity mode: exact erf
+      else { ga = gelu_f(a); gpa = e.out2 ? gelu_grad_f(a) : 0.f; }   // f32 parity mode: exact erf (no second output in eval mode: GELU' is skipped, wave-uniformly)
       v[i] = ga * dm[i];
       g[i] = gpa * dm[i];
     }
