@@ -808,13 +808,24 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
 // =====================================================================================
 // f32 parity kernels: thread per query / per key, panels broadcast from LDS
 // =====================================================================================
+// (256-thread workgroups; the loads of a batch of 7 iterations are all requested before the first LDS store — a rolled
+//  load / wait / store loop serialises one HBM round trip per iteration, see stage_rowmajor2)
 template <int TP>
 __device__ __forceinline__ void stage_f32(float* dst, const float* src, long ld, int T) {
-  for (int idx = threadIdx.x; idx < TP * 16; idx += blockDim.x) {
-    const int t = idx >> 4, c = idx & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < T) v = *reinterpret_cast<const float4*>(src + (size_t)t * ld + c * 4);
-    *reinterpret_cast<float4*>(dst + t * HD + c * 4) = v;
+  constexpr int NIT = (TP * 16 + 255) / 256, NB = 7;
+#pragma unroll
+  for (int i0 = 0; i0 < NIT; i0 += NB) {
+    float4 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int idx = threadIdx.x + (i0 + k) * 256, t = min(idx >> 4, T - 1), c = idx & 15;
+      if (i0 + k < NIT) v[k] = *reinterpret_cast<const float4*>(src + (size_t)t * ld + c * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int idx = threadIdx.x + (i0 + k) * 256, t = idx >> 4, c = idx & 15;
+      if (i0 + k < NIT && idx < TP * 16) *reinterpret_cast<float4*>(dst + t * HD + c * 4) = (t < T) ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 __device__ __forceinline__ void load_row64(const float* p, float v[64]) {
