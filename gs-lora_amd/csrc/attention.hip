@@ -68,6 +68,11 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
 // a fused-backward workgroup lives — profiles/r04_notes.md). NT = threads of the workgroup.
 template <int TP, int NT>
 __device__ __forceinline__ void stage_rowmajor2(bf16_t* d0, const bf16_t* s0, bf16_t* d1, const bf16_t* s1, long ld, int T) {
+#ifdef GSL_ATTN_ROLLED
+  stage_rowmajor<TP>(d0, s0, ld, T);
+  stage_rowmajor<TP>(d1, s1, ld, T);
+  return;
+#endif
   constexpr int NIT = (TP * 8 + NT - 1) / NT;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t v0[NIT], v1[NIT];
@@ -84,6 +89,38 @@ __device__ __forceinline__ void stage_rowmajor2(bf16_t* d0, const bf16_t* s0, bf
       const u32x4_t z = {0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4_t*>(d0 + lds_off(t, c * 8)) = (t < T) ? v0[it] : z;
       *reinterpret_cast<u32x4_t*>(d1 + lds_off(t, c * 8)) = (t < T) ? v1[it] : z;
+    }
+  }
+}
+// the same for the per-item kernels, whose workgroup size is a launch parameter (>= MINT threads) and whose two panels may have different
+// row strides: iteration count for MINT threads, the stride is blockDim.x, out-of-range iterations are predicated off. (With the count for
+// 256 threads the 1024-thread forward of the few-shot regime carried 14 dead vector registers sets and SPILLED: 0.84 -> 1.00 ms per step.)
+template <int TP, int MINT>
+__device__ __forceinline__ void stage_rowmajor2_rt(bf16_t* d0, const bf16_t* s0, long ld0, bf16_t* d1, const bf16_t* s1, long ld1, int T) {
+#ifdef GSL_ATTN_ROLLED      // A/B builds only: the rolled load / wait / store loops of rounds 1 - 3
+  stage_rowmajor<TP>(d0, s0, ld0, T);
+  stage_rowmajor<TP>(d1, s1, ld1, T);
+  return;
+#endif
+  constexpr int NIT = (TP * 8 + MINT - 1) / MINT;      // MINT = the smallest workgroup the kernel is launched with
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t v0[NIT], v1[NIT];
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x, t = idx >> 3, c = idx & 7;
+    v0[it] = z; v1[it] = z;
+    if (idx < TP * 8 && t < T) {
+      v0[it] = *reinterpret_cast<const u32x4_t*>(s0 + (size_t)t * ld0 + c * 8);
+      v1[it] = *reinterpret_cast<const u32x4_t*>(s1 + (size_t)t * ld1 + c * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x, t = idx >> 3, c = idx & 7;
+    if (idx < TP * 8) {
+      *reinterpret_cast<u32x4_t*>(d0 + lds_off(t, c * 8)) = v0[it];
+      *reinterpret_cast<u32x4_t*>(d1 + lds_off(t, c * 8)) = v1[it];
     }
   }
 }
@@ -149,10 +186,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void attn_fwd_bf16_kernel(
     const bf16_t* qrow = qb + (size_t)min(wave * 16 + fr, T - 1) * ldi;
     qn0 = gl_frag(qrow, 0, fc); qn1 = gl_frag(qrow, 1, fc);
   }
-  if (abl != 2) {
-    stage_rowmajor<TP>(Ks, qb + ko, ldi, T);
-    stage_rowmajor<TP>(Vs, qb + 2 * ko, ldi, T);
-  }
+  if (abl != 2) stage_rowmajor2_rt<TP, (NKT == 4 ? 256 : NT)>(Ks, qb + ko, ldi, Vs, qb + 2 * ko, ldi, T);
   __syncthreads();
   if (abl == 1) return;
   const int nqt = (T + 15) / 16;
@@ -393,10 +427,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     of0.v = gl_frag(orow, 0, fc); of1.v = gl_frag(orow, 1, fc);
   };
   load_tile(wave);
-  if (abl != 2) {
-    stage_rowmajor<TP>(Ks, qb + ko, ldi, T);
-    stage_rowmajor<TP>(Vs, qb + 2 * ko, ldi, T);
-  }
+  if (abl != 2) stage_rowmajor2_rt<TP, (NKT == 4 ? 256 : 512)>(Ks, qb + ko, ldi, Vs, qb + 2 * ko, ldi, T);
   __syncthreads();
   if (abl == 1) return;
   const int nqt = (T + 15) / 16;
@@ -483,10 +514,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
     }
   };
   load_keys(wave);
-  if (abl != 2) {
-    stage_rowmajor<TP>(Qs, qb, ldi, T);
-    stage_rowmajor<TP>(Os, dob, ldo, T);
-  }
+  if (abl != 2) stage_rowmajor2_rt<TP, (NKT == 4 ? 256 : 512)>(Qs, qb, ldi, Os, dob, ldo, T);
   for (int t = threadIdx.x; t < TP; t += blockDim.x) {
     lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] * 1.4426950408889634f : 1.0e30f;   // log2 units; padded queries -> p = 0
     del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
@@ -815,16 +843,18 @@ __device__ __forceinline__ void stage_f32(float* dst, const float* src, long ld,
   constexpr int NIT = (TP * 16 + 255) / 256, NB = 7;
 #pragma unroll
   for (int i0 = 0; i0 < NIT; i0 += NB) {
-    float4 v[NB];
+    f32x4_t v[NB];
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int idx = threadIdx.x + (i0 + k) * 256, t = min(idx >> 4, T - 1), c = idx & 15;
-      if (i0 + k < NIT) v[k] = *reinterpret_cast<const float4*>(src + (size_t)t * ld + c * 4);
+      v[k] = z;
+      if (i0 + k < NIT) v[k] = *reinterpret_cast<const f32x4_t*>(src + (size_t)t * ld + c * 4);
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int idx = threadIdx.x + (i0 + k) * 256, t = idx >> 4, c = idx & 15;
-      if (i0 + k < NIT && idx < TP * 16) *reinterpret_cast<float4*>(dst + t * HD + c * 4) = (t < T) ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + k < NIT && idx < TP * 16) *reinterpret_cast<f32x4_t*>(dst + t * HD + c * 4) = (t < T) ? v[k] : z;
     }
   }
 }
@@ -851,7 +881,7 @@ __device__ __forceinline__ float dot64(const float a[64], const float* b) {
 // with 68-float rows (both fragment reads conflict-free). 8 waves, one workgroup per (image, head).
 constexpr int FLD = 68;
 template <int TP>
-__global__ __launch_bounds__(512) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+__global__ __launch_bounds__(512, 2) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                 float* __restrict__ lse, int T, int H, float scale) {
   constexpr int NKT = TP / 16;
   __shared__ __attribute__((aligned(16))) float Ks[TP * FLD];
@@ -861,20 +891,20 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_mfma_kernel(const float* __r
   const float* qb = qkv + (size_t)b * T * ld + h * HD;
   {      // both panels, every load in flight before the first LDS store; rows >= T are zero
     constexpr int NIT = (TP * 16 + 511) / 512;
-    float4 kv[NIT], vv[NIT];
+    f32x4_t kv[NIT], vv[NIT];      // (ext vectors: HIP's float4 struct behind a select ends up in scratch memory)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 512, t = min(idx >> 4, T - 1), c = idx & 15;
-      kv[it] = *reinterpret_cast<const float4*>(qb + (size_t)t * ld + H * HD + c * 4);
-      vv[it] = *reinterpret_cast<const float4*>(qb + (size_t)t * ld + 2 * H * HD + c * 4);
+      kv[it] = *reinterpret_cast<const f32x4_t*>(qb + (size_t)t * ld + H * HD + c * 4);
+      vv[it] = *reinterpret_cast<const f32x4_t*>(qb + (size_t)t * ld + 2 * H * HD + c * 4);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 512, t = idx >> 4, c = idx & 15;
       if (idx < TP * 16) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Ks + t * FLD + c * 4) = (t < T) ? kv[it] : z;
-        *reinterpret_cast<float4*>(Vs + t * FLD + c * 4) = (t < T) ? vv[it] : z;
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4_t*>(Ks + t * FLD + c * 4) = (t < T) ? kv[it] : z;
+        *reinterpret_cast<f32x4_t*>(Vs + t * FLD + c * 4) = (t < T) ? vv[it] : z;
       }
     }
   }
@@ -900,6 +930,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_mfma_kernel(const float* __r
         m = fmaxf(m, acc[r]);
       }
       sc[kt] = acc;
+      __builtin_amdgcn_sched_barrier(0);      // (keeps the 224 fragment reads of the unrolled key loop from being hoisted into one register-spilling batch)
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -920,8 +951,10 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_mfma_kernel(const float* __r
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
           oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * FLD + dt * 16 + fr], sc[kt][r], oacc, 0, 0, 0);
+          if (r == 3 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
       if (qr < T)
         *reinterpret_cast<float4*>(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + 4 * g) =
             make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
