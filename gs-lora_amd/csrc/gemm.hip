@@ -96,7 +96,7 @@ __device__ __forceinline__ void g8_unpack4(uint32_t w, float sq, float g[4]) {
 // VALU issue (profiles/r03_h_wg_timeline.md: 30 k cycles per 256x256 tile with the matrix pipe idle; ~27 instructions per element, 14 of
 // them the A&S erf / exp / rcp pair, computed to 1.5e-7 for a value that is stored as bf16 and an 8-bit code). tools/gen_gelu_table.py:
 // entry i = { f32 bits of Phi(a_i) with a 16-bit mantissa | 8-bit GELU'(a_i) code }, a_i = -4.5 + i * 9 / 4095. The workgroup copies the
-// 16 KB table into LDS behind the K-loop stages (16 LDS-DMA pieces in front of the prologue), the epilogue clamps, scales and truncates
+// 16 KB table into LDS behind the K-loop stages (16 LDS-DMA pieces behind the prologue's requests), the epilogue clamps, scales and truncates
 // the pre-activation into a byte address (v_med3, v_fma, v_cvt_u32, v_and), gathers with ds_read_b32, applies the dropout mask to the
 // ENTRY (one v_cndmask for both outputs: a dropped element takes {Phi = 0, code 26}) and multiplies a / (1 - p) with the entry read as a
 // float (the code byte is < 2^-15 relative noise). Error of Phi at the nearest grid point <= phi(0) * 0.0011 = 4.5e-4 (a quarter of the bf16
@@ -1368,19 +1368,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   constexpr unsigned long long* dbg8 = nullptr;
 #endif
   if (dbg8) dbg8[0] = __builtin_readcyclecounter();
-  if constexpr (TAB) {      // the GELU table: 16 pieces of 1 KB, two per wave, in front of the prologue (retired by its counted wait, seen by every wave behind the K loop's barriers)
-#pragma unroll
+  // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
+  stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
+  stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
+  if constexpr (TAB) {      // the GELU table: 16 pieces of 1 KB, two per wave, BEHIND the prologue's requests (K tile 0 is not delayed by it); the
+#pragma unroll             // counted wait below leaves them in flight, the K loop's first counted wait (step 0, q3) retires them in order
     for (int i = 0; i < 2; ++i) {
       const int piece = wave * 2 + i;
       __builtin_amdgcn_global_load_lds((gptr_t)(GELU_G8_TAB + piece * 256 + lane * 4), (lptr_t)(smem + 2 * STG + piece * 512), 16, 0, 0);
     }
   }
-  // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
-  stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
-  stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
+  constexpr int TABP = TAB ? 2 : 0;
   if (nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 + TABP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + TABP) : "memory");
   __builtin_amdgcn_s_barrier();
   if (dbg8) dbg8[1] = __builtin_readcyclecounter();
   if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
