@@ -21,7 +21,8 @@
 //   * forward, T in (64, 208] and enough (image, head) items: a persistent wave-specialised kernel
 //     (attn_fwd_bf16_pers_kernel: 13 compute waves + 3 loader waves per CU) streams the next item's
 //     panels under the current item's softmax; bit-identical to the one-item-per-workgroup kernel.
-// f32 path (parity mode): thread-per-row VALU kernels with LDS-broadcast panels; exact f32.
+// f32 path (parity mode): v_mfma_f32_16x16x4_f32 kernels (exact f32: a k-ordered fmaf chain per output), K / V or Q / dO panels in LDS;
+//   the cls-query kernels of the last block are templated on the element type.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -834,47 +835,11 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
 #undef GSL_ATTN_STAMP
 
 // =====================================================================================
-// f32 parity kernels: thread per query / per key, panels broadcast from LDS
+// f32 parity kernels (matrix cores, round 4; the thread-per-row VALU kernels of rounds 1 - 3 are gone)
 // =====================================================================================
-// (256-thread workgroups; the loads of a batch of 7 iterations are all requested before the first LDS store — a rolled
-//  load / wait / store loop serialises one HBM round trip per iteration, see stage_rowmajor2)
-template <int TP>
-__device__ __forceinline__ void stage_f32(float* dst, const float* src, long ld, int T) {
-  constexpr int NIT = (TP * 16 + 255) / 256, NB = 7;
-#pragma unroll
-  for (int i0 = 0; i0 < NIT; i0 += NB) {
-    f32x4_t v[NB];
-    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const int idx = threadIdx.x + (i0 + k) * 256, t = min(idx >> 4, T - 1), c = idx & 15;
-      v[k] = z;
-      if (i0 + k < NIT) v[k] = *reinterpret_cast<const f32x4_t*>(src + (size_t)t * ld + c * 4);
-    }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const int idx = threadIdx.x + (i0 + k) * 256, t = idx >> 4, c = idx & 15;
-      if (i0 + k < NIT && idx < TP * 16) *reinterpret_cast<f32x4_t*>(dst + t * HD + c * 4) = (t < T) ? v[k] : z;
-    }
-  }
-}
-__device__ __forceinline__ void load_row64(const float* p, float v[64]) {
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const float4 t = *reinterpret_cast<const float4*>(p + c * 4);
-    v[c * 4] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
-  }
-}
-__device__ __forceinline__ float dot64(const float a[64], const float* b) {
-  float s = 0.f;
-#pragma unroll
-  for (int d = 0; d < 64; ++d) s = fmaf(a[d], b[d], s);
-  return s;
-}
-
 // f32 forward on the matrix cores (round 4: the engines evaluate in f32 by default, and the thread-per-query kernel this replaces —
 // q in registers, sequential fmaf over d, two passes over the keys — was 31 % of an f32 evaluation batch: 13.3 ms per layer at 2 560 images). v_mfma_f32_16x16x4_f32 is an exact-f32 k-ordered fmaf chain, so the scores
-// S = q . k are BIT-IDENTICAL to a sequential fmaf over d (dot64() above, which the f32 backward kernels use), and so are the row maximum and every expf argument; the sums over the
+// S = q . k are BIT-IDENTICAL to a sequential fmaf over d ascending from 0 (what the thread-per-row kernels of rounds 1 - 3 computed), and so are the row maximum and every expf argument; the sums over the
 // keys (l and the P V accumulation) run in a different — still exact f32 — order. Same structure as the bf16 kernels: scores transposed
 // (S^T = K Q^T: a lane owns one query column), all key tiles of a query tile in registers, two-pass softmax, O^T = V^T P^T with the
 // k-slot permutation slot g <-> key 4 g + r so that register r of a score tile IS the B operand of step r. K / V panels row-major in LDS
@@ -918,18 +883,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_f32_mfma_kernel(const float* 
     for (int st = 0; st < 16; ++st) q[st] = qb[(size_t)qrc * ld + 4 * st + g];
     f32x4_t sc[NKT];
     float m = -3.0e38f;
+    static_assert(NKT % 2 == 0, "key tiles are processed in pairs");
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < NKT; kt += 2) {      // two key tiles = two independent accumulator chains (a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32)
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const float* kp = Ks + (kt * 16 + fr) * FLD + g;
 #pragma unroll
-      for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * st], q[st], acc, 0, 0, 0);
+      for (int st = 0; st < 16; ++st) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * st], q[st], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[16 * FLD + 4 * st], q[st], acc1, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[r] = (kt * 16 + 4 * g + r < T) ? acc[r] * scale : -3.0e38f;      // (dot * scale, as the f32 backward kernels recompute it)
-        m = fmaxf(m, acc[r]);
+        acc0[r] = (kt * 16 + 4 * g + r < T) ? acc0[r] * scale : -3.0e38f;      // (dot * scale, as the backward kernels recompute it)
+        acc1[r] = (kt * 16 + 16 + 4 * g + r < T) ? acc1[r] * scale : -3.0e38f;
+        m = fmaxf(m, fmaxf(acc0[r], acc1[r]));
       }
-      sc[kt] = acc;
+      sc[kt] = acc0; sc[kt + 1] = acc1;
       __builtin_amdgcn_sched_barrier(0);      // (keeps the 224 fragment reads of the unrolled key loop from being hoisted into one register-spilling batch)
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -945,100 +915,192 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_f32_mfma_kernel(const float* 
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    f32x4_t oacc[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4_t oacc = {0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * FLD + dt * 16 + fr], sc[kt][r], oacc, 0, 0, 0);
-          if (r == 3 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);
-        }
-      if (qr < T)
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)      // four independent accumulator chains
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * FLD + dt * 16 + fr], sc[kt][r], oacc[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qr < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
         *reinterpret_cast<float4*>(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + 4 * g) =
-            make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
+            make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
     }
     if (g == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m + logf(l);
   }
 }
 
+// ---- f32 backward on the matrix cores (round 4; same operand layouts and k-slot permutation as attn_fwd_f32_mfma_kernel). The thread-per-row
+// kernels of this section took 22 ms per layer at 1 024 images — 39 % of an f32 training step; here a layer is two launches:
+//   dQ:   waves own query tiles; K / V panels in LDS. S^T = K Q^T and dP^T = V dO^T (16 + 16 MFMAs per key tile), p = expf(S scale - lse),
+//         dS = p (dP - delta) scale in C layout = the B operand of dQ^T += K^T dS^T (slot g <-> key 4 g + r); delta = rowsum(dO o) goes to
+//         the workspace the dK / dV launch reads.
+//   dK/dV: waves own key tiles; Q / dO panels in LDS. S = Q K^T and dP = dO V^T with the roles swapped (a lane owns a key column and four
+//         queries), then dV^T += dO^T P and dK^T += Q^T dS over all query tiles.
+// Scores and dP are k-ordered fmaf chains over d ascending; sums over keys / queries run in slot order (exact f32).
 template <int TP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                              float* __restrict__ dqkv, float* __restrict__ delta, int T, int H,
-                                                              float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[TP * HD];
-  __shared__ __attribute__((aligned(16))) float Vs[TP * HD];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const float* qb = qkv + (size_t)b * T * ld + h * HD;
-  stage_f32<TP>(Ks, qb + H * HD, ld, T);
-  stage_f32<TP>(Vs, qb + 2 * H * HD, ld, T);
-  __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= T) return;
-  float q[64], g[64], acc[64];
-  load_row64(qb + (size_t)i * ld, q);
-  load_row64(d_o + ((size_t)b * T + i) * ldo + h * HD, g);
-  const float dl = dot64(g, o + ((size_t)b * T + i) * ldo + h * HD);
-  const float lq = lse[((size_t)b * H + h) * T + i];
+__device__ __forceinline__ void stage_f32_pad2(float* d0, const float* s0, long ld0, float* d1, const float* s1, long ld1, int T) {
+  constexpr int NIT = (TP * 16 + 511) / 512;      // 512-thread workgroups; rows of FLD floats; rows >= T are zero
+  f32x4_t a[NIT], c[NIT];
 #pragma unroll
-  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
-  for (int j = 0; j < T; ++j) {
-    const float p = expf(dot64(q, Ks + j * HD) * scale - lq);
-    const float ds = p * (dot64(g, Vs + j * HD) - dl) * scale;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) acc[d] = fmaf(ds, Ks[j * HD + d], acc[d]);
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * 512, t = min(idx >> 4, T - 1), ch = idx & 15;
+    a[it] = *reinterpret_cast<const f32x4_t*>(s0 + (size_t)t * ld0 + ch * 4);
+    c[it] = *reinterpret_cast<const f32x4_t*>(s1 + (size_t)t * ld1 + ch * 4);
   }
-  float* out = dqkv + ((size_t)b * T + i) * ld + h * HD;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
-    *reinterpret_cast<float4*>(out + c * 4) = make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
-  delta[((size_t)b * H + h) * T + i] = dl;
-}
-
-// WHICH = 0: dK (slot 1 of dqkv), WHICH = 1: dV (slot 2)
-template <int TP, int WHICH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv, int T, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) float Qs[TP * HD];
-  __shared__ __attribute__((aligned(16))) float Gs[TP * HD];   // dO
-  __shared__ float lse_s[TP];
-  __shared__ float del_s[TP];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * HD, ldo = (long)H * HD;
-  const float* qb = qkv + (size_t)b * T * ld + h * HD;
-  stage_f32<TP>(Qs, qb, ld, T);
-  stage_f32<TP>(Gs, d_o + (size_t)b * T * ldo + h * HD, ldo, T);
-  for (int t = threadIdx.x; t < TP; t += blockDim.x) {
-    lse_s[t] = (t < T) ? lse[((size_t)b * H + h) * T + t] : 0.f;
-    del_s[t] = (t < T) ? delta[((size_t)b * H + h) * T + t] : 0.f;
-  }
-  __syncthreads();
-  const int j = threadIdx.x;
-  if (j >= T) return;
-  float k[64], v[64], acc[64];
-  load_row64(qb + (size_t)j * ld + H * HD, k);
-  if (WHICH == 0) load_row64(qb + (size_t)j * ld + 2 * H * HD, v);
-#pragma unroll
-  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
-  for (int i = 0; i < T; ++i) {
-    const float p = expf(dot64(k, Qs + i * HD) * scale - lse_s[i]);
-    if (WHICH == 0) {
-      const float ds = p * (dot64(v, Gs + i * HD) - del_s[i]) * scale;
-#pragma unroll
-      for (int d = 0; d < 64; ++d) acc[d] = fmaf(ds, Qs[i * HD + d], acc[d]);
-    } else {
-#pragma unroll
-      for (int d = 0; d < 64; ++d) acc[d] = fmaf(p, Gs[i * HD + d], acc[d]);
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + it * 512, t = idx >> 4, ch = idx & 15;
+    if (idx < TP * 16) {
+      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4_t*>(d0 + t * FLD + ch * 4) = (t < T) ? a[it] : z;
+      *reinterpret_cast<f32x4_t*>(d1 + t * FLD + ch * 4) = (t < T) ? c[it] : z;
     }
   }
-  float* out = dqkv + ((size_t)b * T + j) * ld + h * HD + (WHICH == 0 ? H * HD : 2 * H * HD);
+}
+
+template <int TP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                     const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                     float* __restrict__ dqkv, float* __restrict__ delta, int T, int H, float scale) {
+  constexpr int NKT = TP / 16;
+  __shared__ __attribute__((aligned(16))) float Ks[TP * FLD];
+  __shared__ __attribute__((aligned(16))) float Vs[TP * FLD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const float* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_f32_pad2<TP>(Ks, qb + H * HD, ld, Vs, qb + 2 * H * HD, ld, T);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+  const int nqt = (T + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 8) {
+    const int qr = qt * 16 + fr, qrc = min(qr, T - 1);
+    const float* gr = d_o + ((size_t)b * T + qrc) * ldo + h * HD;
+    const float* orow = o + ((size_t)b * T + qrc) * ldo + h * HD;
+    float q[16], gq[16];
+    float dl = 0.f;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
-    *reinterpret_cast<float4*>(out + c * 4) = make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
+    for (int st = 0; st < 16; ++st) {
+      q[st] = qb[(size_t)qrc * ld + 4 * st + g];
+      gq[st] = gr[4 * st + g];
+      dl = fmaf(gq[st], orow[4 * st + g], dl);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float lq = lse[((size_t)b * H + h) * T + qrc];
+    f32x4_t dsr[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      const float* kp = Ks + (kt * 16 + fr) * FLD + g;
+      const float* vp = Vs + (kt * 16 + fr) * FLD + g;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * st], q[st], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[4 * st], gq[st], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = (kt * 16 + 4 * g + r < T) ? expf(sa[r] * scale - lq) : 0.f;
+        dsr[kt][r] = pv * (dp[r] - dl) * scale;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4_t dqa[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(kt * 16 + 4 * g + r) * FLD + dt * 16 + fr], dsr[kt][r], dqa[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qr < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(dqkv + ((size_t)b * T + qr) * ld + h * HD + dt * 16 + 4 * g) = dqa[dt];
+    }
+    if (g == 0 && qr < T) delta[((size_t)b * H + h) * T + qr] = dl;
+  }
+}
+
+template <int TP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                      float* __restrict__ dqkv, int T, int H, float scale) {
+  constexpr int NQT = TP / 16;
+  __shared__ __attribute__((aligned(16))) float Qs[TP * FLD];
+  __shared__ __attribute__((aligned(16))) float Gs[TP * FLD];   // dO
+  __shared__ __attribute__((aligned(16))) float lse_s[TP];
+  __shared__ __attribute__((aligned(16))) float del_s[TP];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const float* qb = qkv + (size_t)b * T * ld + h * HD;
+  stage_f32_pad2<TP>(Qs, qb, ld, Gs, d_o + (size_t)b * T * ldo + h * HD, ldo, T);
+  if (threadIdx.x < TP) {
+    const bool in = (int)threadIdx.x < T;
+    lse_s[threadIdx.x] = in ? lse[((size_t)b * H + h) * T + threadIdx.x] : 0.f;
+    del_s[threadIdx.x] = in ? delta[((size_t)b * H + h) * T + threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+  const int nkt = (T + 15) / 16;
+  for (int kp = wave; kp < nkt; kp += 8) {
+    const int kr = kp * 16 + fr, krc = min(kr, T - 1);
+    float k[16], v[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      k[st] = qb[(size_t)krc * ld + H * HD + 4 * st + g];
+      v[st] = qb[(size_t)krc * ld + 2 * H * HD + 4 * st + g];
+    }
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+    for (int qt = 0; qt < NQT; ++qt) {
+      f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      const float* qp = Qs + (qt * 16 + fr) * FLD + g;
+      const float* gp = Gs + (qt * 16 + fr) * FLD + g;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qp[4 * st], k[st], sa, 0, 0, 0);      // D[query 4 g + r][key fr]
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[4 * st], v[st], dp, 0, 0, 0);
+      }
+      const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(&lse_s[qt * 16 + 4 * g]);
+      const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(&del_s[qt * 16 + 4 * g]);
+      float pv[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = (qt * 16 + 4 * g + r < T) ? expf(sa[r] * scale - l4[r]) : 0.f;
+        ds[r] = pv[r] * (dp[r] - d4[r]) * scale;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (qt * 16 + 4 * g + r) * FLD + dt * 16 + fr;
+          adv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[row], pv[r], adv[dt], 0, 0, 0);
+          adk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[row], ds[r], adk[dt], 0, 0, 0);
+        }
+    }
+    if (kr < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        float* base = dqkv + ((size_t)b * T + kr) * ld + h * HD + dt * 16 + 4 * g;
+        *reinterpret_cast<f32x4_t*>(base + H * HD) = adk[dt];
+        *reinterpret_cast<f32x4_t*>(base + 2 * H * HD) = adv[dt];
+      }
+    }
+  }
 }
 
 // =====================================================================================
@@ -1313,13 +1375,11 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
     const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;
     float* dq = (float*)dqkv;
     if (T <= 64) {
-      hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<64>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
-      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64, 0>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
-      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64, 1>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dq_f32_mfma_kernel<64>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dkv_f32_mfma_kernel<64>, grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<224>, grid, blk, 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
-      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<224, 0>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
-      hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<224, 1>), grid, blk, 0, st, q, g, lse, delta_ws, dq, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dq_f32_mfma_kernel<224>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dkv_f32_mfma_kernel<224>, grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale);
     }
   } else return fail(GSL_ERR_ARG, "gsl_attention_bwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd");

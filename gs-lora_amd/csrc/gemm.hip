@@ -1951,6 +1951,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
     __builtin_amdgcn_s_barrier();
     const float* As = smem[buf][0];
     const float* Ws = smem[buf][1];
+    // (requesting the fragments of k-step ks + 1 before the MFMAs of step ks — two register sets — was measured neutral: 114 - 129 TF/s on the
+    //  step's shapes either way, tools/probes/f32_gemm_bench.py; two waves per SIMD already cover the LDS round trip)
 #pragma unroll
     for (int ks = 0; ks < FBK / 4; ++ks) {
       float af[4], wf[4];
