@@ -1121,3 +1121,22 @@ def test_head_with_an_fp16_residual_stream(ops):
         a = ops.head_bwd(dl, de, x, B, T, D, g, m16, r16, e16, Wn, 64.0, dt, **kw)
         c = ops.head_bwd(dl, de, x.float(), B, T, D, g, m16, r16, e16, Wn, 64.0, dt, **kw)
         assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+def test_out_of_range_labels_turn_the_loss_nan_instead_of_reading_out_of_bounds(ops):
+    """a label outside [0, C) (the reference's CrossEntropyLoss raises) must not index the logits row out of bounds: the CE
+    kernels — separate (gsl_ce_fwd / gsl_ce_bwd) and fused (gsl_loss_tail) — produce NaN for that row's loss and gradient, which the
+    engines' deferred meter read (MeterQueue.flush) turns into a FloatingPointError."""
+    B, C, D = 8, 10, 64
+    logits = rnd(B, C, seed=1).cuda()
+    good = (torch.arange(B) % C).cuda()
+    for bad_value in (C, -1, 1 << 20):
+        bad = good.clone(); bad[3] = bad_value
+        assert torch.isfinite(ops.ce_fwd(logits, good)).all()
+        out = ops.ce_fwd(logits, bad)
+        assert torch.isnan(out[0]) and torch.isfinite(out[1])                       # summed loss NaN, hit count intact
+        g = ops.ce_bwd(logits, bad, torch.ones(1, device="cuda"), 1.0)
+        assert torch.isnan(g[3]).all() and torch.isfinite(g[[0, 1, 2, 4, 5, 6, 7]]).all()
+        emb, proto = rnd(B, D, seed=2).cuda(), rnd(C, D, seed=3).cuda()
+        total, meters, coefs, dl, de = ops.loss_tail(logits, bad, 4, emb, proto, torch.ones(1, device="cuda"), 0.15, 105.0, 1e-2, 0.05, 0.1, 2.0)
+        assert torch.isnan(total) and torch.isnan(dl[3]).all() and torch.isfinite(dl[0]).all()
