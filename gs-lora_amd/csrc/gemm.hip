@@ -1371,6 +1371,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
   stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
+  // GSL_P8_DMA_BATCH (A/B, profiles/r04_g_hybrid_stream.md): 0 = one 16 KB half-tile request per phase (2 DMA instructions per wave); 2 = two
+  // half-tiles in q1 and q3; 1 = the whole K tile kt+2 in q3. The stream ALONE runs faster when a K tile is requested as one batch.
+#ifndef GSL_P8_DMA_BATCH
+#define GSL_P8_DMA_BATCH 0
+#endif
+  constexpr int DBATCH = GSL_P8_DMA_BATCH;
+  if constexpr (DBATCH != 0) stage(1, P3{});
+  constexpr int YOUNG = DBATCH ? 8 : 6;          // DMA instructions of a wave younger than K tile kt+1's last piece at the counted wait
   if constexpr (TAB) {      // the GELU table: 16 pieces of 1 KB, two per wave, BEHIND the prologue's requests (K tile 0 is not delayed by it); the
 #pragma unroll             // counted wait below leaves them in flight, the K loop's first counted wait (step 0, q3) retires them in order
     for (int i = 0; i < 2; ++i) {
@@ -1380,8 +1388,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   }
   constexpr int TABP = TAB ? 2 : 0;
   if (nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 + TABP) : "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + TABP) : "memory");
+  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG + 1 + TABP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG + TABP) : "memory");
   __builtin_amdgcn_s_barrier();
   if (dbg8) dbg8[1] = __builtin_readcyclecounter();
   if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
@@ -1485,7 +1493,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 1, P3{});
+    if constexpr (DBATCH == 0) stage(kt + 1, P3{});
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     GSL_P8_MFMA(0, 0, bf0, 0)
     // ---- q1: (rh0, ch1); reads B-h1; stages B-h0(kt+2)
@@ -1494,7 +1502,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 2, P0{});
+    if constexpr (DBATCH != 1) stage(kt + 2, P0{});
+    if constexpr (DBATCH == 2) stage(kt + 2, P1{});
     GSL_P8_MFMA(0, 1, bf1, 1)
     // ---- q2: (rh1, ch1); reads A-h1; stages A-h0(kt+2)
 #pragma unroll
@@ -1502,13 +1511,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 2, P1{});
+    if constexpr (DBATCH == 0) stage(kt + 2, P1{});
     GSL_P8_MFMA(1, 1, bf1, 2)
     // ---- q3: (rh1, ch0); no reads; stages B-h1(kt+2); the once-per-K-tile counted wait: K tile kt+1 has landed
+    if constexpr (DBATCH == 1) { stage(kt + 2, P0{}); stage(kt + 2, P1{}); }
     stage(kt + 2, P2{});
+    if constexpr (DBATCH != 0) stage(kt + 2, P3{});
     if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
 #ifdef GSL_DEV
     if ((e.pf == 2 && kt == 0) || (e.pf == 3 && kt == nk - 3)) warm_next();
 #endif
