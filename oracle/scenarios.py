@@ -140,7 +140,7 @@ ACC = dict(n_per_split=1000, batch=40)
 #            chaotic (remain accuracy swings 25 <-> 90 % between epochs in the REFERENCE itself) — no yardstick for a precision comparison.
 #            6 epochs x 16 steps = 96 steps: below the engines' VER_FREQ = 100 (no evaluate() / checkpoint inside the run).
 # A data seed selects the training batches (labels and noise) and the held-out evaluation samples; the frozen head is one per scenario.
-ACC_SEEDS = (0, 1, 2, 3, 4)
+ACC_SEEDS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)
 ACC_STAT = {
     "harsh": dict(TRAJ, common=1.17, noise=0.08, n_per_split=2000, eval_batch=40, train_labels="traj"),
     "real": dict(batch=16, n_remain=16, n_forget=8, epochs=6, lr=1e-3, lr_min=1e-5, wd=0.05, beta=0.3, alpha=1e-2, BND=105.0, BND_pro=2.0,
