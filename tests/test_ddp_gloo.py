@@ -121,6 +121,14 @@ def _run_step(net, xs, hyper):
     return pack, {k: p.detach().clone() for k, p in net.lora.items()}
 
 
+def _free_port():
+    """A port the OS says is free right now (a fixed pid-derived port can collide with a socket in TIME_WAIT or another process)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, hyper, ret):
     sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-lora_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -151,7 +159,7 @@ def test_two_rank_step_equals_single_process(hyper):
     pack1, params1 = _run_step(net, xs, hyper)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, hyper, ret)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
@@ -197,7 +205,7 @@ def test_two_ranks_evaluate_into_one_work_directory(tmp_path):
         os.utime(p, (time.time() - 1000 + 10 * i, time.time() - 1000 + 10 * i))
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, work, ret)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
@@ -241,10 +249,10 @@ def test_two_ranks_that_disagree_on_the_best_hmean_still_take_one_decision(tmp_p
     open(os.path.join(work, "config.txt"), "w").write("cfg\n")
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_eval_disagree_worker, args=(r, 2, port, work, ret)) for r in range(2)]
     [p.start() for p in procs]
-    [p.join(120) for p in procs]
+    [p.join(300) for p in procs]
     alive = [p.is_alive() for p in procs]
     [p.terminate() for p in procs if p.is_alive()]
     assert not any(alive), "a rank hung in evaluate()"
