@@ -528,7 +528,6 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
   const int trow = 4 * fc + (fr >> 2), tcol = (fr & 3) * 4;      // this lane's piece of a 4 x 16 block (transpose-read address)
-  const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
   bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
   f32x4_t g1[4], g2[4];
 #pragma unroll
@@ -2020,6 +2019,7 @@ static inline int mrev_for(int key) {
 }
 
 // workgroups of the persistent kernels: one per CU
+#if GSL_P8_PERSISTENT
 static inline int p8p_grid() {
   static int n = 0;
   if (!n) {
@@ -2030,6 +2030,7 @@ static inline int p8p_grid() {
   }
   return n;
 }
+#endif
 
 template <int EPI>
 static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
