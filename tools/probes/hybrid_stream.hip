@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ int g_krot;   // host-set: sibling N-tile j starts its K loop at K tile j * g_krot (mod nk), as the production kernel's krot
 constexpr int BK = 64, HT = 128 * BK;      // half-tile: 128 rows x 64 bf16 = 16 KB
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -44,9 +45,12 @@ __global__ __launch_bounds__(512) void probe(const bf16_t* __restrict__ A, int l
   const int nk = K / BK;
   const int lrow = lane >> 3, lc = lane & 7;
   const int fr = lane & 15, fc = lane >> 4;
+  const int krot = (g_krot * (tile % nbn)) % nk;
   auto issue_dma = [&](int kt) {               // every wave issues 2 pieces of each 16 KB half-tile
     if (kt >= nk) return;
     bf16_t* dst = smem + (kt % NSLOT) * SLOT;
+    const int kslot = kt;
+    kt = (kt + krot) % nk;
 #pragma unroll
     for (int p = 0; p < (HYB ? 2 : 4); ++p) {  // half-tiles: HYB: A-h0, A-h1; FULL: W-h0, A-h0, W-h1, A-h1
       const int isA = HYB ? 1 : (p & 1), half = HYB ? p : (p >> 1);
@@ -226,15 +230,15 @@ __global__ __launch_bounds__(512) void probe1b(const bf16_t* __restrict__ A, int
   if (tid == 0) stamps[blockIdx.x] = t1 - t0;
 }
 
-struct Ctx { bf16_t *A, *W; unsigned long long* st; float* sink; int M, N, K, lda; };
+struct Ctx { bf16_t *A, *W; unsigned long long* st; float* sink; int M, N, K, lda, ldw; };
 
 template <int HYB, int AHEAD, int MODE>
 void run(const Ctx& c, const char* label) {
   const int grid = (c.M / 256) * (c.N / 256);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
-    if constexpr (MODE >= 3) hipLaunchKernelGGL((probe1b<(MODE == 4), (MODE == 5)>), dim3(grid), dim3(512), 0, 0, c.A, c.lda, c.W, c.K, c.K, c.M, c.N, c.st, c.sink);
-    else hipLaunchKernelGGL((probe<HYB, AHEAD, MODE>), dim3(grid), dim3(512), 0, 0, c.A, c.lda, c.W, c.K, c.K, c.M, c.N, c.st, c.sink);
+    if constexpr (MODE >= 3) hipLaunchKernelGGL((probe1b<(MODE == 4), (MODE == 5)>), dim3(grid), dim3(512), 0, 0, c.A, c.lda, c.W, c.ldw, c.K, c.M, c.N, c.st, c.sink);
+    else hipLaunchKernelGGL((probe<HYB, AHEAD, MODE>), dim3(grid), dim3(512), 0, 0, c.A, c.lda, c.W, c.ldw, c.K, c.M, c.N, c.st, c.sink);
   };
   launch(); launch();
   hipEventRecord(e0); for (int i = 0; i < 5; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -250,11 +254,12 @@ void run(const Ctx& c, const char* label) {
 
 int main() {
   Ctx c; c.M = 201728;
+  { int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_krot), &z, sizeof(int)); }
   hipMalloc(&c.st, 65536 * 8); hipMalloc(&c.sink, 64);
   for (int shape = 0; shape < 2; ++shape) {
     c.N = shape ? 512 : 2048; c.K = shape ? 2048 : 512;
-    c.lda = c.K;
-    const size_t ea = (size_t)c.M * (c.K + 512) + 65536, ew = (size_t)c.N * c.K + 65536;
+    c.lda = c.K; c.ldw = c.K;
+    const size_t ea = (size_t)c.M * (c.K + 512) + 65536, ew = (size_t)c.N * (c.K + 512) + 65536;
     hipMalloc(&c.A, ea * 2); hipMalloc(&c.W, ew * 2);
     hipMemset(c.A, 0x3c, ea * 2); hipMemset(c.W, 0x3c, ew * 2);
     printf("\nshape M = %d, N = %d, K = %d (%s)\n\n", c.M, c.N, c.K, shape ? "FFN2 forward" : "FFN1 / QKV class");
@@ -279,6 +284,37 @@ int main() {
       snprintf(lab, 64, "1 barrier staggered, pitch K + %d", pad);
       run<0, 1, 5>(c, lab);
     }
+    c.lda = c.K;
+    for (int pad : {64, 128, 320}) {                // W rows padded (W is L2-resident: does its power-of-two pitch alias L2 channels?)
+      c.ldw = c.K + pad;
+      char lab[64]; snprintf(lab, 64, "streams only, W pitch K + %d", pad);
+      run<0, 1, 0>(c, lab);
+    }
+    c.lda = c.K + 64; c.ldw = c.K + 64;
+    run<0, 1, 0>(c, "streams only, A and W pitch K + 64");
+    run<0, 1, 5>(c, "1 barrier staggered, A and W pitch K + 64");
+    c.lda = c.K; c.ldw = c.K;
+    hipFree(c.A); hipFree(c.W);
+  }
+  // how the K = 2048 stream depends on the number of sibling N-tiles that share an A row panel through the XCD's L2 (HBM-side bytes per K tile)
+  printf("\nK = 2048, streams only, by N (sibling tiles per A panel = N / 256)\n\n| variant | operands | K tiles ahead | mode | launch us | cycles / K tile (mean) | (median) | TFLOP/s |\n|---|---|---|---|---|---|---|---|\n");
+  for (int kr : {1, 4, 16}) {
+    c.N = 512; c.K = 2048; c.M = 201728; c.lda = c.K; c.ldw = c.K;
+    hipMalloc(&c.A, ((size_t)c.M * c.K + 65536) * 2); hipMalloc(&c.W, ((size_t)c.N * c.K + 65536) * 2);
+    hipMemset(c.A, 0x3c, ((size_t)c.M * c.K + 65536) * 2); hipMemset(c.W, 0x3c, ((size_t)c.N * c.K + 65536) * 2);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_krot), &kr, sizeof(int));
+    char lab[64]; snprintf(lab, 64, "N = 512, sibling K offset %d", kr);
+    run<0, 1, 0>(c, lab);
+    run<0, 1, 5>(c, "  (1-barrier staggered loop; no rotation there)");
+    hipFree(c.A); hipFree(c.W);
+  }
+  { int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_krot), &z, sizeof(int)); }
+  for (int n : {256, 512, 1024, 2048}) {
+    c.N = n; c.K = 2048; c.M = n >= 1024 ? 50432 : 201728; c.lda = c.K; c.ldw = c.K;
+    hipMalloc(&c.A, ((size_t)c.M * c.K + 65536) * 2); hipMalloc(&c.W, ((size_t)c.N * c.K + 65536) * 2);
+    hipMemset(c.A, 0x3c, ((size_t)c.M * c.K + 65536) * 2); hipMemset(c.W, 0x3c, ((size_t)c.N * c.K + 65536) * 2);
+    char lab[64]; snprintf(lab, 64, "N = %d, M = %d", n, c.M);
+    run<0, 1, 0>(c, lab);
     hipFree(c.A); hipFree(c.W);
   }
   return 0;
