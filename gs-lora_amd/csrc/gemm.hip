@@ -1472,6 +1472,72 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
   };
 #endif
+#ifndef GSL_P8_PHASES
+#define GSL_P8_PHASES 8
+#endif
+#if GSL_P8_PHASES == 4
+  // A/B (profiles/r04_notes.md): TWO phases of 32 MFMAs per K tile instead of four of 16 — half the barriers. pA: row half 0 against both column
+  // halves (reads B-h0, B-h1, A-h0: 16 ds_read_b128), pB: row half 1 (reads A-h1: 8). Requests: A-h1(kt+1) in pA, the other three half-tiles of
+  // kt+2 in pB; two counted waits per K tile (pA retires A-h1(kt), pB the three half-tiles pA(kt+1) reads), each a whole K tile behind its requests.
+#define GSL_P8_MFMA2(RH, CHA, BFA, CHB, BFB, PH)                                                             \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  GSL_P8_PEXTRA(PH)                                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+        acc[(RH) * 4 + i][(CHA) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFA[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHA) * 2 + j], 0, 0, 0); \
+        acc[(RH) * 4 + i][(CHB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFB[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHB) * 2 + j], 0, 0, 0); \
+      }                                                                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+#define GSL_P8_WAIT4()                                                                                      \
+  if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                               \
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16_t* As0 = smem + (kt & 1) * STG;
+    const bf16_t* As1 = As0 + HT;
+    const bf16_t* Bs0 = As0 + BM4 * BK;
+    const bf16_t* Bs1 = Bs0 + HT;
+    // ---- pA: row half 0 x both column halves
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf0[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs0 + boff[j][ks]);
+    if constexpr (LORA) {
+      pf[0] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff0);
+      pf[1] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 1, P3{});
+    GSL_P8_WAIT4()
+    GSL_P8_MFMA2(0, 0, bf0, 1, bf1, 0)
+    // ---- pB: row half 1 x both column halves
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt + 2, P0{}); stage(kt + 2, P1{}); stage(kt + 2, P2{});
+    GSL_P8_WAIT4()
+    GSL_P8_MFMA2(1, 1, bf1, 0, bf0, 2)
+  }
+#undef GSL_P8_MFMA2
+#undef GSL_P8_WAIT4
+#else
   for (int kt = 0; kt < nk; ++kt) {
     const bf16_t* As0 = smem + (kt & 1) * STG;
     const bf16_t* As1 = As0 + HT;
@@ -1524,6 +1590,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #endif
     GSL_P8_MFMA(1, 0, bf0, 3)
   }
+#endif
 #undef GSL_P8_MFMA
 #undef GSL_P8_PEXTRA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
