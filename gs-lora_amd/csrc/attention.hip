@@ -30,8 +30,10 @@
 #include "gsl_common.h"
 
 using namespace gsl;
+#include "gsl_h16.h"
+GSL_OPNS_BEGIN
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef op16x8_t bf16x8_t;      // MFMA operand in this translation unit's 16-bit format (gsl_common.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int HD = 64;    // head dim
@@ -51,7 +53,7 @@ union Frag {
 };
 
 __device__ __forceinline__ f32x4_t mfma16(const bf16x8_t a, const bf16x8_t b, const f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  return GSL_MFMA16(a, b, c, 0, 0, 0);
 }
 
 // stage a [T][64] bf16 panel (row stride ld elements in global) into row-major LDS [TP][KLD], zero rows >= T
@@ -149,7 +151,7 @@ __device__ __forceinline__ bf16x8_t gl_frag(const bf16_t* rowptr, int ks, int fc
   return *reinterpret_cast<const bf16x8_t*>(rowptr + ks * 32 + fc * 8);
 }
 __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4_t v, float mul) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * mul, v[1] * mul), pack2bf(v[2] * mul, v[3] * mul));
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2o(v[0] * mul, v[1] * mul), pack2o(v[2] * mul, v[3] * mul));
 }
 
 // Item order (round 4): hardware places workgroup w on XCD w % 8, and the tensors o / dO / dqkv are TOKEN-major — the H heads of an image own
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void attn_fwd_bf16_kernel(
     Frag pf[NKT / 2];
 #pragma unroll
     for (int pr = 0; pr < NKT / 2; ++pr) {
-      pf[pr].u = make_uint4(pack2bf(s[2 * pr][0], s[2 * pr][1]), pack2bf(s[2 * pr][2], s[2 * pr][3]),
-                            pack2bf(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2bf(s[2 * pr + 1][2], s[2 * pr + 1][3]));
+      pf[pr].u = make_uint4(pack2o(s[2 * pr][0], s[2 * pr][1]), pack2o(s[2 * pr][2], s[2 * pr][3]),
+                            pack2o(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2o(s[2 * pr + 1][2], s[2 * pr + 1][3]));
     }
     const float inv = 1.0f / l;
 #pragma unroll
@@ -378,10 +380,10 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
 #pragma unroll
     for (int pr = 0; pr < NKT / 2; ++pr) {
       if (2 * pr + 1 < NKV)
-        pf[pr].u = make_uint4(pack2bf(s[2 * pr][0], s[2 * pr][1]), pack2bf(s[2 * pr][2], s[2 * pr][3]),
-                              pack2bf(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2bf(s[2 * pr + 1][2], s[2 * pr + 1][3]));
+        pf[pr].u = make_uint4(pack2o(s[2 * pr][0], s[2 * pr][1]), pack2o(s[2 * pr][2], s[2 * pr][3]),
+                              pack2o(s[2 * pr + 1][0], s[2 * pr + 1][1]), pack2o(s[2 * pr + 1][2], s[2 * pr + 1][3]));
       else        // the empty tile's probabilities are exactly zero
-        pf[pr].u = make_uint4(pack2bf(s[2 * pr][0], s[2 * pr][1]), pack2bf(s[2 * pr][2], s[2 * pr][3]), 0u, 0u);
+        pf[pr].u = make_uint4(pack2o(s[2 * pr][0], s[2 * pr][1]), pack2o(s[2 * pr][2], s[2 * pr][3]), 0u, 0u);
     }
     const float inv = 1.0f / l;
     wg_barrier_lds();                                   // V(item) is in LDS; Q / K panels may be overwritten from here on
@@ -443,8 +445,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
       const uint32_t c[8] = {of0.u.x, of0.u.y, of0.u.z, of0.u.w, of1.u.x, of1.u.y, of1.u.z, of1.u.w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        dl += __uint_as_float(a[i] << 16) * __uint_as_float(c[i] << 16);
-        dl += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(c[i] & 0xffff0000u);
+        float a0, a1, c0, c1;
+        unpack2o(a[i], a0, a1); unpack2o(c[i], c0, c1);
+        dl += a0 * c0;
+        dl += a1 * c1;
       }
     }
     dl += __shfl_xor(dl, 16, 64);
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
         if (kt >= ktf) { if (kt * 16 + fc * 4 + r >= T) p = 0.f; }
         ds[r] = p * (dp[r] - dl);
       }
-      if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.y = pack2bf(ds[2], ds[3]); }
-      else { dsf[kt / 2].u.z = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.w = pack2bf(ds[2], ds[3]); }
+      if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2o(ds[0], ds[1]); dsf[kt / 2].u.y = pack2o(ds[2], ds[3]); }
+      else { dsf[kt / 2].u.z = pack2o(ds[0], ds[1]); dsf[kt / 2].u.w = pack2o(ds[2], ds[3]); }
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -558,11 +562,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kern
             ds[r] = p[r] * (dp[r] - dv[r]);          // softmax scale applied once to the dK accumulators at the store
           }
           if (half == 0) {
-            pf[t].u.x = pack2bf(p[0], p[1]); pf[t].u.y = pack2bf(p[2], p[3]);
-            dsf[t].u.x = pack2bf(ds[0], ds[1]); dsf[t].u.y = pack2bf(ds[2], ds[3]);
+            pf[t].u.x = pack2o(p[0], p[1]); pf[t].u.y = pack2o(p[2], p[3]);
+            dsf[t].u.x = pack2o(ds[0], ds[1]); dsf[t].u.y = pack2o(ds[2], ds[3]);
           } else {
-            pf[t].u.z = pack2bf(p[0], p[1]); pf[t].u.w = pack2bf(p[2], p[3]);
-            dsf[t].u.z = pack2bf(ds[0], ds[1]); dsf[t].u.w = pack2bf(ds[2], ds[3]);
+            pf[t].u.z = pack2o(p[0], p[1]); pf[t].u.w = pack2o(p[2], p[3]);
+            dsf[t].u.z = pack2o(ds[0], ds[1]); dsf[t].u.w = pack2o(ds[2], ds[3]);
           }
         }
       }
@@ -661,8 +665,10 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
         const uint32_t c[8] = {of0.u.x, of0.u.y, of0.u.z, of0.u.w, of1.u.x, of1.u.y, of1.u.z, of1.u.w};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          dl += __uint_as_float(a[i] << 16) * __uint_as_float(c[i] << 16);
-          dl += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(c[i] & 0xffff0000u);
+          float a0, a1, c0, c1;
+          unpack2o(a[i], a0, a1); unpack2o(c[i], c0, c1);
+          dl += a0 * c0;
+          dl += a1 * c1;
         }
       }
       dl += __shfl_xor(dl, 16, 64);
@@ -687,8 +693,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
           if (FAST ? (kt == NKT - 2) : (kt >= ktf)) { if (kt * 16 + fc * 4 + r >= T) p = 0.f; }
           ds[r] = p * (dp[r] - dl);
         }
-        if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.y = pack2bf(ds[2], ds[3]); }
-        else { dsf[kt / 2].u.z = pack2bf(ds[0], ds[1]); dsf[kt / 2].u.w = pack2bf(ds[2], ds[3]); }
+        if ((kt & 1) == 0) { dsf[kt / 2].u.x = pack2o(ds[0], ds[1]); dsf[kt / 2].u.y = pack2o(ds[2], ds[3]); }
+        else { dsf[kt / 2].u.z = pack2o(ds[0], ds[1]); dsf[kt / 2].u.w = pack2o(ds[2], ds[3]); }
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -803,11 +809,11 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
           ds[r] = p[r] * (dp[r] - dv[r]);
         }
         if (half == 0) {
-          pf.u.x = pack2bf(p[0], p[1]); pf.u.y = pack2bf(p[2], p[3]);
-          dsf.u.x = pack2bf(ds[0], ds[1]); dsf.u.y = pack2bf(ds[2], ds[3]);
+          pf.u.x = pack2o(p[0], p[1]); pf.u.y = pack2o(p[2], p[3]);
+          dsf.u.x = pack2o(ds[0], ds[1]); dsf.u.y = pack2o(ds[2], ds[3]);
         } else {
-          pf.u.z = pack2bf(p[0], p[1]); pf.u.w = pack2bf(p[2], p[3]);
-          dsf.u.z = pack2bf(ds[0], ds[1]); dsf.u.w = pack2bf(ds[2], ds[3]);
+          pf.u.z = pack2o(p[0], p[1]); pf.u.w = pack2o(p[2], p[3]);
+          dsf.u.z = pack2o(ds[0], ds[1]); dsf.u.w = pack2o(ds[2], ds[3]);
         }
       }
 #pragma unroll
@@ -1260,31 +1266,37 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__
   if (tid == 0) lse_cls[(size_t)b * H + h] = m + logf(e);
 }
 
-extern "C" int gsl_attention_fwd_cls(const void* qkv, const void* q_cls, void* o_cls, float* lse_cls, int B, int T, int H, float scale,
+extern "C" int GSL_ENTRY(gsl_attention_fwd_cls)(const void* qkv, const void* q_cls, void* o_cls, float* lse_cls, int B, int T, int H, float scale,
                                      int dtype, int qkv_layout, gsl_stream_t s) {
+  GSL_FORWARD_H16(dtype, h16_gsl_attention_fwd_cls(qkv, q_cls, o_cls, lse_cls, B, T, H, scale, dtype, qkv_layout, s));
   GSL_CHECK_ARG(qkv && o_cls && lse_cls && B > 0 && T > 1 && T <= 256 && H > 0, "null/size (T <= 256)");
   GSL_CHECK_ARG(qkv_layout >= 0 && qkv_layout <= 2 && (qkv_layout != 2 || q_cls), "qkv_layout: 0 token-major, 1 head-major, 2 kv + q_cls");
   const dim3 grid(B * H), blk(256);
-  if (dtype == GSL_BF16)
+  if (dtype == GSL_OP16)
     hipLaunchKernelGGL(attn_fwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)q_cls, (bf16_t*)o_cls, lse_cls, T, H, scale, qkv_layout);
+#if GSL_HAS_F32
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(attn_fwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)q_cls, (float*)o_cls, lse_cls, T, H, scale, qkv_layout);
+#endif
   else return fail(GSL_ERR_ARG, "gsl_attention_fwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_fwd_cls");
 }
 
-extern "C" int gsl_attention_bwd_cls(const void* qkv, const void* q_cls, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
+extern "C" int GSL_ENTRY(gsl_attention_bwd_cls)(const void* qkv, const void* q_cls, const void* o, const void* d_o_cls, const float* lse, void* dqkv,
                                      void* dq_cls, int B, int T, int H, float scale, int dtype, int qkv_layout, int cls_compact,
                                      gsl_stream_t s) {
+  GSL_FORWARD_H16(dtype, h16_gsl_attention_bwd_cls(qkv, q_cls, o, d_o_cls, lse, dqkv, dq_cls, B, T, H, scale, dtype, qkv_layout, cls_compact, s));
   GSL_CHECK_ARG(qkv && o && d_o_cls && lse && dqkv && B > 0 && T > 1 && H > 0, "null/size");
   GSL_CHECK_ARG(qkv_layout >= 0 && qkv_layout <= 2 && (qkv_layout != 2 || (q_cls && dq_cls)), "qkv_layout: 0 token-major, 1 head-major, 2 kv + q_cls / dq_cls");
   const dim3 grid(B * H), blk(256);
-  if (dtype == GSL_BF16)
+  if (dtype == GSL_OP16)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16_t>, grid, blk, 0, as_stream(s), (const bf16_t*)qkv, (const bf16_t*)q_cls, (const bf16_t*)o,
                        (const bf16_t*)d_o_cls, lse, (bf16_t*)dqkv, (bf16_t*)dq_cls, T, H, scale, qkv_layout, cls_compact);
+#if GSL_HAS_F32
   else if (dtype == GSL_F32)
     hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid, blk, 0, as_stream(s), (const float*)qkv, (const float*)q_cls, (const float*)o,
                        (const float*)d_o_cls, lse, (float*)dqkv, (float*)dq_cls, T, H, scale, qkv_layout, cls_compact);
+#endif
   else return fail(GSL_ERR_ARG, "gsl_attention_bwd_cls: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd_cls");
 }
@@ -1314,17 +1326,18 @@ static inline int attn_abl() { return attn_env("GSL_ATTN_ABL", 0); }
 // =====================================================================================
 // C ABI
 // =====================================================================================
-extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype,
+extern "C" int GSL_ENTRY(gsl_attention_fwd)(const void* qkv, void* o, float* lse, int B, int T, int H, float scale, int dtype,
                                  int qkv_layout, gsl_stream_t s) {
+  GSL_FORWARD_H16(dtype, h16_gsl_attention_fwd(qkv, o, lse, B, T, H, scale, dtype, qkv_layout, s));
   GSL_CHECK_ARG(qkv && o && lse && B > 0 && T > 1 && H > 0, "null/size");
-  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_BF16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
+  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_OP16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
   const int hm = qkv_layout;
   GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
   // (item_remap for the forward: measured +1 % — 212 -> 215 us at B = 1024 —, so the plain order stays; the backward gains 2.3 %: profiles/r04_notes.md)
   const int imap = (B % 8 == 0 && attn_num_cus() % 8 == 0) ? attn_env("GSL_ATTN_ITEM_REMAP_FWD", 0) : 0;
-  if (dtype == GSL_BF16) {
+  if (dtype == GSL_OP16) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, grid, blk, 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else if (attn_persistent() && T <= 208 && B * H >= 2 * attn_num_cus())
     {
@@ -1333,22 +1346,27 @@ extern "C" int gsl_attention_fwd(const void* qkv, void* o, float* lse, int B, in
     }
     else if (B * H < attn_num_cus()) hipLaunchKernelGGL((attn_fwd_bf16_kernel<14, 1024>), grid, dim3(1024), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
     else hipLaunchKernelGGL(attn_fwd_bf16_kernel<14>, grid, dim3(512), 0, st, (const bf16_t*)qkv, (bf16_t*)o, lse, T, H, scale, attn_abl(), hm);
-  } else if (dtype == GSL_F32) {
+  }
+#if GSL_HAS_F32
+  else if (dtype == GSL_F32) {
     if (T <= 64) hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel<64>, grid, dim3(512), 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
     else hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel<224>, grid, dim3(512), 0, st, (const float*)qkv, (float*)o, lse, T, H, scale);
-  } else return fail(GSL_ERR_ARG, "gsl_attention_fwd: bad dtype%s %ld", "", dtype);
+  }
+#endif
+  else return fail(GSL_ERR_ARG, "gsl_attention_fwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_fwd");
 }
 
-extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+extern "C" int GSL_ENTRY(gsl_attention_bwd)(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
                                  float* delta_ws, int B, int T, int H, float scale, int dtype, int qkv_layout, gsl_stream_t s) {
+  GSL_FORWARD_H16(dtype, h16_gsl_attention_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, T, H, scale, dtype, qkv_layout, s));
   GSL_CHECK_ARG(qkv && o && d_o && lse && dqkv && delta_ws && B > 0 && T > 1 && H > 0, "null/size");
-  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_BF16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
+  GSL_CHECK_ARG(qkv_layout == 0 || (qkv_layout == 1 && dtype == GSL_OP16), "qkv_layout: 0 token-major, 1 head-major (bf16 kernels only)");
   const int hm = qkv_layout;
   GSL_CHECK_ARG(T <= 224, "T <= 224 tokens (single-panel attention)");
   hipStream_t st = as_stream(s);
   const dim3 grid(B * H), blk(256);
-  if (dtype == GSL_BF16) {
+  if (dtype == GSL_OP16) {
     const bf16_t* q = (const bf16_t*)qkv; const bf16_t* oo = (const bf16_t*)o; const bf16_t* g = (const bf16_t*)d_o;
     bf16_t* dq = (bf16_t*)dqkv;
     const int imap = (B % 8 == 0) ? attn_env("GSL_ATTN_ITEM_REMAP", 1) : 0;      // heads of an image on one XCD (item_remap)
@@ -1371,7 +1389,9 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
         if (attn_env("GSL_ATTN_NT", 1) == 1) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 1>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm);
         else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<14, 2>), grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale, attn_abl(), hm); }
     }
-  } else if (dtype == GSL_F32) {
+  }
+#if GSL_HAS_F32
+  else if (dtype == GSL_F32) {
     const float* q = (const float*)qkv; const float* oo = (const float*)o; const float* g = (const float*)d_o;
     float* dq = (float*)dqkv;
     if (T <= 64) {
@@ -1381,6 +1401,9 @@ extern "C" int gsl_attention_bwd(const void* qkv, const void* o, const void* d_o
       hipLaunchKernelGGL(attn_bwd_dq_f32_mfma_kernel<224>, grid, dim3(512), 0, st, q, oo, g, lse, dq, delta_ws, T, H, scale);
       hipLaunchKernelGGL(attn_bwd_dkv_f32_mfma_kernel<224>, grid, dim3(512), 0, st, q, g, lse, delta_ws, dq, T, H, scale);
     }
-  } else return fail(GSL_ERR_ARG, "gsl_attention_bwd: bad dtype%s %ld", "", dtype);
+  }
+#endif
+  else return fail(GSL_ERR_ARG, "gsl_attention_bwd: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_attention_bwd");
 }
+GSL_OPNS_END

@@ -22,8 +22,10 @@
 #include <type_traits>
 
 using namespace gsl;
+#include "gsl_h16.h"
+GSL_OPNS_BEGIN
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef op16x8_t bf16x8_t;      // MFMA operand in this translation unit's 16-bit format (gsl_common.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 struct EpiArgs {
@@ -315,7 +317,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = (v[q] * e.drop.scale) * __uint_as_float(ent[q]);
           bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
-          *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
           // the four code bytes: v_perm_b32 x 2 + v_or
           *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) =
               __builtin_amdgcn_perm(ent[1], ent[0], 0x0c0c0400u) | __builtin_amdgcn_perm(ent[3], ent[2], 0x04000c0cu);
@@ -333,11 +335,11 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         }
         bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
         if constexpr (EPI == GSL_EPI_BIAS_RES_BF16 || EPI == GSL_EPI_PATCH_BF16) *reinterpret_cast<uint2*>(d) = make_uint2(pack2s(v[0], v[1], e.f16), pack2s(v[2], v[3], e.f16));
-        else *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
         if constexpr (G8) {
           *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) = g8_pack4(g, kq8);
         } else if constexpr (NOUT == 2) {
-          const uint2 pg = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+          const uint2 pg = make_uint2(pack2o(g[0], g[1]), pack2o(g[2], g[3]));
           if constexpr (SEQ) held[ii][j] = pg; else *reinterpret_cast<uint2*>(d + 64 * CLD) = pg;
         }
       }
@@ -443,14 +445,16 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
         float ga[4], gb[4];
         g8_unpack4(ax[r].x, sq8, ga);
         g8_unpack4(ax[r].y, sq8, gb);
-        o[0] = pack2bf(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2bf(lo[2] * ga[2], lo[3] * ga[3]);
-        o[2] = pack2bf(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2bf(hi[2] * gb[2], hi[3] * gb[3]);
+        o[0] = pack2o(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2o(lo[2] * ga[2], lo[3] * ga[3]);
+        o[2] = pack2o(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2o(hi[2] * gb[2], hi[3] * gb[3]);
       } else {
         const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
-          o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+          float a0, a1;
+          unpack2o(a[k], a0, a1);
+          o[k] = pack2o(c0 * a0, c1 * a1);
         }
       }
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), e.stmode);
@@ -575,14 +579,16 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
         float ga[4], gb[4];
         g8_unpack4(ax[r].x, sq8, ga);
         g8_unpack4(ax[r].y, sq8, gb);
-        o[0] = pack2bf(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2bf(lo[2] * ga[2], lo[3] * ga[3]);
-        o[2] = pack2bf(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2bf(hi[2] * gb[2], hi[3] * gb[3]);
+        o[0] = pack2o(lo[0] * ga[0], lo[1] * ga[1]); o[1] = pack2o(lo[2] * ga[2], lo[3] * ga[3]);
+        o[2] = pack2o(hi[0] * gb[0], hi[1] * gb[1]); o[3] = pack2o(hi[2] * gb[2], hi[3] * gb[3]);
       } else {
         const uint32_t a[4] = {ax[r].x, ax[r].y, ax[r].z, ax[r].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float c0 = (k < 2) ? lo[2 * k] : hi[2 * k - 4], c1 = (k < 2) ? lo[2 * k + 1] : hi[2 * k - 3];
-          o[k] = pack2bf(c0 * __uint_as_float(a[k] << 16), c1 * __uint_as_float(a[k] & 0xffff0000u));
+          float a0, a1;
+          unpack2o(a[k], a0, a1);
+          o[k] = pack2o(c0 * a0, c1 * a1);
         }
       }
       const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
@@ -617,8 +623,8 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       a1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p1 + 16 * CLD));
       a2.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p2));
       a2.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(p2 + 16 * CLD));
-      g1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, b1.v, g1[t], 0, 0, 0);
-      g2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2.v, b2.v, g2[t], 0, 0, 0);
+      g1[t] = GSL_MFMA16(a1.v, b1.v, g1[t], 0, 0, 0);
+      g2[t] = GSL_MFMA16(a2.v, b2.v, g2[t], 0, 0, 0);
     }
     asm volatile("" ::: "memory");
   }
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = GSL_MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -1052,7 +1058,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
         const int rt = wm * 32 + wn * 16 + fr;
         const bf16x8_t ta = *reinterpret_cast<const bf16x8_t*>(st + rt * BK + (((ks * 4 + fc) ^ (rt & 7)) << 3));
         const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(st + (BMS + BNT) * BK + fr * BK + (((ks * 4 + fc) ^ (fr & 7)) << 3));
-        accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ta, accp, 0, 0, 0);
+        accp = GSL_MFMA16(pf, ta, accp, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+          acc[i][j] = GSL_MFMA16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
   }
   if constexpr (KS == 2) {      // group 1 hands its accumulators to group 0: f32, [wave][fragment][lane] behind the t buffer, fixed order 0 + 1
     __builtin_amdgcn_s_barrier();                      // the stages are free
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
     bf16_t* tbuf = smem;
     if (lead) {
       bf16_t* d = tbuf + (wm * 32 + wn * 16 + fr) * 32 + fc * 4;
-      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[0], lk.s * accp[1]), pack2bf(lk.s * accp[2], lk.s * accp[3]));
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[0], lk.s * accp[1]), pack2o(lk.s * accp[2], lk.s * accp[3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
     __builtin_amdgcn_s_barrier();
@@ -1118,7 +1124,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 32 + i * 16 + fr) * 32 + fc * 8);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, tf, acc[i][j], 0, 0, 0);
+        acc[i][j] = GSL_MFMA16(qf, tf, acc[i][j], 0, 0, 0);
       }
     }
     }
@@ -1218,7 +1224,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = GSL_MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(af[i]), "v"(wf[i])); }
@@ -1409,10 +1415,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #define GSL_P8_PEXTRA(PH)                                                                                   \
   if constexpr (LORA) {                                                                                     \
     constexpr int ks_ = (PH) & 1, t_ = (PH) >> 1;                                                           \
-    if (wn == 0) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[0][ks_], accp[t_], 0, 0, 0);      \
-    else if (wn == 1) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[1][ks_], accp[t_], 0, 0, 0); \
-    else if (wn == 2) accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[2][ks_], accp[t_], 0, 0, 0); \
-    else accp[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks_], af[3][ks_], accp[t_], 0, 0, 0);               \
+    if (wn == 0) accp[t_] = GSL_MFMA16(pf[ks_], af[0][ks_], accp[t_], 0, 0, 0);      \
+    else if (wn == 1) accp[t_] = GSL_MFMA16(pf[ks_], af[1][ks_], accp[t_], 0, 0, 0); \
+    else if (wn == 2) accp[t_] = GSL_MFMA16(pf[ks_], af[2][ks_], accp[t_], 0, 0, 0); \
+    else accp[t_] = GSL_MFMA16(pf[ks_], af[3][ks_], accp[t_], 0, 0, 0);               \
   }
 #else
 #define GSL_P8_PEXTRA(PH)                                                                                   \
@@ -1420,13 +1426,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if ((wn >> 1) == ((PH) >> 1)) {                                                                         \
       if (pi) {                                                                                             \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
-          accp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[2][ks], accp[0], 0, 0, 0);           \
-          accp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[3][ks], accp[1], 0, 0, 0);           \
+          accp[0] = GSL_MFMA16(pf[ks], af[2][ks], accp[0], 0, 0, 0);           \
+          accp[1] = GSL_MFMA16(pf[ks], af[3][ks], accp[1], 0, 0, 0);           \
         }                                                                                                   \
       } else {                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
-          accp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[0][ks], accp[0], 0, 0, 0);           \
-          accp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], af[1][ks], accp[1], 0, 0, 0);           \
+          accp[0] = GSL_MFMA16(pf[ks], af[0][ks], accp[0], 0, 0, 0);           \
+          accp[1] = GSL_MFMA16(pf[ks], af[1][ks], accp[1], 0, 0, 0);           \
         }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
@@ -1447,7 +1453,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-        acc[(RH) * 4 + i][(CH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
+        acc[(RH) * 4 + i][(CH) * 2 + j] = GSL_MFMA16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   __builtin_amdgcn_s_barrier();                                                                             \
@@ -1488,8 +1494,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-        acc[(RH) * 4 + i][(CHA) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFA[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHA) * 2 + j], 0, 0, 0); \
-        acc[(RH) * 4 + i][(CHB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFB[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHB) * 2 + j], 0, 0, 0); \
+        acc[(RH) * 4 + i][(CHA) * 2 + j] = GSL_MFMA16(BFA[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHA) * 2 + j], 0, 0, 0); \
+        acc[(RH) * 4 + i][(CHB) * 2 + j] = GSL_MFMA16(BFB[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHB) * 2 + j], 0, 0, 0); \
       }                                                                                                     \
   __builtin_amdgcn_s_setprio(0);                                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -1604,7 +1610,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       bf16_t* d = t16 + (wm * 128 + GSL_P8_TFRAG(t) * 16 + fr) * 16 + fc * 4;
-      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[t][0], lk.s * accp[t][1]), pack2o(lk.s * accp[t][2], lk.s * accp[t][3]));
     }
     __syncthreads();
     if (n0 == 0 && lk.tout) {
@@ -1636,7 +1642,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       if (fc >= 2) tf = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};       // k slots 16..31 of the rank-r k-step
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+        acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
     __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
     epilogue_staged_mulgrad<8, EPI == GSL_EPI_MUL_G8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
@@ -1650,7 +1656,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       bf16_t* d = tbuf + (wm * 128 + GSL_P8_TFRAG(t) * 16 + fr) * 32 + fc * 4;
-      *reinterpret_cast<uint2*>(d) = make_uint2(pack2bf(lk.s * accp[t][0], lk.s * accp[t][1]), pack2bf(lk.s * accp[t][2], lk.s * accp[t][3]));
+      *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[t][0], lk.s * accp[t][1]), pack2o(lk.s * accp[t][2], lk.s * accp[t][3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
     __builtin_amdgcn_s_barrier();
@@ -1676,7 +1682,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+        acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
   }
   if constexpr (!LORA && epi_is_gelu<EPI>()) {
@@ -1704,7 +1710,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], tf, acc[i][j], 0, 0, 0);
+          acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -1842,7 +1848,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(const bf16_t* __rest
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-        acc[(RH) * 4 + i][(CH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
+        acc[(RH) * 4 + i][(CH) * 2 + j] = GSL_MFMA16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   __builtin_amdgcn_s_barrier();                                                                             \
@@ -2103,7 +2109,7 @@ template <int EPI>
 static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2,
                        int lda2, const void* W2, int ldw2, int K2, const EpiArgs& e_in, hipStream_t st) {
   const EpiArgs& e = e_in;
-  if (dtype == GSL_BF16) {
+  if (dtype == GSL_OP16) {
     const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     // Tile choice, measured on MI355X at M = 201 728 (profiles/r01_gemm_ab.md): N >= 512 wants the 256x256 8-phase tile (also for the
     // VALU-heavy BIAS_GELU epilogue), skinny N the 256x128 ring. Fewer than 128 tiles of 256x256 cannot fill the 256 CUs: the 128x128
@@ -2232,7 +2238,9 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       GSL_LAUNCH((gemm_bf16_glds_kernel<EPI, 1>), nblk, 256);
     }
 #undef GSL_LAUNCH
-  } else {
+  }
+#if GSL_HAS_F32
+  else {
     // parity mode: the matrix-core kernel wherever its 128x128 tiles are not mostly padding (skinny N = 64 LoRA projections, a handful of
     // rows: the 64x64 VALU kernel); the two are bit-identical, the choice is speed only
     if (e.N >= 128 && e.M >= 64) {
@@ -2247,15 +2255,18 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
                          ldw1, K1, (const float*)A2, lda2, (const float*)W2, ldw2, K2, e);
     }
   }
+#endif
   return check_launch("gsl_gemm_nt");
 }
 
-extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
+extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
                            const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
                            const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                            const float* pos, const float* cls, int T, float p_drop, uint64_t seed, uint32_t site,
                            gsl_stream_t s) {
-  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
+  GSL_FORWARD_H16(dtype, h16_gsl_gemm_nt(A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, M, N, dtype, epilogue, alpha, bias, res, aux, out, out2,
+                                         ldo, pos, cls, T, p_drop, seed, site, s));
+  GSL_CHECK_ARG((GSL_HAS_F32 && dtype == GSL_F32) || dtype == GSL_OP16, "dtype");
   GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0, "M>0, N>0, N%4==0");
   GSL_CHECK_ARG(K1 > 0 && (K1 % 64) == 0 && K2 >= 0 && (K2 % 64) == 0, "K1,K2 multiples of 64");
   GSL_CHECK_ARG(A1 && W1 && out && (K2 == 0 || (A2 && W2)), "null operand");
@@ -2272,7 +2283,7 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
     case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_F32: return launch_gemm<GSL_EPI_STORE_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
-      GSL_CHECK_ARG(dtype == GSL_BF16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");
+      GSL_CHECK_ARG(dtype == GSL_OP16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");
       e.hmT = T; e.hmH = N / 192;
       return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_RES_F32:
@@ -2282,13 +2293,13 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
       e.f16 = 1;
       [[fallthrough]];
     case GSL_EPI_BIAS_RES_BF16:
-      GSL_CHECK_ARG(bias && res && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/res required, bf16 only");
+      GSL_CHECK_ARG(bias && res && dtype == GSL_OP16 && (ldo % 8) == 0, "bias/res required, bf16 only");
       return launch_gemm<GSL_EPI_BIAS_RES_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_PATCH_F16:
       e.f16 = 1;
       [[fallthrough]];
     case GSL_EPI_PATCH_BF16:
-      GSL_CHECK_ARG(bias && pos && cls && T > 0 && dtype == GSL_BF16 && (ldo % 8) == 0, "bias/pos/cls/T required, bf16 only");
+      GSL_CHECK_ARG(bias && pos && cls && T > 0 && dtype == GSL_OP16 && (ldo % 8) == 0, "bias/pos/cls/T required, bf16 only");
       return launch_gemm<GSL_EPI_PATCH_BF16>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_GELU:
       GSL_CHECK_ARG(bias, "bias required");
@@ -2297,10 +2308,10 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
       GSL_CHECK_ARG(aux, "aux required");
       return launch_gemm<GSL_EPI_MUL>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_GELU_G8:
-      GSL_CHECK_ARG(bias && dtype == GSL_BF16 && (N % 64) == 0, "bias required, bf16 only, N % 64 == 0 (slab-major code tensor)");
+      GSL_CHECK_ARG(bias && dtype == GSL_OP16 && (N % 64) == 0, "bias required, bf16 only, N % 64 == 0 (slab-major code tensor)");
       return launch_gemm<GSL_EPI_BIAS_GELU_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_MUL_G8:      // aux = 8-bit GELU' codes [M, ldo bytes]; p_drop = the dropout rate of the forward that wrote them (no mask is applied here)
-      GSL_CHECK_ARG(aux && dtype == GSL_BF16 && (N % 64) == 0, "aux required, bf16 only, N % 64 == 0 (slab-major code tensor)");
+      GSL_CHECK_ARG(aux && dtype == GSL_OP16 && (N % 64) == 0, "aux required, bf16 only, N % 64 == 0 (slab-major code tensor)");
       return launch_gemm<GSL_EPI_MUL_G8>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_PATCH:
       GSL_CHECK_ARG(bias && pos && cls && T > 0, "bias/pos/cls/T required");
@@ -2309,11 +2320,13 @@ extern "C" int gsl_gemm_nt(const void* A1, int lda1, const void* W1, int ldw1, i
   }
 }
 
-extern "C" int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+extern "C" int GSL_ENTRY(gsl_gemm_nt_lora)(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
                                 int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
                                 const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
-  if (dtype != GSL_BF16) return fail(GSL_ERR_UNSUPPORTED, "gsl_gemm_nt_lora: bf16 only (f32 parity mode uses gsl_gemm_nt with a K segment)%s %ld", "", dtype);
+  GSL_FORWARD_H16(dtype, h16_gsl_gemm_nt_lora(A, lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, tout, ldt, M, N, dtype, epilogue, bias, res, aux, out,
+                                              out2, ldo, p_drop, seed, site, s));
+  if (dtype != GSL_OP16) return fail(GSL_ERR_UNSUPPORTED, "gsl_gemm_nt_lora: bf16 / fp16 operands only (f32 parity mode uses gsl_gemm_nt with a K segment)%s %ld", "", dtype);
   GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && (K % 64) == 0, "M,N>0, N%4==0, K%64==0");
   GSL_CHECK_ARG(A && W && P && Q && out, "null operand");
   GSL_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (ldp % 8) == 0 && (ldq % 8) == 0 && ldq >= 32 && (ldo % 4) == 0 &&
@@ -2398,7 +2411,7 @@ __global__ __launch_bounds__(256) void mulgrad_reduce1_kernel(const float4* __re
 // level 2: fixed-order sum of the slabs, output strides, optional accumulate; blockIdx.y selects the gradient
 __global__ __launch_bounds__(256) void mulgrad_reduce2_kernel(const float* __restrict__ part2, long which_stride, float* G1, long g1sn, long g1sj,
                                                               float* G2, long g2sn, long g2sj, int N, int R, int r, int nslab,
-                                                              int accumulate) {
+                                                              int accumulate, const float* __restrict__ gscale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * R) return;
   const int n = idx / R, j = idx % R;
@@ -2406,18 +2419,25 @@ __global__ __launch_bounds__(256) void mulgrad_reduce2_kernel(const float* __res
   const float* p = part2 + (size_t)blockIdx.y * which_stride;
   float s = 0.f;
   for (int k = 0; k < nslab; ++k) s += p[(size_t)k * N * R + idx];
+  if (gscale) s *= gscale[1];      // fp16 operands: the backward ran on gradients multiplied by gscale[0] (a power of two): exact un-scaling
   float* g = blockIdx.y ? (G2 + (size_t)n * g2sn + (size_t)j * g2sj) : (G1 + (size_t)n * g1sn + (size_t)j * g1sj);
   *g = accumulate ? (*g + s) : s;
 }
+#if GSL_HAS_F32
 extern "C" long gsl_gemm_mulgrad_ws_elems(int M, int N, int r) {
   const long R = (r <= 8) ? 8 : 16;
   const long ntile = (M + BM4 - 1) / BM4, nslab = (ntile + GF_FAN - 1) / GF_FAN;
   return 2 * (ntile + nslab) * (long)N * R;
 }
-extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+#endif
+extern "C" int GSL_ENTRY(gsl_gemm_nt_lora_mulgrad)(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
                                         int ldq, float lora_scale, void* tout, int ldt, int M, int N, const void* aux, void* out,
                                         int ldo, const void* U1, int ldu1, float* G1, long g1sn, long g1sj, const void* Y2, float* G2,
-                                        long g2sn, long g2sj, int r, int accumulate, float* ws, int aux_u8, float p_drop, gsl_stream_t s) {
+                                        long g2sn, long g2sj, int r, int accumulate, float* ws, int aux_u8, float p_drop, int dtype,
+                                        const float* gscale, gsl_stream_t s) {
+  GSL_FORWARD_H16(dtype, h16_gsl_gemm_nt_lora_mulgrad(A, lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, tout, ldt, M, N, aux, out, ldo, U1, ldu1, G1, g1sn,
+                                                      g1sj, Y2, G2, g2sn, g2sj, r, accumulate, ws, aux_u8, p_drop, dtype, gscale, s));
+  GSL_CHECK_ARG(dtype == GSL_OP16, "dtype: bf16 or fp16 operands");
   GSL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "p_drop");
   GSL_CHECK_ARG(M > 0 && N >= 8 && (N % 8) == 0 && K > 0 && (K % 64) == 0, "M>0, N%8==0, K%64==0");
   GSL_CHECK_ARG(A && W && P && Q && out && aux && U1 && G1 && Y2 && G2 && ws, "null operand");
@@ -2453,13 +2473,13 @@ extern "C" int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, i
   const int NR4 = (int)(NR / 4);
   if (nslab == 1) {      // one slab: the second level sums the M tiles itself, in the same order (one launch less in the launch-bound regime)
     hipLaunchKernelGGL(mulgrad_reduce2_kernel, dim3(((int)NR + 255) / 256, 2), dim3(256), 0, st, ws, (long)((size_t)ntile * NR), G1, g1sn,
-                       g1sj, G2, g2sn, g2sj, N, R, r, ntile, accumulate);
+                       g1sj, G2, g2sn, g2sj, N, R, r, ntile, accumulate, gscale);
     return check_launch("gsl_gemm_nt_lora_mulgrad(reduce)");
   }
   hipLaunchKernelGGL(mulgrad_reduce1_kernel, dim3((NR4 + 255) / 256, nslab, 2), dim3(256), 0, st, (const float4*)ws, (float4*)part2, NR4,
                      ntile, (long)((size_t)ntile * NR / 4), (long)((size_t)nslab * NR / 4));
   hipLaunchKernelGGL(mulgrad_reduce2_kernel, dim3(((int)NR + 255) / 256, 2), dim3(256), 0, st, part2, (long)((size_t)nslab * NR), G1, g1sn,
-                     g1sj, G2, g2sn, g2sj, N, R, r, nslab, accumulate);
+                     g1sj, G2, g2sn, g2sj, N, R, r, nslab, accumulate, gscale);
   return check_launch("gsl_gemm_nt_lora_mulgrad(reduce)");
 }
-
+GSL_OPNS_END

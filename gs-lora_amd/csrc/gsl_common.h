@@ -53,27 +53,21 @@ template <> struct Elem<float> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
-template <> struct Elem<bf16_t> {
-  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
-  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
-  static __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
-    uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-  }
-  static __device__ __forceinline__ void st4(bf16_t* p, const float v[4]) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-  }
-};
-
 // ---- fp16 (IEEE binary16): element type of the FORWARD residual stream in speed mode (round 4). The stream is only ever read by
 // LayerNorm kernels and residual-add epilogues — never a matrix-core operand — so it does not need bf16's exponent range, and fp16's 11-bit
 // significand rounds each of the 13 stream tensors of a forward 8x finer than bf16's 8 bits at the same 2 bytes per element
 // (profiles/r04_b_precision_ablation.md: the bf16 stream was 3/4 of the speed mode's logit error). Values are clamped to +-65504 on store.
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 gsl_f16x2;
+// saturating f32 -> fp16: finite values and +-Inf clamp to +-65504, NaN stays NaN. (v_med3_f32 alone returns the middle of the two
+// bounds and a NaN as -65504: a diverged step must stay visible as NaN through every 16-bit tensor, as in the bf16 / f32 forms and in the
+// reference. One v_cmp + v_cndmask on top of the v_med3.)
+__device__ __forceinline__ float clamp_h(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+  return (v != v) ? v : c;
+}
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
-  const gsl_f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+  const gsl_f32x2 v = {clamp_h(lo), clamp_h(hi)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, gsl_f16x2));      // round to nearest even
 }
 __device__ __forceinline__ void unpack2h(uint32_t u, float& lo, float& hi) {
@@ -88,13 +82,60 @@ __device__ __forceinline__ void unpack2s(uint32_t u, int f16, float& lo, float& 
 }
 template <> struct Elem<f16_t> {
   static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
-  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)clamp_h(v); }
   static __device__ __forceinline__ void ld4(const f16_t* p, float v[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
     unpack2h(t.x, v[0], v[1]); unpack2h(t.y, v[2], v[3]);
   }
   static __device__ __forceinline__ void st4(f16_t* p, const float v[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+  }
+};
+
+// ------------------------------------------------------------------ the 16-bit matrix-core operand format of a translation unit
+// The speed mode exists in two operand formats with the SAME kernels, bytes and MFMA rate: bf16 (dtype GSL_BF16: 8-bit significand,
+// f32's exponent range) and IEEE fp16 (dtype GSL_F16, round 5: 11-bit significand; activations clamp at +-65504 on store, the
+// backward runs on gradients multiplied by a power-of-two loss scale that the LoRA-gradient reductions divide out again).
+// gemm.hip and attention.hip are compiled TWICE (gslora_hip/build.py): once plain (bf16 + the f32 parity kernels, the exported entry
+// points) and once with -DGSL_OP_F16 — then every kernel of the file lives in namespace gsl_h16, the operand helpers below mean fp16,
+// only the 16-bit paths are compiled and the entry points are the hidden symbols h16_<name> that the exported ones forward to when
+// dtype == GSL_F16. Storage type of an operand element is uint16_t in both formats (op16_t): every conversion goes through these
+// helpers, nothing converts numerically by accident.
+typedef uint16_t op16_t;
+#ifdef GSL_OP_F16
+#define GSL_OP16 GSL_F16
+#define GSL_OPNS_BEGIN namespace gsl_h16 {
+#define GSL_OPNS_END }
+#define GSL_ENTRY(name) h16_##name
+#define GSL_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+typedef _Float16 gsl_op16_elem;
+__device__ __forceinline__ uint32_t pack2o(float lo, float hi) { return pack2h(lo, hi); }
+__device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) { unpack2h(u, lo, hi); }
+__device__ __forceinline__ float o2f(op16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ op16_t f2o(float f) { return __builtin_bit_cast(op16_t, (_Float16)clamp_h(f)); }
+#else
+#define GSL_OP16 GSL_BF16
+#define GSL_OPNS_BEGIN
+#define GSL_OPNS_END
+#define GSL_ENTRY(name) name
+#define GSL_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+typedef __bf16 gsl_op16_elem;
+__device__ __forceinline__ uint32_t pack2o(float lo, float hi) { return pack2bf(lo, hi); }
+__device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float o2f(op16_t v) { return bf2f(v); }
+__device__ __forceinline__ op16_t f2o(float f) { return f2bf(f); }
+#endif
+typedef __attribute__((ext_vector_type(8))) gsl_op16_elem op16x8_t;      // one MFMA A / B operand: 8 elements per lane
+// element access of an operand tensor (uint16_t storage) in this translation unit's format
+template <> struct Elem<op16_t> {
+  static __device__ __forceinline__ float ld(const op16_t* p) { return o2f(*p); }
+  static __device__ __forceinline__ void st(op16_t* p, float v) { *p = f2o(v); }
+  static __device__ __forceinline__ void ld4(const op16_t* p, float v[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    unpack2o(t.x, v[0], v[1]); unpack2o(t.y, v[2], v[3]);
+  }
+  static __device__ __forceinline__ void st4(op16_t* p, const float v[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
   }
 };
 

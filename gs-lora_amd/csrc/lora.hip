@@ -30,6 +30,13 @@ template <> struct LgVec<bf16_t> {
     v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
   }
 };
+template <> struct LgVec<f16_t> {      // fp16 operands (round 5)
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const f16_t* p, float v[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    unpack2h(t.x, v[0], v[1]); unpack2h(t.y, v[2], v[3]); unpack2h(t.z, v[4], v[5]); unpack2h(t.w, v[6], v[7]);
+  }
+};
 template <> struct LgVec<float> {
   static constexpr int V = 4;
   static __device__ __forceinline__ void ld(const float* p, float v[4]) {
@@ -46,6 +53,12 @@ template <> struct LgRaw<bf16_t> {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
     v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
     v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+template <> struct LgRaw<f16_t> {
+  typedef uint4 type;
+  static __device__ __forceinline__ void unpack(const uint4 t, float v[8]) {
+    unpack2h(t.x, v[0], v[1]); unpack2h(t.y, v[2], v[3]); unpack2h(t.z, v[4], v[5]); unpack2h(t.w, v[6], v[7]);
   }
 };
 template <> struct LgRaw<float> {
@@ -162,10 +175,13 @@ __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restr
 typedef short lg_v4s_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) lg_v4s_t* lg_lds_v4s_p;
 typedef __attribute__((ext_vector_type(8))) __bf16 lg_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 lg_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float lg_f32x4_t;
 constexpr int LGM_CN = 256, LGM_YLD = LGM_CN + 16, LGM_ULD = 32, LGM_K = 32;
 
 // body of one workgroup: column block bxi (256 columns of Y), row split `split`; R = padded rank of the partial layout (8 or 16)
+// F16: the operands are IEEE fp16 (dtype GSL_F16) instead of bf16 — the same bytes through the same LDS path, the other MFMA opcode
+template <bool F16>
 __device__ __forceinline__ void lgm_block(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
                                           float* __restrict__ part, int M, int N, int rows_per_split, int R, int bxi, int split) {
   __shared__ __attribute__((aligned(16))) bf16_t ys[2][LGM_K * LGM_YLD];
@@ -204,16 +220,17 @@ __device__ __forceinline__ void lgm_block(const bf16_t* __restrict__ Y, long ldy
     const int buf = it & 1;
     const bool more = rb + LGM_K < r1;
     if (more) gload(rb + LGM_K);
-    union { lg_v4s_t h[2]; lg_bf16x8_t v; } bf;
+    union { lg_v4s_t h[2]; lg_bf16x8_t v; lg_f16x8_t w; } bf;
     bf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(&us[buf][trow * LGM_ULD + tcol]));
     bf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(&us[buf][(trow + 16) * LGM_ULD + tcol]));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      union { lg_v4s_t h[2]; lg_bf16x8_t v; } af;
+      union { lg_v4s_t h[2]; lg_bf16x8_t v; lg_f16x8_t w; } af;
       const bf16_t* p = &ys[buf][trow * LGM_YLD + wave * 64 + t * 16 + tcol];
       af.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(p));
       af.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lg_lds_v4s_p)(p + 16 * LGM_YLD));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc[t], 0, 0, 0);
+      if constexpr (F16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.w, bf.w, acc[t], 0, 0, 0);
+      else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc[t], 0, 0, 0);
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();
@@ -229,10 +246,10 @@ __device__ __forceinline__ void lgm_block(const bf16_t* __restrict__ Y, long ldy
       }
   }
 }
-template <int R>
+template <int R, bool F16>
 __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
                                                              float* __restrict__ part, int M, int N, int rows_per_split) {
-  lgm_block(Y, ldy, U, ldu, part, M, N, rows_per_split, R, blockIdx.x, blockIdx.y);
+  lgm_block<F16>(Y, ldy, U, ldu, part, M, N, rows_per_split, R, blockIdx.x, blockIdx.y);
 }
 
 // ---- batched form: every LoRA-gradient reduction of a backward pass in two launches (the launch-bound regime: few-shot batches run 24
@@ -245,15 +262,16 @@ struct LgbEntry {
 };
 struct LgbArgs { int n; LgbEntry e[LGB_MAX]; };
 
+template <bool F16>
 __global__ __launch_bounds__(256) void lora_grad_batch_partial_kernel(const LgbArgs a, float* __restrict__ ws) {
   int d = 0;
   for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].wg0) ? k : d;
   const LgbEntry& e = a.e[d];
   const int local = (int)blockIdx.x - e.wg0;
-  lgm_block(e.Y, e.ldy, e.U, e.ldu, ws + e.ws0, e.M, e.N, e.rps, e.R, local % e.bx, local / e.bx);
+  lgm_block<F16>(e.Y, e.ldy, e.U, e.ldu, ws + e.ws0, e.M, e.N, e.rps, e.R, local % e.bx, local / e.bx);
 }
 // fixed-order sum of an entry's splits, output strides (+ accumulate) applied on the way out
-__global__ __launch_bounds__(256) void lora_grad_batch_reduce_kernel(const LgbArgs a, const float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void lora_grad_batch_reduce_kernel(const LgbArgs a, const float* __restrict__ ws, const float* __restrict__ gscale) {
   int d = 0;
   for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].rb0) ? k : d;
   const LgbEntry& e = a.e[d];
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(256) void lora_grad_batch_reduce_kernel(const LgbAr
   const size_t NR = (size_t)e.N * e.R;
   float s = 0.f;
   for (int k = 0; k < e.nsplit; ++k) s += p[(size_t)k * NR];
+  if (gscale) s *= gscale[1];      // loss-scaled backward (fp16 operands): divide the power-of-two scale out, exactly
   float* g = e.G + (size_t)n * e.gsn + (size_t)j * e.gsj;
   *g = e.acc ? (*g + s) : s;
 }
@@ -278,7 +297,7 @@ static inline void lgm_plan(int M, int N, int& bx, int& nsplit, int& rps) {
   rps = ((steps + nsplit - 1) / nsplit) * LGM_K;
   nsplit = (M + rps - 1) / rps;
 }
-static inline bool lgm_usable(int M, int N, int ldu, int dtype) { return dtype == GSL_BF16 && (N % LGM_CN) == 0 && ldu >= 16 && M >= 64; }
+static inline bool lgm_usable(int M, int N, int ldu, int dtype) { return dtype != GSL_F32 && (N % LGM_CN) == 0 && ldu >= 16 && M >= 64; }
 
 // level 1: thread (idx, sb) sums LG_FAN consecutive splits  -> part2[sb][idx]
 __global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ part2,
@@ -293,13 +312,14 @@ __global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __r
 // level 2: fixed-order sum of the level-1 slabs, apply output strides (+ accumulate)
 template <int R>
 __global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __restrict__ part2, float* G, long gsn, long gsj,
-                                                                int N, int r, int nslab, int accumulate) {
+                                                                int N, int r, int nslab, int accumulate, const float* __restrict__ gscale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * R) return;
   const int n = idx / R, j = idx % R;
   if (j >= r) return;
   float s = 0.f;
   for (int k = 0; k < nslab; ++k) s += part2[(size_t)k * N * R + idx];
+  if (gscale) s *= gscale[1];
   float* g = G + (size_t)n * gsn + (size_t)j * gsj;
   *g = accumulate ? (*g + s) : s;
 }
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __r
 // split, the 4 sub-sums are combined through LDS in wave order (deterministic), output strides (+ accumulate) applied on the way out
 template <int R>
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ part, float* G, long gsn, long gsj, int N, int r,
-                                                               int nsplit, int accumulate) {
+                                                               int nsplit, int accumulate, const float* __restrict__ gscale) {
   __shared__ float sm[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + l, NR = N * R;
@@ -318,7 +338,8 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __re
   sm[w][l] = s;
   __syncthreads();
   if (w == 0 && idx < NR) {
-    const float t = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    float t = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    if (gscale) t *= gscale[1];
     const int n = idx / R, j = idx % R;
     if (j < r) {
       float* g = G + (size_t)n * gsn + (size_t)j * gsj;
@@ -359,11 +380,11 @@ extern "C" long gsl_lora_grad_ws_elems(int M, int N, int r) {
 }
 
 extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj, int M, int N, int r,
-                             int dtype, int accumulate, float* ws, gsl_stream_t s) {
+                             int dtype, int accumulate, float* ws, const float* gscale, gsl_stream_t s) {
   GSL_CHECK_ARG(Y && U && G && ws && M > 0 && N > 0 && ldy >= N, "null/size");
   GSL_CHECK_ARG(r >= 1 && r <= 16 && ldu >= 16 && (ldu % 8) == 0, "r in [1,16], ldu >= 16 (zero-padded)");
-  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
-  const int V = (dtype == GSL_BF16) ? 8 : 4;
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16 || dtype == GSL_F16, "dtype");
+  const int V = (dtype != GSL_F32) ? 8 : 4;
   GSL_CHECK_ARG((N % V) == 0, "N must be a multiple of the vector width");
   hipStream_t st = as_stream(s);
   const int R = (r <= 8) ? 8 : 16;
@@ -378,22 +399,24 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
     if (want && lgm_usable(M, N, ldu, dtype) && (reinterpret_cast<uintptr_t>(U) % 16) == 0 && (reinterpret_cast<uintptr_t>(Y) % 16) == 0 &&
         ((size_t)ldu * 2) % 16 == 0 && ((size_t)ldy * 2) % 16 == 0) {
       lgm_plan(M, N, bx, nsplit, rps);
-      if (R == 8) hipLaunchKernelGGL(lora_grad_mfma_kernel<8>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, ws, M, N, rps);
-      else hipLaunchKernelGGL(lora_grad_mfma_kernel<16>, dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, ws, M, N, rps);
+#define GSL_LGM(RR, FF) hipLaunchKernelGGL((lora_grad_mfma_kernel<RR, FF>), dim3(bx, nsplit), dim3(256), 0, st, (const bf16_t*)Y, ldy, (const bf16_t*)U, ldu, ws, M, N, rps)
+      if (dtype == GSL_F16) { if (R == 8) GSL_LGM(8, true); else GSL_LGM(16, true); }
+      else { if (R == 8) GSL_LGM(8, false); else GSL_LGM(16, false); }
+#undef GSL_LGM
       int rc0 = check_launch("gsl_lora_grad(mfma partial)");
       if (rc0) return rc0;
       const int totm = N * R;
       if (nsplit <= 160 && totm >= 8192) {     // few splits, many outputs: one launch (measured 166 -> 162 us at N = 2048; at N = 512 the two-level form wins)
-        if (R == 8) hipLaunchKernelGGL(lora_grad_reduce_kernel<8>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
-        else hipLaunchKernelGGL(lora_grad_reduce_kernel<16>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate);
+        if (R == 8) hipLaunchKernelGGL(lora_grad_reduce_kernel<8>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate, gscale);
+        else hipLaunchKernelGGL(lora_grad_reduce_kernel<16>, dim3((totm + 63) / 64), dim3(256), 0, st, ws, G, gsn, gsj, N, r, nsplit, accumulate, gscale);
         return check_launch("gsl_lora_grad(reduce)");
       }
       float* part2m = ws + (size_t)nsplit * N * R;
       int nslabm = (nsplit + LG_FAN - 1) / LG_FAN;
       if (nslabm == 1) { part2m = ws; nslabm = nsplit; }      // one slab: the second level sums the splits itself, in the same order (one launch less)
       else hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((totm + 255) / 256, nslabm), dim3(256), 0, st, ws, part2m, totm, nsplit);
-      if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
-      else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate);
+      if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate, gscale);
+      else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((totm + 255) / 256), dim3(256), 0, st, part2m, G, gsn, gsj, N, r, nslabm, accumulate, gscale);
       return check_launch("gsl_lora_grad(reduce)");
     }
   }
@@ -405,6 +428,7 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
   hipLaunchKernelGGL((lora_grad_partial_kernel<TT, RR>), dim3(bx, nsplit), dim3(256), red_bytes, st, (const TT*)Y, ldy, (const TT*)U, \
                      ldu, ws, M, N, rps, CG)
   if (dtype == GSL_BF16) { if (R == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
+  else if (dtype == GSL_F16) { if (R == 8) LAUNCH(f16_t, 8); else LAUNCH(f16_t, 16); }
   else { if (R == 8) LAUNCH(float, 8); else LAUNCH(float, 16); }
 #undef LAUNCH
   int rc = check_launch("gsl_lora_grad(partial)");
@@ -413,8 +437,8 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
   int nslab = (nsplit + LG_FAN - 1) / LG_FAN;
   if (nslab == 1) { part2 = ws; nslab = nsplit; }
   else hipLaunchKernelGGL(lora_grad_reduce1_kernel, dim3((tot + 255) / 256, nslab), dim3(256), 0, st, ws, part2, tot, nsplit);
-  if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
-  else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate);
+  if (R == 8) hipLaunchKernelGGL(lora_grad_reduce2_kernel<8>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate, gscale);
+  else hipLaunchKernelGGL(lora_grad_reduce2_kernel<16>, dim3((tot + 255) / 256), dim3(256), 0, st, part2, G, gsn, gsj, N, r, nslab, accumulate, gscale);
   return check_launch("gsl_lora_grad(reduce)");
 }
 
@@ -521,16 +545,18 @@ extern "C" long gsl_lora_grad_batch_ws_elems(const gsl_lgrad_desc* descs, int n)
 
 // n LoRA-gradient reductions G_k (+)= Y_k^T U_k (bf16 operands, see gsl_lora_grad) in two launches per 24 descriptors. descs is a HOST
 // array: the launch carries the descriptors by value (HIP-graph capture keeps them). The G_k of one call must not overlap.
-extern "C" int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, gsl_stream_t s) {
+extern "C" int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, int dtype, const float* gscale, gsl_stream_t s) {
   GSL_CHECK_ARG(descs && n > 0 && ws, "null/size");
+  GSL_CHECK_ARG(dtype == GSL_BF16 || dtype == GSL_F16, "dtype: bf16 or fp16 operands");
   hipStream_t st = as_stream(s);
   for (int k0 = 0; k0 < n; k0 += LGB_MAX) {
     LgbArgs a;
     int nwg = 0, nrb = 0;
     const int rc = lgb_plan(descs + k0, min(LGB_MAX, n - k0), &a, nullptr, &nwg, &nrb);
     if (rc) return rc;
-    hipLaunchKernelGGL(lora_grad_batch_partial_kernel, dim3(nwg), dim3(256), 0, st, a, ws);
-    hipLaunchKernelGGL(lora_grad_batch_reduce_kernel, dim3(nrb), dim3(256), 0, st, a, (const float*)ws);
+    if (dtype == GSL_F16) hipLaunchKernelGGL(lora_grad_batch_partial_kernel<true>, dim3(nwg), dim3(256), 0, st, a, ws);
+    else hipLaunchKernelGGL(lora_grad_batch_partial_kernel<false>, dim3(nwg), dim3(256), 0, st, a, ws);
+    hipLaunchKernelGGL(lora_grad_batch_reduce_kernel, dim3(nrb), dim3(256), 0, st, a, (const float*)ws, gscale);
     const int rc2 = check_launch("gsl_lora_grad_batch");
     if (rc2) return rc2;
   }
@@ -638,6 +664,7 @@ extern "C" int gsl_cast(const float* in, void* out, long n, int dtype, gsl_strea
   GSL_CHECK_ARG(in && out && n > 0, "null/size");
   const int grid = (int)min((n + 255) / 256, (long)(256 * 16));
   if (dtype == GSL_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, (bf16_t*)out, n);
+  else if (dtype == GSL_F16) hipLaunchKernelGGL(cast_kernel<f16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, (f16_t*)out, n);
   else if (dtype == GSL_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, as_stream(s), in, (float*)out, n);
   else return fail(GSL_ERR_ARG, "gsl_cast: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_cast");
@@ -661,6 +688,7 @@ extern "C" int gsl_transpose_cast(const float* in, void* out, int R, int C, int 
   GSL_CHECK_ARG(in && out && R > 0 && C > 0, "null/size");
   dim3 grid((C + 31) / 32, (R + 31) / 32), blk(32, 8);
   if (dtype == GSL_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, blk, 0, as_stream(s), in, (bf16_t*)out, R, C);
+  else if (dtype == GSL_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, blk, 0, as_stream(s), in, (f16_t*)out, R, C);
   else if (dtype == GSL_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, blk, 0, as_stream(s), in, (float*)out, R, C);
   else return fail(GSL_ERR_ARG, "gsl_transpose_cast: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_transpose_cast");
@@ -682,6 +710,7 @@ extern "C" int gsl_pack_pad(const float* in, long si, long sj, int rows, int col
   const long tot = (long)rows_out * ld_out;
   const int grid = (int)min((tot + 255) / 256, (long)(256 * 8));
   if (dtype == GSL_BF16) hipLaunchKernelGGL(pack_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, si, sj, rows, cols, scale, (bf16_t*)out, rows_out, ld_out);
+  else if (dtype == GSL_F16) hipLaunchKernelGGL(pack_pad_kernel<f16_t>, dim3(grid), dim3(256), 0, as_stream(s), in, si, sj, rows, cols, scale, (f16_t*)out, rows_out, ld_out);
   else if (dtype == GSL_F32) hipLaunchKernelGGL(pack_pad_kernel<float>, dim3(grid), dim3(256), 0, as_stream(s), in, si, sj, rows, cols, scale, (float*)out, rows_out, ld_out);
   else return fail(GSL_ERR_ARG, "gsl_pack_pad: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_pack_pad");
@@ -703,6 +732,7 @@ extern "C" int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long ma
   GSL_CHECK_ARG(descs_dev && n > 0 && max_elems > 0, "null/size");
   const dim3 grid((unsigned)min((max_elems + 255) / 256, (long)64), (unsigned)n);
   if (dtype == GSL_BF16) hipLaunchKernelGGL(pack_pad_batch_kernel<bf16_t>, grid, dim3(256), 0, as_stream(s), descs_dev);
+  else if (dtype == GSL_F16) hipLaunchKernelGGL(pack_pad_batch_kernel<f16_t>, grid, dim3(256), 0, as_stream(s), descs_dev);
   else if (dtype == GSL_F32) hipLaunchKernelGGL(pack_pad_batch_kernel<float>, grid, dim3(256), 0, as_stream(s), descs_dev);
   else return fail(GSL_ERR_ARG, "gsl_pack_pad_batch: bad dtype%s %ld", "", dtype);
   return check_launch("gsl_pack_pad_batch");

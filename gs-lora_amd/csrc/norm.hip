@@ -128,14 +128,15 @@ template <int NPL>
 static int ln_fwd_launch(const void* x, long xs, const float* gamma, const float* beta, float eps, void* y, float* mean,
                          float* rstd, int M, int dtype, int xdtype, hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
-  if (dtype == GSL_BF16 && xdtype == GSL_F16)
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t, f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
-  else if (dtype == GSL_BF16 && xdtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
-  else if (dtype == GSL_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, bf16_t, float>), dim3(grid), dim3(256), 0, st, (const float*)x, xs, gamma, beta, eps, (bf16_t*)y, mean, rstd, M);
-  else
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, xs, gamma, beta, eps, (float*)y, mean, rstd, M);
+#define GSL_LNF(T, X)                                                                                                              \
+  hipLaunchKernelGGL((ln_fwd_kernel<NPL, T, X>), dim3(grid), dim3(256), 0, st, (const X*)x, xs, gamma, beta, eps, (T*)y, mean, rstd, M)
+  if (dtype == GSL_F16 && xdtype == GSL_F16) GSL_LNF(f16_t, f16_t);      // fp16 operands (round 5): y is an fp16 MFMA operand
+  else if (dtype == GSL_F16) GSL_LNF(f16_t, float);
+  else if (dtype == GSL_BF16 && xdtype == GSL_F16) GSL_LNF(bf16_t, f16_t);
+  else if (dtype == GSL_BF16 && xdtype == GSL_BF16) GSL_LNF(bf16_t, bf16_t);
+  else if (dtype == GSL_BF16) GSL_LNF(bf16_t, float);
+  else GSL_LNF(float, float);
+#undef GSL_LNF
   return check_launch("gsl_layernorm_fwd");
 }
 
@@ -147,7 +148,11 @@ static int ln_bwd_launch(const void* dy, const void* x, long xs, const float* ga
 #define GSL_LNB(T, S, X)                                                                                                            \
   hipLaunchKernelGGL((ln_bwd_kernel<NPL, T, S, X>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const X*)x, xs, gamma, mean, rstd, \
                      (const S*)dres, (S*)dx, ios, (T*)dxb, M, drop, drs, cls_T)
-  if (dtype == GSL_BF16 && sdtype == GSL_BF16 && xdtype == GSL_F16) GSL_LNB(bf16_t, bf16_t, f16_t);
+  if (dtype == GSL_F16 && sdtype == GSL_F16 && xdtype == GSL_F16) GSL_LNB(f16_t, f16_t, f16_t);      // fp16 operands: loss-scaled gradients
+  else if (dtype == GSL_F16 && sdtype == GSL_F16) GSL_LNB(f16_t, f16_t, float);
+  else if (dtype == GSL_F16 && xdtype == GSL_F16) GSL_LNB(f16_t, float, f16_t);
+  else if (dtype == GSL_F16) GSL_LNB(f16_t, float, float);
+  else if (dtype == GSL_BF16 && sdtype == GSL_BF16 && xdtype == GSL_F16) GSL_LNB(bf16_t, bf16_t, f16_t);
   else if (dtype == GSL_BF16 && xdtype == GSL_F16) GSL_LNB(bf16_t, float, f16_t);
   else if (dtype == GSL_BF16 && sdtype == GSL_BF16 && xdtype == GSL_BF16) GSL_LNB(bf16_t, bf16_t, bf16_t);
   else if (dtype == GSL_BF16 && sdtype == GSL_BF16) GSL_LNB(bf16_t, bf16_t, float);
@@ -271,8 +276,9 @@ __global__ __launch_bounds__(256, (KS <= 16 ? 4 : 3)) void ln_fwd_lora_kernel(co
 extern "C" int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                                  void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0, "null/size");
-  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
-  GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16), "x dtype (bf16 / fp16 only in bf16 mode)");
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16 || dtype == GSL_F16, "dtype");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16) || (x_dtype == GSL_F16 && dtype == GSL_F16),
+                "x dtype (a 16-bit stream only in a 16-bit mode; bf16 stream only with bf16 operands)");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
 #define CALL(N) ln_fwd_launch<N>(x, x_row_stride, gamma, beta, eps, y, mean, rstd, M, dtype, x_dtype, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
@@ -284,9 +290,10 @@ extern "C" int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_strid
                                  int dtype, int stream_dtype, int x_dtype, float p_drop, uint64_t seed, uint32_t site,
                                  long drop_row_stride, int dres_cls_T, gsl_stream_t s) {
   GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
-  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16, "dtype");
-  GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == GSL_BF16 && dtype == GSL_BF16), "stream dtype (bf16 only in bf16 mode)");
-  GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16), "x dtype (bf16 / fp16 only in bf16 mode)");
+  GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16 || dtype == GSL_F16, "dtype");
+  GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == dtype && dtype != GSL_F32), "stream dtype (f32, or the operand format of a 16-bit mode)");
+  GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16) || (x_dtype == GSL_F16 && dtype == GSL_F16),
+                "x dtype (a 16-bit stream only in a 16-bit mode; bf16 stream only with bf16 operands)");
   GSL_CHECK_ARG((x_row_stride % 4) == 0, "row stride alignment");
   GSL_CHECK_ARG(dres_cls_T >= 0 && (dres_cls_T == 0 || (dres && dres != dx)), "dres_cls_T: compact dres, out of place");
   const DropCfg drop = make_drop(p_drop, seed, site);

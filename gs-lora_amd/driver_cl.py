@@ -76,7 +76,7 @@ def get_args(argv=None):
     p.add_argument("--pro_r_weight", type=float, default=0.01)
     p.add_argument("--lora_rank", type=int, default=8)
     p.add_argument("--dropout", type=float, default=0.1)
-    p.add_argument("--dtype", default="bf16")
+    p.add_argument("--dtype", default=os.environ.get("GSLORA_DTYPE", "fp16"), help="fp16 | bf16 (16-bit MFMA operands) | fp32 (parity mode)")
     p.add_argument("--small", action="store_true", help="shrunken model (48 px, dim 128, depth 3) for tests")
     p.add_argument("--outdir", default=None)
     p.add_argument("--seed", type=int, default=1337)

@@ -107,6 +107,13 @@ def train_one_epoch(model: torch.nn.Module, dataloader_forget, dataloader_remain
 
 # dtype eval_data() evaluates in: "fp32" (default: the reference's arithmetic), "bf16", or "model" (the model's own training mode)
 EVAL_DTYPE = os.environ.get("GSLORA_EVAL_DTYPE", "fp32").lower()
+_EVAL_SAME = ("model", "train", "same", "")
+if EVAL_DTYPE not in _EVAL_SAME:      # validated at import (a typo must not surface at the first evaluate(), an eval interval into the run)
+    from vit_pytorch_face.vit_face import compute_dtype_of as _cdt
+    try:
+        _cdt(EVAL_DTYPE)
+    except ValueError as e:
+        raise ValueError(f"GSLORA_EVAL_DTYPE={EVAL_DTYPE!r}: use one of {_EVAL_SAME[:3]} or a compute dtype name ({e})") from None
 
 
 def save_rank():
@@ -180,7 +187,7 @@ def eval_data(model, dataloader, device, mode: str, batch: int = 0):
     # mode instead (bf16 speed), =bf16 / =fp32 force a mode.
     net = _unwrap(model)
     eval_dt, train_dt = EVAL_DTYPE, getattr(net, "compute_dtype", None)
-    if eval_dt in ("model", "train", "same", "") or not hasattr(net, "set_compute_dtype"):
+    if eval_dt in _EVAL_SAME or not hasattr(net, "set_compute_dtype"):
         eval_dt = None
     if eval_dt:
         net.set_compute_dtype(eval_dt)

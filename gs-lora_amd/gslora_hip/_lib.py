@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSLORA_HIP_LIB") or os.path.join(_HERE, "libgslora_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libgslora_hip_dev.so")
 
-F32, BF16, F16 = 0, 1, 2      # F16: the x_dtype of a forward residual stream carried in IEEE fp16 (bf16 speed mode only)
+F32, BF16, F16 = 0, 1, 2      # F16: IEEE fp16 MFMA operands (round 5) — and, as an x_dtype, the forward residual stream format of both 16-bit modes
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM, EPI_BIAS_RES_BF16, EPI_PATCH_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 EPI_MUL_G8, EPI_BIAS_GELU_G8, EPI_BIAS_RES_F16, EPI_PATCH_F16 = 9, 10, 11, 12
 NORM_SPLIT = 8
@@ -35,7 +35,7 @@ SIGNATURES = {
                          _f, _u64, _u32, _vp],
     "gsl_gemm_mulgrad_ws_elems": [_i, _i, _i],
     "gsl_gemm_nt_lora_mulgrad": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _i,
-                                 _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _i, _f, _vp],
+                                 _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _i, _f, _i, _vp, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gsl_layernorm_fwd_lora": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
@@ -44,12 +44,12 @@ SIGNATURES = {
     "gsl_attention_fwd_cls": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_bwd_cls": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp],
     "gsl_lora_grad_ws_elems": [_i, _i, _i],
-    "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp],
+    "gsl_lora_grad": [_vp, _l, _vp, _i, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "gsl_lora_grad_batch_ws_elems": [_vp, _i],
-    "gsl_lora_grad_batch": [_vp, _i, _vp, _vp],
+    "gsl_lora_grad_batch": [_vp, _i, _vp, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
     "gsl_head_fwd": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
-    "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp, _vp, _vp],
     "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -15,7 +15,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 SOURCES = ["gemm.hip", "norm.hip", "lora.hip", "head.hip", "attention.hip"]
-HEADERS = ["gsl_common.h", "exports.map"]
+# translation units that are compiled a second time with -DGSL_OP_F16: the same kernels with IEEE fp16 MFMA operands (dtype GSL_F16), in
+# namespace gsl_h16, behind hidden h16_<entry> symbols that the exported entry points forward to (csrc/gsl_common.h, csrc/gsl_h16.h)
+SOURCES_F16 = ["gemm.hip", "attention.hip"]
+HEADERS = ["gsl_common.h", "gsl_h16.h", "exports.map", "gelu_g8_table.inc"]
 DEV_ONLY = ["gemm_dev_a.inc", "gemm_dev_b.inc"]
 OUT = os.path.join(HERE, "libgslora_hip.so")
 OUT_DEV = os.path.join(HERE, "libgslora_hip_dev.so")
@@ -44,10 +47,12 @@ def build(force=False, verbose=True, dev=False, defines=(), out=None, tag=None):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + (["-DGSL_DEV"] if dev else []) + list(defines)
     procs = []
     objs = []
-    for src in SOURCES:      # one hipcc per translation unit, in parallel (gemm.hip dominates)
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES] + [(src, src.replace(".hip", "_f16.o"), ["-DGSL_OP_F16"]) for src in SOURCES_F16]
+    units.sort(key=lambda u: u[0] != "gemm.hip")      # the two gemm.hip compiles dominate: start them first
+    for src, oname, extra in units:      # one hipcc per translation unit, in parallel
+        obj = os.path.join(objdir, oname)
         objs.append(obj)
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[gslora_hip.build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

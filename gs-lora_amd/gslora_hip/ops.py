@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 
-DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}      # (fp16: element type of the forward residual stream only)
+DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}      # (fp16: MFMA operand format of the "fp16" mode; also the forward residual stream of both 16-bit modes)
 
 
 def _p(t):
@@ -99,17 +99,18 @@ def gemm_nt_lora(A, W, P, Q, lora_scale, tout, out, *, epilogue=L.EPI_STORE, bia
     return out
 
 
-def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True, tag=None, p_drop=0.0):
+def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate=True, tag=None, p_drop=0.0, gscale=None):
     """out = (A W^T + t Q^T) * aux with t = lora_scale * A P^T (as gemm_nt_lora, epilogue MUL) and, from the same tiles,
     G1[n*g1s[0] + j*g1s[1]] (+)= sum_m out[m,n] U1[m,j] and G2[n*g2s[0] + j*g2s[1]] (+)= sum_m Y2[m,n] t[m,j].
-    A uint8 aux is the 8-bit GELU' code of EPI_BIAS_GELU_G8; p_drop is then the dropout rate of the forward that wrote it."""
-    _need(A, W, P, Q, tout, out, aux, U1, Y2)
+    A uint8 aux is the 8-bit GELU' code of EPI_BIAS_GELU_G8; p_drop is then the dropout rate of the forward that wrote it.
+    gscale: device {S, 1/S} of a loss-scaled (fp16) backward — G1 / G2 receive the sums multiplied by 1/S."""
+    _need(A, W, P, Q, tout, out, aux, U1, Y2, gscale)
     M, K = A.shape
     N = W.shape[0]
     if PROFILE is not None and tag in PROFILE:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate, p_drop=p_drop)
+        gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2, G2, g2s, r, accumulate, p_drop=p_drop, gscale=gscale)
         ev[1].record()
         PROFILE[tag].append((ev[0], ev[1], M, N, K, 0))
         return out
@@ -128,7 +129,7 @@ def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2
                                          float(lora_scale), _p(tout), 0 if tout is None else tout.stride(0), M, N, _p(aux), _p(out),
                                          out.stride(0), _p(U1), U1.stride(0), G1.data_ptr(), g1s[0], g1s[1], _p(Y2), G2.data_ptr(),
                                          g2s[0], g2s[1], r, 1 if accumulate else 0, _p(ws), 1 if aux.dtype == torch.uint8 else 0,
-                                         float(p_drop), _stream()), "gsl_gemm_nt_lora_mulgrad")
+                                         float(p_drop), code(A.dtype), _p(gscale), _stream()), "gsl_gemm_nt_lora_mulgrad")
     return out
 
 
@@ -230,9 +231,9 @@ _ws_cache = {}
 _ws_retired = []
 
 
-def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
+def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True, gscale=None):
     """G[n*gsn + j*gsj] (+)= sum_m Y[m,n] U[m,j]; G is a view into the flat f32 gradient bucket. Y / U may be column blocks of wider
-    row-major tensors (unit column stride)."""
+    row-major tensors (unit column stride). gscale: device {S, 1/S} of a loss-scaled (fp16) backward: the sum is multiplied by 1/S."""
     if not (Y.is_cuda and U.is_cuda and Y.stride(1) == 1 and U.stride(1) == 1):
         raise RuntimeError("lora_grad: operands must be CUDA tensors with unit column stride")
     M, N = Y.shape
@@ -246,7 +247,7 @@ def lora_grad(Y, U, G, gsn, gsj, r, accumulate=True):
         ws = torch.empty(max(need, 1 << 22), device=Y.device, dtype=torch.float32)
         _ws_cache[key] = ws
     L.check(lib.gsl_lora_grad(_p(Y), Y.stride(0), _p(U), U.stride(0), G.data_ptr(), gsn, gsj, M, N, r, code(Y.dtype),
-                              1 if accumulate else 0, _p(ws), _stream()), "gsl_lora_grad")
+                              1 if accumulate else 0, _p(ws), _p(gscale), _stream()), "gsl_lora_grad")
 
 
 class _LgradDesc(ctypes.Structure):      # mirrors struct gsl_lgrad_desc (include/gslora_hip.h), 72 bytes
@@ -256,13 +257,13 @@ class _LgradDesc(ctypes.Structure):      # mirrors struct gsl_lgrad_desc (includ
 
 
 def lora_grad_batchable(Y, U, r):
-    """Can this reduction ride in gsl_lora_grad_batch (bf16 MFMA form: 256-column blocks, 16-byte rows)?"""
-    return (Y.dtype == torch.bfloat16 and U.dtype == torch.bfloat16 and Y.is_cuda and Y.stride(1) == 1 and U.stride(1) == 1
+    """Can this reduction ride in gsl_lora_grad_batch (16-bit MFMA form: 256-column blocks, 16-byte rows)?"""
+    return (Y.dtype in (torch.bfloat16, torch.float16) and U.dtype == Y.dtype and Y.is_cuda and Y.stride(1) == 1 and U.stride(1) == 1
             and Y.shape[1] % 256 == 0 and Y.stride(0) % 8 == 0 and U.stride(0) % 8 == 0 and U.stride(0) >= 16 and 1 <= r <= 16
             and Y.data_ptr() % 16 == 0 and U.data_ptr() % 16 == 0)
 
 
-def lora_grad_batch(entries):
+def lora_grad_batch(entries, gscale=None):
     """entries: [(Y, U, G, gsn, gsj, r, accumulate)] as for lora_grad — all of them in two launches (gsl_lora_grad_batch). The
     descriptors travel in the kernel arguments: nothing to keep alive on the host, HIP-graph capture friendly."""
     if not entries:
@@ -284,7 +285,7 @@ def lora_grad_batch(entries):
             _ws_retired.append(ws)      # a captured HIP graph may still launch with the old workspace: never free it
         ws = torch.empty(max(need, 1 << 22), device=dev, dtype=torch.float32)
         _ws_cache[key] = ws
-    L.check(lib.gsl_lora_grad_batch(arr, len(entries), _p(ws), _stream()), "gsl_lora_grad_batch")
+    L.check(lib.gsl_lora_grad_batch(arr, len(entries), _p(ws), code(entries[0][0].dtype), _p(gscale), _stream()), "gsl_lora_grad_batch")
 
 
 def loss_combine(ce_r_sum, ce_f_sum, kl_f_sum, kl_r_sum, structure, hit_r, hit_f, n_r, n_f, beta, BND, alpha, w_f, w_r, BND_pro):
@@ -348,16 +349,20 @@ def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=No
 
 
 def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False,
-             pool_mean=False, stream_dtype=torch.float32, compact=False):
-    """compact (pool='cls' only): dx / dxb are [B, D] — the cls rows alone, nothing zero-filled."""
-    _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn)
+             pool_mean=False, stream_dtype=torch.float32, compact=False, gscale=None):
+    """compact (pool='cls' only): dx / dxb are [B, D] — the cls rows alone, nothing zero-filled.
+    gscale: f32 [2] device tensor -> loss-scaled gradients (fp16 operands): dx / dxb come out multiplied by the power of two S the
+    kernel picks from their largest magnitude, and gscale receives {S, 1/S} for the LoRA-gradient reductions (gsl_head_bwd)."""
+    _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn, gscale)
+    amax_ws = torch.empty(B, device=x.device, dtype=torch.float32) if gscale is not None else None
     rows = B if compact else B * T
     dx = torch.empty(rows, D, device=x.device, dtype=stream_dtype)
     dxb = torch.empty(rows, D, device=x.device, dtype=dtype)
     C = Wn.shape[0] if Wn is not None else 0
     L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), code(x.dtype), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
                                   _p(dxb), B, D, C, float(cos_s), code(dtype), code(stream_dtype), float(p_drop), int(seed), int(site),
-                                  1 if linear else 0, 1 if pool_mean else 0, 1 if compact else 0, _stream()), "gsl_head_bwd")
+                                  1 if linear else 0, 1 if pool_mean else 0, 1 if compact else 0, _p(gscale), _p(amax_ws), _stream()),
+            "gsl_head_bwd")
     return dx, dxb
 
 

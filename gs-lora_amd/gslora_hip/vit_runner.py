@@ -16,6 +16,7 @@ from . import _lib as L
 from . import ops
 
 PADK = 64                                  # LoRA K-segment width fed to the GEMM (r zero-padded to 64)
+OP16 = (torch.bfloat16, torch.float16)     # the two operand formats of the speed mode ("bf16" / "fp16")
 SITE_EMB = 1_000_000
 # ---- numeric form of the bf16 speed mode: the three PRODUCT knobs (read once from the environment; module attributes, so a caller /
 # tools/precision_ablation.py / the tests can also set them in-process). The f32 parity mode ignores them. README.md documents them.
@@ -312,7 +313,7 @@ class ViTRunner:
         8-phase kernel from INK_MIN_ROWS rows on, and on the 64x64 ring kernel wherever gsl_gemm_nt_lora picks it (few rows: the
         launch-bound regime, where the separate skinny GEMM is a 6 - 12 us launch per adapted layer and direction). In between, the
         N = 512 GEMMs would run the 8-phase kernel on a handful of workgroups and the two-launch K-segment form wins."""
-        if dtype != torch.bfloat16 or self._rank > 16:
+        if dtype not in OP16 or self._rank > 16:
             return False
         if rows >= INK_MIN_ROWS:
             return True
@@ -378,8 +379,8 @@ class ViTRunner:
         eps = sp.ln_eps
 
         patches = ops.patchify(parts, sp.patch_size, dt)
-        xbf = dt == torch.bfloat16 and FWD_STREAM != "f32"        # the residual stream in 2 bytes per element
-        xf16 = xbf and FWD_STREAM == "f16"
+        xbf = dt in OP16 and FWD_STREAM != "f32"        # the residual stream in 2 bytes per element
+        xf16 = xbf and (FWD_STREAM == "f16" or dt == torch.float16)      # (fp16 operands: the 16-bit stream is fp16 too)
         xdt = (torch.float16 if xf16 else torch.bfloat16) if xbf else torch.float32            # dtype of the residual stream
         epi_res = (L.EPI_BIAS_RES_F16 if xf16 else L.EPI_BIAS_RES_BF16) if xbf else L.EPI_BIAS_RES_F32
         x = torch.empty(M, D, device=img.device, dtype=xdt)
@@ -395,7 +396,7 @@ class ViTRunner:
             tail = TAIL_CLS and i == len(sp.blocks) - 1 and sp.pool == "cls"
             qsplit = tail and QSPLIT and not attn_site
             inner = H * 64
-            hm = 1 if (QKV_HEAD_MAJOR and dt == torch.bfloat16) else 0
+            hm = 1 if (QKV_HEAD_MAJOR and dt in OP16) else 0
             epi_qkv = L.EPI_STORE_QKV_HM if hm else L.EPI_STORE
             uq = q_cls = None
             if qsplit:      # K and V for every token, Q for the cls rows only (rows inner .. 3*inner of the fused weight are K | V)
@@ -433,7 +434,7 @@ class ViTRunner:
             mlp = l1.weight.shape[0]
             lora_on = r > 0 and not attn_site and not l1.merged
             # bf16 stream: LayerNorm 2 also emits u1 = s * xn2 A1^T (the LoRA K segment of FFN1) instead of a skinny GEMM that re-reads xn2
-            ln_u1 = LN_LORA and lora_on and r <= 16 and D in (512, 768) and x1.dtype == torch.bfloat16 and dt == torch.bfloat16
+            ln_u1 = LN_LORA and lora_on and r <= 16 and D in (512, 768) and x1.dtype == torch.bfloat16 and dt == torch.bfloat16      # (bf16 operands + bf16 stream only)
             if ln_u1:
                 xn2, mean2, rstd2, u1_ln = ops.layernorm_fwd_lora(x1, D, Mr, D, n2.weight.detach(), n2.bias.detach(), eps,
                                                                    self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), s_lora)
@@ -444,7 +445,7 @@ class ViTRunner:
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
             u1 = u2 = None
             h = torch.empty(Mr, mlp, device=img.device, dtype=dt)
-            gp8 = GP8 and dt == torch.bfloat16 and save and mlp % 64 == 0
+            gp8 = GP8 and dt in OP16 and save and mlp % 64 == 0
             epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
             gp = torch.empty(Mr, mlp, device=img.device, dtype=torch.uint8 if gp8 else dt) if save else None
             if lora_on:
@@ -528,11 +529,14 @@ class ViTRunner:
             demb = demb.contiguous().float()
         if dlogits is not None and saved["Wn"] is None:
             raise RuntimeError("backward through logits requires a forward with labels")
+        # fp16 operands: the backward runs on loss-scaled gradients — gsl_head_bwd picks the power of two S on the device and writes
+        # {S, 1/S} here; every LoRA-gradient reduction below multiplies by 1/S on the way out (bf16 / f32: no scaling)
+        gscale = torch.empty(2, device=saved["x_last"].device, dtype=torch.float32) if dt == torch.float16 else None
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
-                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32,
-                               compact=(sp.pool == "cls"))      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
+                               stream_dtype=dt if (dt in OP16 and GRAD_STREAM_BF16) else torch.float32,
+                               compact=(sp.pool == "cls"), gscale=gscale)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -545,10 +549,10 @@ class ViTRunner:
             if Y.shape[0] < LGRAD_BATCH_MAX_ROWS and B * T < LGRAD_BATCH_MAX_ROWS and ops.lora_grad_batchable(Y, U, rr):
                 pending.append((Y, U, G, gsn, gsj, rr, True))
             else:
-                ops.lora_grad(Y, U, G, gsn, gsj, rr)
+                ops.lora_grad(Y, U, G, gsn, gsj, rr, gscale=gscale)
 
         def flush():
-            ops.lora_grad_batch(pending)
+            ops.lora_grad_batch(pending, gscale=gscale)
             pending.clear()
 
         for i in reversed(range(nl)):
@@ -581,7 +585,8 @@ class ViTRunner:
                 # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
                 ops.gemm_nt_lora_mulgrad(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                          self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, gp,
-                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx", p_drop=p_drop)
+                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx", p_drop=p_drop,
+                                         gscale=gscale)
             elif ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
                 ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                  self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, epilogue=epi_mul, aux=gp, p_drop=p_drop)
@@ -633,7 +638,7 @@ class ViTRunner:
                 wt = self.wT(f"qkv{i}", blk.qkv_w, dt)                     # [dim, 3*inner]
                 ops.gemm_nt(dkv, wt[:, inner:], dxn1)
                 rows = dxn1.view(B, T * D)[:, :D]                          # the cls rows of dxn1, T*D apart: updated in place
-                ops.gemm_nt(dq_cls, wt[:, :inner], rows, epilogue=L.EPI_BIAS_RES_BF16 if dt == torch.bfloat16 else L.EPI_BIAS_RES_F32,
+                ops.gemm_nt(dq_cls, wt[:, :inner], rows, epilogue={torch.bfloat16: L.EPI_BIAS_RES_BF16, torch.float16: L.EPI_BIAS_RES_F16}.get(dt, L.EPI_BIAS_RES_F32),
                             bias=self._zeros(D, dev), res=rows)
                 del dkv, dq_cls
             else:
@@ -671,11 +676,14 @@ class ViTRunner:
             demb = demb.contiguous().float()
         if dlogits is not None and saved["Wn"] is None:
             raise RuntimeError("backward through logits requires a forward with labels")
+        # fp16 operands: the backward runs on loss-scaled gradients — gsl_head_bwd picks the power of two S on the device and writes
+        # {S, 1/S} here; every LoRA-gradient reduction below multiplies by 1/S on the way out (bf16 / f32: no scaling)
+        gscale = torch.empty(2, device=saved["x_last"].device, dtype=torch.float32) if dt == torch.float16 else None
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
-                               stream_dtype=dt if (dt == torch.bfloat16 and GRAD_STREAM_BF16) else torch.float32,
-                               compact=(sp.pool == "cls"))      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
+                               stream_dtype=dt if (dt in OP16 and GRAD_STREAM_BF16) else torch.float32,
+                               compact=(sp.pool == "cls"), gscale=gscale)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
@@ -724,8 +732,8 @@ class ViTRunner:
             ng, inner = len(ml.enable_lora), H * 64
             gA, gB = gv[id(ml.lora_A)], gv[id(ml.lora_B)]
             for g in range(ng):
-                ops.lora_grad(st["xn"], v[:, g * r:], gA[g * r:(g + 1) * r], 1, D, r)                       # dA_g[j, c]
-                ops.lora_grad(dqkv[:, g * inner:(g + 1) * inner], st["uq"][:, g * r:], gB[g * inner:(g + 1) * inner], r, 1, r)   # dB_g[n, j]
+                ops.lora_grad(st["xn"], v[:, g * r:], gA[g * r:(g + 1) * r], 1, D, r, gscale=gscale)                       # dA_g[j, c]
+                ops.lora_grad(dqkv[:, g * inner:(g + 1) * inner], st["uq"][:, g * r:], gB[g * inner:(g + 1) * inner], r, 1, r, gscale=gscale)   # dB_g[n, j]
             if self.grad_hook is not None:
                 self.grad_hook(i)
             if i == 0:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from gslora_hip.vit_runner import BlockSpec, ModelSpec
-from .vit_face import HipModelMixin, _DTYPES
+from .vit_face import HipModelMixin, compute_dtype_of, DEFAULT_DTYPE
 
 
 class _Holder(nn.Module):
@@ -107,7 +107,7 @@ class ModifiedViT(HipModelMixin, nn.Module):
         self.class_token = vit_model.class_token
         self.encoder = vit_model.encoder
         self.heads = vit_model.heads
-        self.compute_dtype = _DTYPES[os.environ.get("GSLORA_DTYPE", "bf16").lower()]
+        self.compute_dtype = compute_dtype_of(os.environ.get("GSLORA_DTYPE", DEFAULT_DTYPE))
         self._runner = None
         self.hip_spec()      # validate the geometry once, loudly
 

@@ -19,7 +19,20 @@ import loralib as lora
 from gslora_hip.vit_runner import BlockSpec, ModelSpec, ViTRunner
 
 MIN_NUM_PATCHES = 16
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "float16": torch.float16, "half": torch.float16,
+           "fp32": torch.float32, "f32": torch.float32, "float32": torch.float32}
+
+
+def compute_dtype_of(name):
+    """'fp16' | 'bf16' | 'fp32' (and their aliases) or a torch dtype -> torch dtype; ValueError lists the allowed names."""
+    if not isinstance(name, str):
+        if name in (torch.float32, torch.bfloat16, torch.float16):
+            return name
+        raise ValueError(f"gs-lora_amd: compute dtype must be torch.float32 / bfloat16 / float16, not {name!r}")
+    try:
+        return _DTYPES[name.lower()]
+    except KeyError:
+        raise ValueError(f"gs-lora_amd: unknown compute dtype {name!r}; allowed: {sorted(_DTYPES)}") from None
 
 
 class CosFace(nn.Module):
@@ -123,6 +136,11 @@ class _ViTFaceFn(torch.autograd.Function):
         return (None, None, None) + (None,) * ctx.n
 
 
+# the speed mode a model starts in (GSLORA_DTYPE overrides): IEEE fp16 operands since round 5 — same kernels, bytes and MFMA rate as bf16,
+# 3 more significand bits on every matrix-core operand; DESIGN.md section 7 has what that buys in trajectory fidelity
+DEFAULT_DTYPE = "fp16"
+
+
 class HipModelMixin:
     """Shared by the model families that run on ViTRunner (ViT_face, ModifiedViT): compute-dtype switch, the lazily built
     runner / flat LoRA bucket, and the one-autograd-node call."""
@@ -130,8 +148,9 @@ class HipModelMixin:
     accepts_batch_tuple = True      # forward(img) also takes a tuple of image batches, processed as one batch (gslora_hip.step)
 
     def set_compute_dtype(self, name):
-        """'bf16' (speed: bf16 MFMA operands, f32 accumulate) or 'fp32' (parity: exact-f32 kernels)."""
-        self.compute_dtype = _DTYPES[name.lower()] if isinstance(name, str) else name
+        """'fp16' / 'bf16' (speed: 16-bit MFMA operands of that format, f32 accumulate; fp16 runs its backward on loss-scaled gradients)
+        or 'fp32' (parity: exact-f32 kernels)."""
+        self.compute_dtype = compute_dtype_of(name)
         return self
 
     def runner(self):
@@ -195,7 +214,7 @@ class ViT_face(HipModelMixin, nn.Module):
         self.lora_pos = lora_pos
         self.attn_scale = dim ** -0.5
         self.dropout_p, self.emb_dropout_p = float(dropout), float(emb_dropout)
-        self.compute_dtype = _DTYPES[os.environ.get("GSLORA_DTYPE", "bf16").lower()]
+        self.compute_dtype = compute_dtype_of(os.environ.get("GSLORA_DTYPE", DEFAULT_DTYPE))
         self._runner = None
 
     # ---- helpers for the runner -------------------------------------------------------------

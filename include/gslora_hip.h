@@ -7,8 +7,9 @@
  *  - every call is asynchronous on the given hipStream_t (passed as void*; NULL = default stream).
  *  - return 0 on success, negative gsl_status on error; message via gsl_last_error()
  *    (thread-local). Never aborts.
- *  - dtype selects the operand/activation element type: GSL_F32 (parity mode, exact-f32 kernels)
- *    or GSL_BF16 (speed mode: bf16 operands, f32 accumulate on MFMA). LayerNorm statistics, biases,
+ *  - dtype selects the operand/activation element type: GSL_F32 (parity mode, exact-f32 kernels),
+ *    GSL_BF16 or GSL_F16 (speed mode: 16-bit operands, f32 accumulate on MFMA; "bf16" in the comments below means either 16-bit
+ *    format unless a comment says otherwise). LayerNorm statistics, biases,
  *    LoRA master weights, losses and optimizer state are always f32; the residual stream and its
  *    gradient are f32 or — in speed mode, per call (x_dtype / stream_dtype) — bf16.
  *
@@ -30,7 +31,11 @@ extern "C" {
 
 typedef void* gsl_stream_t;
 
-enum gsl_dtype { GSL_F32 = 0, GSL_BF16 = 1, GSL_F16 = 2 /* x_dtype ONLY: the forward residual stream of the bf16 speed mode as IEEE fp16 (round 4) */ };
+/* GSL_F16 (round 5): the speed mode with IEEE fp16 operands — the same kernels, bytes and MFMA rate as GSL_BF16 (v_mfma_f32_16x16x32_f16),
+ * an 11-bit significand instead of 8. Activations saturate at +-65504 on store (NaN / Inf stay visible); the backward runs on gradients
+ * multiplied by a power-of-two loss scale chosen on the device by gsl_head_bwd (gscale = {S, 1/S}) which the LoRA-gradient reductions
+ * divide out again, exactly. As an x_dtype it is also the forward residual stream format of the GSL_BF16 mode (round 4). */
+enum gsl_dtype { GSL_F32 = 0, GSL_BF16 = 1, GSL_F16 = 2 };
 
 enum gsl_status {
   GSL_OK = 0,
@@ -106,14 +111,16 @@ GSL_API int gsl_gemm_nt_lora(const void* A, int lda, const void* W, int ldw, int
  * U1 [M, ldu1 >= 16] bf16 (columns r..15 zero or discarded), Y2 / aux / out [M,N] bf16 with row stride ldo, N % 8 == 0.
  * ws f32 >= gsl_gemm_mulgrad_ws_elems(M, N, r). Reductions are fixed-order (bit-reproducible).
  * aux_u8 != 0: aux is the 8-bit GELU' code tensor of GSL_EPI_BIAS_GELU_G8 (slab-major [N/64][M][64], N % 64 == 0) and p_drop the
- * dropout rate of that forward. */
+ * dropout rate of that forward. dtype: GSL_BF16 or GSL_F16 (the operand format of every 16-bit tensor of the call).
+ * gscale (nullable): device pointer to {S, 1/S} written by gsl_head_bwd — the reductions are multiplied by 1/S on the way out (the
+ * operands carry loss-scaled gradients; a power of two, so the un-scaling is exact). */
 GSL_API long gsl_gemm_mulgrad_ws_elems(int M, int N, int r);
 GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int ldw, int K,
                              const void* P, int ldp, const void* Q, int ldq, float lora_scale, void* tout, int ldt,
                              int M, int N, const void* aux, void* out, int ldo,
                              const void* U1, int ldu1, float* G1, long g1sn, long g1sj,
                              const void* Y2, float* G2, long g2sn, long g2sj,
-                             int r, int accumulate, float* ws, int aux_u8, float p_drop, gsl_stream_t s);
+                             int r, int accumulate, float* ws, int aux_u8, float p_drop, int dtype, const float* gscale, gsl_stream_t s);
 
 /* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x — the residual stream — is `x_dtype` (f32; bf16 when the bf16
  * speed mode carries the forward stream in bf16), rows of length D at stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M].
@@ -164,18 +171,19 @@ GSL_API int gsl_attention_bwd_cls(const void* qkv, const void* q_cls, const void
 /* ---- K9 LoRA gradient (skinny, reduction over M rows): G[n*gsn + j*gsj] (+)= sum_m Y[m,n] * U[m,j]
  * Y[dtype] [M,N] with row stride ldy >= N elements (a column block of a wider tensor is allowed), U[dtype] [M,ldu] (first r columns
  * used, r <= 16; columns r..15 must be readable zeros or belong to other adapters whose products are discarded).
- * ws f32 >= gsl_lora_grad_ws_elems(). */
+ * ws f32 >= gsl_lora_grad_ws_elems(). gscale (nullable): device {S, 1/S} of a loss-scaled backward (see gsl_head_bwd): the sums are
+ * multiplied by 1/S before they are stored / accumulated. */
 GSL_API long gsl_lora_grad_ws_elems(int M, int N, int r);
 GSL_API int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, float* G, long gsn, long gsj,
-                  int M, int N, int r, int dtype, int accumulate, float* ws, gsl_stream_t s);
-/* The same for n reductions in two launches per 24 descriptors (the launch-bound regime: a few-shot step runs 24 of them). bf16 operands
- * only, N % 256 == 0, 16-byte aligned rows; any M >= 1. `descs` is a HOST array — the launches carry the descriptors by value, so a captured
+                  int M, int N, int r, int dtype, int accumulate, float* ws, const float* gscale, gsl_stream_t s);
+/* The same for n reductions in two launches per 24 descriptors (the launch-bound regime: a few-shot step runs 24 of them). 16-bit operands
+ * only (dtype GSL_BF16 or GSL_F16, one format per call; gscale as above), N % 256 == 0, 16-byte aligned rows; any M >= 1. `descs` is a HOST array — the launches carry the descriptors by value, so a captured
  * HIP graph keeps them. The G of one call must not overlap. ws: gsl_lora_grad_batch_ws_elems(descs, n) floats (-1: invalid descriptor). */
 typedef struct gsl_lgrad_desc {
   const void* Y; long ldy; const void* U; int ldu; int M; int N; int r; int accumulate; int pad_; float* G; long gsn, gsj;
 } gsl_lgrad_desc;
 GSL_API long gsl_lora_grad_batch_ws_elems(const gsl_lgrad_desc* descs, int n);
-GSL_API int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, gsl_stream_t s);
+GSL_API int gsl_lora_grad_batch(const gsl_lgrad_desc* descs, int n, float* ws, int dtype, const float* gscale, gsl_stream_t s);
 
 
 /* ---- K10 head: cls pool + LayerNorm + CosFace (vit_face.py:540-546, 171-208; s=64, m=0.35).
@@ -191,11 +199,16 @@ GSL_API int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamma, 
  * dlogits [B,C] / demb [B,D] nullable. dx [B*T,D]: with pool='cls' the cls rows get the gradient and the others are zeroed,
  * with pool='mean' every token row gets d pooled / T. dxb[dtype] = dx * dropmask(site) (nullable). dx is `stream_dtype` (see
  * gsl_layernorm_bwd). compact != 0 (pool='cls' only): dx / dxb are [B,D], the cls rows alone — nothing is zero-filled; the dropout
- * counters stay those of the dense tensor. */
+ * counters stay those of the dense tensor.
+ * gscale != NULL (fp16 operands): LOSS-SCALED backward. The kernel runs twice: pass 1 writes max|d loss / d stream| of every image to
+ * amax_ws [B], pass 2 picks the power of two S with S * max in [2^10, 2^11), stores dx / dxb multiplied by S and publishes
+ * gscale[0..1] = {S, 1/S} on the device (no host sync; HIP-graph safe). Every kernel downstream is linear in the gradient; the
+ * LoRA-gradient reductions take gscale and divide S out. */
 GSL_API int gsl_head_bwd(const float* dlogits, const float* demb, const void* x, int x_dtype, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
                  void* dx, void* dxb, int B, int D, int C, float cos_s, int dtype, int stream_dtype,
-                 float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, int compact, gsl_stream_t s);
+                 float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, int compact,
+                 float* gscale, float* amax_ws, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
  * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */

@@ -57,7 +57,7 @@ def test_constructor_contract():
         ViT_face_low()
     m = make_model(cfg)
     assert m.attn_scale == cfg["dim"] ** -0.5         # reference quirk: dim, not dim_head
-    assert m.num_tokens == 26 and m.compute_dtype in (torch.bfloat16, torch.float32)
+    assert m.num_tokens == 26 and m.compute_dtype in (torch.float16, torch.bfloat16, torch.float32)
 
 
 def test_lora_merge_state_machine_and_init():

@@ -49,7 +49,11 @@ def run(mode, attrs):
 
 
 ref = run("fp32", {})
-CONFIGS = [("bf16 (default: fp16 forward stream, bf16 gradient stream, 8-bit GELU')", {}),
+CONFIGS = [("fp16 operands (round 5 default: fp16 streams, loss-scaled backward, 8-bit GELU')", {"_mode": "fp16"}),
+           ("fp16 operands, fp16 GELU' instead of the 8-bit code", {"_mode": "fp16", "GP8": False}),
+           ("fp16 operands, f32 forward + gradient streams", {"_mode": "fp16", "FWD_STREAM": "f32", "GRAD_STREAM_BF16": False}),
+           ("fp16 operands, all wide (f32 streams, fp16 GELU')", {"_mode": "fp16", "FWD_STREAM": "f32", "GRAD_STREAM_BF16": False, "GP8": False}),
+           ("bf16 operands (round 4 default: fp16 forward stream, bf16 gradient stream, 8-bit GELU')", {}),
            ("bf16 forward residual stream (round 3)", {"FWD_STREAM": "bf16"}),
            ("f32 forward residual stream", {"FWD_STREAM": "f32"}),
            ("f32 gradient residual stream", {"GRAD_STREAM_BF16": False}),
@@ -60,7 +64,8 @@ print(f"FULL ViT-P8S8, batch {B}+{B}, against the f32 parity mode of the same pa
 print("| configuration | logits max abs (scale 64) | emb max abs | loss | LoRA grad rel. Frobenius | cosine | worst tensor rel. | dA1 / dB1 / dA2 / dB2 rel. |")
 print("|---|---|---|---|---|---|---|---|")
 for name, attrs in CONFIGS:
-    lo, em, g, tot = run("bf16", attrs)
+    attrs = dict(attrs)
+    lo, em, g, tot = run(attrs.pop("_mode", "bf16"), attrs)
     g32 = torch.cat([ref[2][k] for k in g])
     g16 = torch.cat([g[k] for k in g])
     worst = max(float((g[k] - ref[2][k]).norm() / ref[2][k].norm()) for k in g if ref[2][k].norm() > 0)
