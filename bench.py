@@ -10,7 +10,7 @@ the run fails.
 
 Workload (config.workload): BASELINE.json configs[1] — ViT-P8S8 depth 6, 112 px, LoRA r=8 on both FFN linears, CosFace-100 head,
 per-GPU batch 512 remain + 512 forget images resident in HBM (weak scaling; `--scaling strong` keeps the GLOBAL batch at 512 + 512),
-bf16 speed mode, dropout 0.1 / emb-dropout 0.1 (the reference's training setting), prototype term on, FusedAdamW (lr 1e-2, wd 0.05).
+16-bit speed mode (--dtype fp16, the default: IEEE fp16 MFMA operands; bf16: the same kernels on bf16 operands), dropout 0.1 / emb-dropout 0.1 (the reference's training setting), prototype term on, FusedAdamW (lr 1e-2, wd 0.05).
 One "step" = the engine_cl.train_one_epoch loop body (2 forwards, 5 loss terms, backward, packed scalar all-reduce + gradient
 all-reduce when N > 1, AdamW). Prints ONE JSON line on rank 0.
 
@@ -234,7 +234,7 @@ class GsLoraWorkload:
         """engine_cl.eval_data (reference engine_cl.py:318-346) on a synthetic test loader shaped like the reference's: batches of
         5 x batch images (train/train_own_forget_cl.py:737-750), device resident, labels passed (margin logits). Timed OUTSIDE the step
         metric's region, in both evaluation dtypes: "fp32" = the engines' default (the reference's arithmetic, whatever mode the model
-        trains in), "bf16" = GSLORA_EVAL_DTYPE=model. One untimed batch first (operand caches of the evaluation dtype, eval-mode merge)."""
+        trains in), "fp16" / "bf16" = the two 16-bit operand formats (GSLORA_EVAL_DTYPE=fp16 | bf16 | model). One untimed batch first (operand caches of the evaluation dtype, eval-mode merge)."""
         import engine_cl
         dev = self.x_r.device
         g = torch.Generator(device="cpu").manual_seed(4242)
@@ -245,7 +245,7 @@ class GsLoraWorkload:
         import contextlib
         import io
         try:
-            for name, ev in (("fp32", "fp32"), ("bf16", "bf16")):
+            for name, ev in (("fp32", "fp32"), ("fp16", "fp16"), ("bf16", "bf16")):
                 engine_cl.EVAL_DTYPE = ev
                 with contextlib.redirect_stdout(io.StringIO()):
                     engine_cl.eval_data(self.model, [batch], dev, "warm-up", 0)
@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration: 2 (default, the metric's), 4 ViT-B/16 r=16 b48, 5 few-shot b4")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU images per forward (remain and forget each; default: the config's); with --scaling strong: the GLOBAL batch")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="fp16", help="fp16 (default since round 5: IEEE fp16 MFMA operands, loss-scaled backward) | bf16 | fp32 (parity mode)")
     ap.add_argument("--dropout", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", default=None, help="replay the step as captured HIP graph segments (the engines' default for launch-bound batches; default: the config's)")
@@ -434,7 +434,11 @@ def main():
         out = {
             "metric": metric, "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+            "dtype_note": {"fp16": "IEEE fp16 MFMA operands (v_mfma_f32_16x16x32_f16: the rate and bytes of bf16, 11-bit significand), f32 accumulate, "
+                                   "backward on loss-scaled gradients; --dtype bf16 runs the same kernels on bf16 operands",
+                           "bf16": "bf16 MFMA operands, f32 accumulate", "fp32": "exact-f32 parity kernels"}.get(args.dtype, args.dtype),
+            "data": "synthetic",
             "config": {"workload": ("STUB (CPU plumbing test, not a measurement)" if stub else
                                     f"{C['name']}, per-GPU batch {B} remain + {B} forget ({img} synthetic), dropout {args.dropout}, prototype "
                                     f"term on (BND_pro {C['BND_pro']}, w_f {C['pro_f']}), FusedAdamW" + (", HIP-graph replay" if args.graph else "")),

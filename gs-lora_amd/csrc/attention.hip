@@ -71,11 +71,6 @@ __device__ __forceinline__ void stage_rowmajor(bf16_t* dst, const bf16_t* src, l
 // a fused-backward workgroup lives — profiles/r04_notes.md). NT = threads of the workgroup.
 template <int TP, int NT>
 __device__ __forceinline__ void stage_rowmajor2(bf16_t* d0, const bf16_t* s0, bf16_t* d1, const bf16_t* s1, long ld, int T) {
-#ifdef GSL_ATTN_ROLLED
-  stage_rowmajor<TP>(d0, s0, ld, T);
-  stage_rowmajor<TP>(d1, s1, ld, T);
-  return;
-#endif
   constexpr int NIT = (TP * 8 + NT - 1) / NT;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t v0[NIT], v1[NIT];
@@ -100,11 +95,6 @@ __device__ __forceinline__ void stage_rowmajor2(bf16_t* d0, const bf16_t* s0, bf
 // 256 threads the 1024-thread forward of the few-shot regime carried 14 dead vector registers sets and SPILLED: 0.84 -> 1.00 ms per step.)
 template <int TP, int MINT>
 __device__ __forceinline__ void stage_rowmajor2_rt(bf16_t* d0, const bf16_t* s0, long ld0, bf16_t* d1, const bf16_t* s1, long ld1, int T) {
-#ifdef GSL_ATTN_ROLLED      // A/B builds only: the rolled load / wait / store loops of rounds 1 - 3
-  stage_rowmajor<TP>(d0, s0, ld0, T);
-  stage_rowmajor<TP>(d1, s1, ld1, T);
-  return;
-#endif
   constexpr int NIT = (TP * 8 + MINT - 1) / MINT;      // MINT = the smallest workgroup the kernel is launched with
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t v0[NIT], v1[NIT];
@@ -177,6 +167,7 @@ __device__ __forceinline__ int item_remap(int seq, int H, int on) {
 template <int NKT, int NT = 512>
 __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int T, int H, float scale, int abl, int hm) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
@@ -272,6 +263,7 @@ __device__ __forceinline__ void wg_barrier_lds() {
 template <int NKT, bool FAST>
 __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                                   float* __restrict__ lse, int T, int H, float scale, int nitems, int hm, int imap) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int TP = NKT * 16;
   constexpr int NCW = 13;                 // compute waves = query tiles (host: T <= 208)
   constexpr int NST = 9;                  // loader steps per panel: 24 rows x 8 chunks per step, 9 * 24 = 216 >= 208 rows
@@ -407,6 +399,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int T,
                                                                int H, float scale, int abl, int hm) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
@@ -492,6 +485,7 @@ template <int NKT, int NT>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, int T, int H, float scale, int abl, int hm) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int TP = NKT * 16;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Os[TP * KLD];   // dO row-major
@@ -611,6 +605,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
                                                                      const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                      bf16_t* __restrict__ dqkv, int T, int H, float scale,
                                                                      unsigned long long* __restrict__ stamps, int hm, int imap) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int TP = NKT * 16;
   // development (GSL_ATTN_STAMPS = device address of 256 x 8 u64): cycle stamps of every 64th workgroup
   unsigned long long* dbg = (stamps && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0) ? stamps + (blockIdx.x / 64) * 8 : nullptr;   // uniform
@@ -854,6 +849,7 @@ constexpr int FLD = 68;
 template <int TP>
 __global__ __launch_bounds__(512, 2) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                 float* __restrict__ lse, int T, int H, float scale) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int NKT = TP / 16;
   __shared__ __attribute__((aligned(16))) float Ks[TP * FLD];
   __shared__ __attribute__((aligned(16))) float Vs[TP * FLD];
@@ -976,6 +972,7 @@ template <int TP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                      float* __restrict__ dqkv, float* __restrict__ delta, int T, int H, float scale) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int NKT = TP / 16;
   __shared__ __attribute__((aligned(16))) float Ks[TP * FLD];
   __shared__ __attribute__((aligned(16))) float Vs[TP * FLD];
@@ -1043,6 +1040,7 @@ template <int TP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                                       float* __restrict__ dqkv, int T, int H, float scale) {
+  GSL_OP16_KERNEL_ENTRY();
   constexpr int NQT = TP / 16;
   __shared__ __attribute__((aligned(16))) float Qs[TP * FLD];
   __shared__ __attribute__((aligned(16))) float Gs[TP * FLD];   // dO
@@ -1136,6 +1134,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
                                                            const T* __restrict__ d_o_cls, const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, T* __restrict__ dq_cls, int Tn, int H, float scale, int hm,
                                                            int cls_compact) {
+  GSL_OP16_KERNEL_ENTRY();
   __shared__ float q0[HD], g0[HD], red[32][HD];
   __shared__ float sD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -1207,6 +1206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ q_cls, T* __restrict__ o_cls,
                                                            float* __restrict__ lse_cls, int Tn, int H, float scale, int hm) {
+  GSL_OP16_KERNEL_ENTRY();
   __shared__ float q0[HD], sc[256], red[32][HD];
   __shared__ float sm[16];
   const int b = blockIdx.x / H, h = blockIdx.x % H;

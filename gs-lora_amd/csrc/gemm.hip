@@ -71,11 +71,7 @@ template <int EPI> constexpr bool epi_is_gelu() { return EPI == GSL_EPI_BIAS_GEL
 // row and consecutive rows follow each other, so the 16-row store instruction of the FFN1 epilogue writes 1 KB and the 8-row load
 // instruction of the FFN2-dX epilogue reads 512 B of consecutive memory (row-major [M, N] made them 64-byte pieces 2 KB apart: +8 % write
 // traffic by the PMC counters). The tensor is private to this pair of epilogues (never a GEMM operand); N % 64 == 0.
-#ifdef GSL_G8_ROWMAJOR      // A/B builds only (python -m gslora_hip.build --variant g8rm -DGSL_G8_ROWMAJOR): row-major [M, N] codes
-__device__ __forceinline__ size_t g8_off(int M, int m, int n) { return (size_t)m * 2048 + (size_t)n; }
-#else
 __device__ __forceinline__ size_t g8_off(int M, int m, int n) { return ((size_t)(n >> 6) * (size_t)M + (size_t)m) * 64 + (size_t)(n & 63); }
-#endif
 // kq = 200 * (1 - p): g (already scaled by keep / (1 - p)) -> code
 __device__ __forceinline__ uint32_t g8_pack4(const float g[4], float kq) {
   uint32_t w = 0u;
@@ -478,11 +474,8 @@ constexpr int GF_BLOCK_B = 8 * GF_WAVE_B + GF_T16_B;            // 159744 of the
 typedef short gf_v4s_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) gf_v4s_t* gf_lds_v4s_p;
 union GfFrag { gf_v4s_t h[2]; bf16x8_t v; };
-#ifndef GSL_GF_NT
-#define GSL_GF_NT 1
-#endif
-template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {
-  if constexpr (GSL_GF_NT) {
+template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {      // read-once epilogue operand: non-temporal load
+  {
     if constexpr (sizeof(V) == 16) {
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
       const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -492,8 +485,6 @@ template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {
       const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
       return make_uint2(t[0], t[1]);
     }
-  } else {
-    return *reinterpret_cast<const V*>(p);
   }
 }
 // global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
@@ -506,7 +497,7 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
-    // g' and h are read exactly once by exactly one workgroup: non-temporal loads (GSL_GF_NT), so that these 1.2 GB per launch do not
+    // g' and h are read exactly once by exactly one workgroup: non-temporal loads, so that these 1.2 GB per launch do not
     // push the dY row panel — which the 8 N-tiles of a row panel share through the XCD's L2 — out between sibling tiles
     // (calibrated FETCH_SIZE: 2.0 GB fetched per launch against 1.45 GB of operands, profiles/r04_pmc_calibration.md)
     if constexpr (G8) {      // 8-bit GELU' codes: 8 bytes per lane and row (only .x / .y of the slot are live)
@@ -541,21 +532,15 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   // round q + 2's as soon as round q has consumed its set (after its multiply / LDS hand-over). A round's operands are therefore in
   // flight for more than a whole round (~1.5) instead of half of one, which covers the round trip that grows from ~2.5 k to ~5 k
   // cycles when all CUs stream. The second set costs no registers at the kernel level: the K loop's operand fragments (72 VGPRs) are
-  // dead here and every round frees 32 accumulator registers. GSL_MULGRAD_PREFETCH=1 builds the single-set form (A/B probes).
-#ifndef GSL_MULGRAD_PREFETCH
-#define GSL_MULGRAD_PREFETCH 2
-#endif
-  constexpr bool TWOSETS = (GSL_MULGRAD_PREFETCH >= 2);
+  // dead here and every round frees 32 accumulator registers.
   GfOperands gob;
-  if constexpr (TWOSETS) {
-    asm volatile("" ::: "memory");
-    if (NI / 2 > 1) gf_request<G8>(e, gob, mw, nw, 1, lane);
-    asm volatile("" ::: "memory");
-  }
+  asm volatile("" ::: "memory");
+  if (NI / 2 > 1) gf_request<G8>(e, gob, mw, nw, 1, lane);
+  asm volatile("" ::: "memory");
   const float sq8 = e.drop.scale / G8_K;
 #pragma unroll
   for (int ic = 0; ic < NI / 2; ++ic) {
-    GfOperands& op = (TWOSETS && (ic & 1)) ? gob : go;      // (the loop is fully unrolled: a compile-time choice)
+    GfOperands& op = (ic & 1) ? gob : go;      // (the loop is fully unrolled: a compile-time choice)
     uint4 (&ax)[4] = op.ax;
     uint4 (&hx)[4] = op.hx;
     uint4 &u1a = op.u1a, &u1b = op.u1b;
@@ -605,8 +590,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
     }
     asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
     // this round's set is consumed: refill it for the round that uses it next
-    if constexpr (TWOSETS) { if (ic + 2 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 2, lane); }
-    else { if (ic + 1 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 1, lane); }
+    if (ic + 2 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 2, lane);
     asm volatile("" ::: "memory");
     GfFrag b1, b2;
     b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
@@ -822,6 +806,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                              const bf16_t* __restrict__ A2, int lda2,
                                                              const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[NBUF][2][BM * BK];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -917,15 +902,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 #ifndef GSL_SMALL_NSTS
 #define GSL_SMALL_NSTS 3      // stages of the 64x64 ring kernel: 3 x 16 KB = three workgroups per CU (4: two; measured, r03_notes.md)
 #endif
-#ifndef GSL_TUPD
-#define GSL_TUPD 0      // 1: fused FFN1 applies its LoRA K segment as a rank-32 update behind the K loop instead of a ninth K tile (measured slower)
-#endif
-#ifndef GSL_P8_AUX_A
-#define GSL_P8_AUX_A 0
-#endif
-#ifndef GSL_P8_AUX_W
-#define GSL_P8_AUX_W 0
-#endif
 struct LoraInk {
   const bf16_t* P; int ldp;
   const bf16_t* Q; int ldq;
@@ -959,6 +935,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
                                                               const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   constexpr int BNT = 32 * NJ;                                   // tile columns
   constexpr int STS = (BMS + BNT + (LORA ? 16 : 0)) * BK;
@@ -1153,6 +1130,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                               const bf16_t* __restrict__ A2, int lda2,
                                                               const bf16_t* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[3 * ST3];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1279,6 +1257,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W1, int ldw1, int K1,
                                                            const bf16_t* __restrict__ A2, int lda2,
                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, LoraInk lk, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   constexpr int STG = LORA ? ST4L : ST4;
   static_assert(!GRAD || (LORA && epi_is_mul<EPI>()), "GRAD is the gradient-fused form of the in-kernel-LoRA MUL GEMM");
@@ -1326,9 +1305,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
-      // cache policy of the two operand streams (aux: 1 = sc0, 2 = nt, 16 = sc1): measured, profiles/r03_notes.md
-      if constexpr (isA) __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, GSL_P8_AUX_A);
-      else __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, GSL_P8_AUX_W);
+      // (cache-policy bits on the two operand streams — sc0 / nt / sc1 — were measured neutral to negative: profiles/r03_notes.md)
+      if constexpr (isA) __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)g * ld + k0 + csw[i]), (lptr_t)(dst + (wave * 2 + i) * 8 * BK), 16, 0, 0);
     }
     if constexpr (LORA && PIECE == 0) {
       if (wave < 2) {
@@ -1376,14 +1355,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
   stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
-  // GSL_P8_DMA_BATCH (A/B, profiles/r04_g_hybrid_stream.md): 0 = one 16 KB half-tile request per phase (2 DMA instructions per wave); 2 = two
-  // half-tiles in q1 and q3; 1 = the whole K tile kt+2 in q3. The stream ALONE runs faster when a K tile is requested as one batch.
-#ifndef GSL_P8_DMA_BATCH
-#define GSL_P8_DMA_BATCH 0
-#endif
-  constexpr int DBATCH = GSL_P8_DMA_BATCH;
-  if constexpr (DBATCH != 0) stage(1, P3{});
-  constexpr int YOUNG = DBATCH ? 8 : 6;          // DMA instructions of a wave younger than K tile kt+1's last piece at the counted wait
+  // (one 16 KB half-tile request per phase, 2 DMA instructions per wave; batching a K tile's requests is neutral in this loop although the
+  //  stream ALONE runs faster that way: profiles/r04_g_hybrid_stream.md)
+  constexpr int YOUNG = 6;          // DMA instructions of a wave younger than K tile kt+1's last piece at the counted wait
   if constexpr (TAB) {      // the GELU table: 16 pieces of 1 KB, two per wave, BEHIND the prologue's requests (K tile 0 is not delayed by it); the
 #pragma unroll             // counted wait below leaves them in flight, the K loop's first counted wait (step 0, q3) retires them in order
     for (int i = 0; i < 2; ++i) {
@@ -1405,22 +1379,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   const int poff0 = fr * BK + (((0 * 4 + fc) ^ (fr & 7)) << 3), poff1 = fr * BK + (((1 * 4 + fc) ^ (fr & 7)) << 3);
   const int pi = (wn & 1) * 2;      // this wave's two row fragments (within its row half wn >> 1) of the 16 extra columns
   // In-kernel LoRA: the 16 extra output columns t = A P^T need 16 MFMAs per wave row and K tile (8 row fragments x 2 k-steps), shared by
-  // the row's 4 waves. GSL_LORA_SPREAD=1 (measured slower, off): wave wn owns row fragment wn of EACH row half and issues ONE extra MFMA in every phase
-  // (q0 / q1 on the row-half-0 fragment still in registers, q2 / q3 on the row-half-1 fragment): 17 MFMAs per wave and phase. The
-  // default form gives a wave 4 extra MFMAs in ONE phase (20 + 16 + 20 + 16 on the barrier-paced path).
-#ifndef GSL_LORA_SPREAD
-#define GSL_LORA_SPREAD 0
-#endif
-#if GSL_LORA_SPREAD
-#define GSL_P8_PEXTRA(PH)                                                                                   \
-  if constexpr (LORA) {                                                                                     \
-    constexpr int ks_ = (PH) & 1, t_ = (PH) >> 1;                                                           \
-    if (wn == 0) accp[t_] = GSL_MFMA16(pf[ks_], af[0][ks_], accp[t_], 0, 0, 0);      \
-    else if (wn == 1) accp[t_] = GSL_MFMA16(pf[ks_], af[1][ks_], accp[t_], 0, 0, 0); \
-    else if (wn == 2) accp[t_] = GSL_MFMA16(pf[ks_], af[2][ks_], accp[t_], 0, 0, 0); \
-    else accp[t_] = GSL_MFMA16(pf[ks_], af[3][ks_], accp[t_], 0, 0, 0);               \
-  }
-#else
+  // the row's 4 waves: a wave issues its 4 extra MFMAs in ONE phase (20 + 16 + 20 + 16 on the barrier-paced path). One extra MFMA in every
+  // phase instead was measured slower (profiles/r03_notes.md; the wave-uniform branch ladder costs more than the uneven phases).
 #define GSL_P8_PEXTRA(PH)                                                                                   \
   if constexpr (LORA && ((PH) == 0 || (PH) == 2)) {                                                         \
     if ((wn >> 1) == ((PH) >> 1)) {                                                                         \
@@ -1437,13 +1397,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       }                                                                                                     \
     }                                                                                                       \
   }
-#endif
   // row fragment (of the wave row's 8) that accp[t] holds
-#if GSL_LORA_SPREAD
-#define GSL_P8_TFRAG(t) ((t) * 4 + wn)
-#else
 #define GSL_P8_TFRAG(t) (2 * wn + (t))
-#endif
 #define GSL_P8_MFMA(RH, CH, BF, PH)                                                                          \
   __builtin_amdgcn_s_barrier();                                                                             \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
@@ -1478,72 +1433,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
   };
 #endif
-#ifndef GSL_P8_PHASES
-#define GSL_P8_PHASES 8
-#endif
-#if GSL_P8_PHASES == 4
-  // A/B (profiles/r04_notes.md): TWO phases of 32 MFMAs per K tile instead of four of 16 — half the barriers. pA: row half 0 against both column
-  // halves (reads B-h0, B-h1, A-h0: 16 ds_read_b128), pB: row half 1 (reads A-h1: 8). Requests: A-h1(kt+1) in pA, the other three half-tiles of
-  // kt+2 in pB; two counted waits per K tile (pA retires A-h1(kt), pB the three half-tiles pA(kt+1) reads), each a whole K tile behind its requests.
-#define GSL_P8_MFMA2(RH, CHA, BFA, CHB, BFB, PH)                                                             \
-  __builtin_amdgcn_s_barrier();                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-  __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                            \
-  GSL_P8_PEXTRA(PH)                                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-        acc[(RH) * 4 + i][(CHA) * 2 + j] = GSL_MFMA16(BFA[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHA) * 2 + j], 0, 0, 0); \
-        acc[(RH) * 4 + i][(CHB) * 2 + j] = GSL_MFMA16(BFB[j][ks], af[i][ks], acc[(RH) * 4 + i][(CHB) * 2 + j], 0, 0, 0); \
-      }                                                                                                     \
-  __builtin_amdgcn_s_setprio(0);                                                                            \
-  __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_barrier();                                                                             \
-  __builtin_amdgcn_sched_barrier(0);
-#define GSL_P8_WAIT4()                                                                                      \
-  if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-  else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                               \
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  for (int kt = 0; kt < nk; ++kt) {
-    const bf16_t* As0 = smem + (kt & 1) * STG;
-    const bf16_t* As1 = As0 + HT;
-    const bf16_t* Bs0 = As0 + BM4 * BK;
-    const bf16_t* Bs1 = Bs0 + HT;
-    // ---- pA: row half 0 x both column halves
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf0[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs0 + boff[j][ks]);
-    if constexpr (LORA) {
-      pf[0] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff0);
-      pf[1] = *reinterpret_cast<const bf16x8_t*>(Bs0 + 2 * HT + poff1);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 1, P3{});
-    GSL_P8_WAIT4()
-    GSL_P8_MFMA2(0, 0, bf0, 1, bf1, 0)
-    // ---- pB: row half 1 x both column halves
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(kt + 2, P0{}); stage(kt + 2, P1{}); stage(kt + 2, P2{});
-    GSL_P8_WAIT4()
-    GSL_P8_MFMA2(1, 1, bf1, 0, bf0, 2)
-  }
-#undef GSL_P8_MFMA2
-#undef GSL_P8_WAIT4
-#else
+  // (a 4-phase cut of this loop — two phases of 32 MFMAs per K tile, half the barriers — is bit-identical and 0.7 % slower per step:
+  //  profiles/r04_notes.md; commit 52d4782 has the code)
   for (int kt = 0; kt < nk; ++kt) {
     const bf16_t* As0 = smem + (kt & 1) * STG;
     const bf16_t* As1 = As0 + HT;
@@ -1564,7 +1455,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DBATCH == 0) stage(kt + 1, P3{});
+    stage(kt + 1, P3{});
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     GSL_P8_MFMA(0, 0, bf0, 0)
     // ---- q1: (rh0, ch1); reads B-h1; stages B-h0(kt+2)
@@ -1573,8 +1464,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DBATCH != 1) stage(kt + 2, P0{});
-    if constexpr (DBATCH == 2) stage(kt + 2, P1{});
+    stage(kt + 2, P0{});
     GSL_P8_MFMA(0, 1, bf1, 1)
     // ---- q2: (rh1, ch1); reads A-h1; stages A-h0(kt+2)
 #pragma unroll
@@ -1582,12 +1472,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DBATCH == 0) stage(kt + 2, P1{});
+    stage(kt + 2, P1{});
     GSL_P8_MFMA(1, 1, bf1, 2)
     // ---- q3: (rh1, ch0); no reads; stages B-h1(kt+2); the once-per-K-tile counted wait: K tile kt+1 has landed
-    if constexpr (DBATCH == 1) { stage(kt + 2, P0{}); stage(kt + 2, P1{}); }
     stage(kt + 2, P2{});
-    if constexpr (DBATCH != 0) stage(kt + 2, P3{});
     if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
@@ -1596,7 +1484,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #endif
     GSL_P8_MFMA(1, 0, bf0, 3)
   }
-#endif
 #undef GSL_P8_MFMA
 #undef GSL_P8_PEXTRA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
@@ -1685,35 +1572,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
   }
-  if constexpr (!LORA && epi_is_gelu<EPI>()) {
-    // The LoRA term of the fused FFN1 with t GIVEN (u = s * xn A^T from the skinny GEMM in front, lk.tout [M, >= 32], lk.Q = B [N, >= 32]):
-    // one rank-32 k-step from LDS behind the K loop instead of a ninth K tile of 64 (a whole stage of LDS-DMA and 64 MFMAs per wave for
-    // 8 - 16 live columns). Same products in the same order as the K-segment form (its second k-step multiplies zeros): bit-identical.
-    if (lk.Q) {
-      __builtin_amdgcn_s_barrier();                    // stages are free
-      bf16_t* tbuf = smem;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {                    // 256 rows x 32 columns = 1024 16-byte pieces
-        const int piece = tid * 2 + q, row = piece >> 2, c = piece & 3;
-        const int gm = min(m0 + row, e.M - 1);
-        *reinterpret_cast<uint4*>(tbuf + row * 32 + c * 8) = *reinterpret_cast<const uint4*>(lk.tout + (size_t)gm * lk.ldt + c * 8);
-      }
-      bf16x8_t qf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
-        qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(tbuf + (wm * 128 + i * 16 + fr) * 32 + fc * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
-      }
-    }
-  }
   if constexpr (EPI == GSL_EPI_BIAS_RES_F32 || EPI == GSL_EPI_PATCH) {
     if ((e.N % 4) == 0 && (e.ldo % 4) == 0 && e.N >= 4 && (EPI != GSL_EPI_PATCH || e.ldo == e.N)) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
@@ -1755,182 +1613,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
 }
 
-// The persistent form of the 8-phase kernel below is a MEASURED ALTERNATIVE, compiled only with -DGSL_P8_PERSISTENT=1 (python -m gslora_hip.build
-// --variant p8p -DGSL_P8_PERSISTENT=1): bit-identical to the per-tile kernel, and no faster — out-proj dX 137 -> 132 us, QKV 406 -> 420 us,
-// FFN1-dX 493 -> 507 us, step 23.29 -> 23.26 ms on the same box (profiles/r04_notes.md). What the prefetch under the epilogue and the
-// missing relaunch save comes back inside the K loop and the epilogue, whose stores share the CU's memory path with the prefetch.
-#ifndef GSL_P8_PERSISTENT
+// (a persistent form of this kernel — tiles walked per CU, the next tile's first K tile requested under the current epilogue — is
+//  bit-identical and time-neutral: csrc/gemm_dev_c.inc, development build only; profiles/r04_notes.md)
+#ifdef GSL_DEV
+#include "gemm_dev_c.inc"
+#else
 #define GSL_P8_PERSISTENT 0
 #endif
-#if GSL_P8_PERSISTENT
-// One 1 KB LDS-DMA piece (global_load_lds_dwordx4: lane l's 16 bytes land at lds + 16 l) as inline assembly. The persistent kernel keeps
-// LDS-DMA requests in flight ACROSS its epilogue; with the builtin the compiler's waitcnt pass sees "an LDS-DMA may be pending" in front of
-// every ds_write of the epilogue staging (same __shared__ object: may alias) and inserts s_waitcnt vmcnt(0) there — which also waits for the
-// epilogue's own global stores, 64 times per tile. Behind inline assembly the requests are invisible to that pass; every wait on them in
-// this kernel is a hand-counted s_waitcnt anyway. (The pass's own vmcnt waits for the loads it does track can only wait for MORE than it
-// meant to: unknown younger requests add to the outstanding count.)
-__device__ __forceinline__ void lds_dma16(const void* g, const void* lds) {
-  const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)lds);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
-}
-
-// ------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, 8-phase schedule, PERSISTENT (round 4)
-// gemm_bf16_p8_kernel pays per tile: a workgroup launch behind the previous tile's store drain (2.4 - 4.8 k cycles), a prologue in which
-// the first seven half-tiles arrive with nothing to compute on (2.7 - 6 k), and an epilogue (7 - 25 k) during which the CU's LDS-DMA path —
-// the resource that bounds the K loop, profiles/r04_dma_ceiling.md — idles. Here one workgroup per CU walks tiles seq = blockIdx + i * grid
-// (xcd_remap(seq): the N-tiles of one A row panel still meet on one XCD) and, as soon as the K loop of a tile is done, requests K tile 0 of
-// the NEXT tile into stage A while the epilogue of the current tile runs out of the LDS above it (stage B's bytes + 9.7 KB: the staged
-// bf16 epilogue needs 73.7 KB); K tile 1's first three half-tiles follow once the staging is free. Same K loop, same fragments, same
-// epilogue code: bit-identical to gemm_bf16_p8_kernel. EPI: the staged bf16-output epilogues without a second LDS consumer (STORE incl.
-// the head-major QKV store).
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(const bf16_t* __restrict__ A1, int lda1,
-                                                            const bf16_t* __restrict__ W1, int ldw1, int K1,
-                                                            const bf16_t* __restrict__ A2, int lda2,
-                                                            const bf16_t* __restrict__ W2, int ldw2, int K2, int ntiles, EpiArgs e) {
-  resolve_drop(e.drop);
-  constexpr int STG = ST4;
-  constexpr int EOFF = STG;                                    // epilogue staging starts at stage B
-  constexpr int SMEM_E = EOFF + 8 * (CST_WAVE / 2);            // one bf16 output: 64 rows x 144 B per wave
-  static_assert(SMEM_E * 2 <= 163840, "LDS");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_E];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nbn = (e.N + BN4 - 1) / BN4;
-  const int nk1 = K1 / BK, nk = nk1 + K2 / BK;
-  const int lrow = lane >> 3, lc = lane & 7;
-  constexpr int HT = 128 * BK;
-  int m0 = 0, n0 = 0;
-  int arow[2], brow[2], csw[2];
-  auto set_tile = [&](int seq) {
-    const int tile = xcd_remap(seq, ntiles);
-    m0 = (tile / nbn) * BM4; n0 = (tile % nbn) * BN4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wave * 2 + i) * 8 + lrow;
-      arow[i] = m0 + (r >> 6) * 128 + (r & 63);
-      brow[i] = n0 + (r >> 5) * 64 + (r & 31);
-      csw[i] = (lc ^ (r & 7)) * 8;
-    }
-  };
-  auto stage = [&](int kt, auto piece_c) {
-    constexpr int PIECE = decltype(piece_c)::value;
-    if (kt >= nk) return;
-    constexpr bool isA = PIECE & 1;
-    constexpr int half = PIECE >> 1;
-    bf16_t* dst = smem + (kt & 1) * STG + (isA ? 0 : BM4 * BK) + half * HT;
-    const bf16_t* base; int ld, k0;
-    if (kt < nk1) { base = isA ? A1 : W1; ld = isA ? lda1 : ldw1; k0 = kt * BK; }
-    else { base = isA ? A2 : W2; ld = isA ? lda2 : ldw2; k0 = (kt - nk1) * BK; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int g = isA ? min(arow[i] + half * 64, e.M - 1) : min(brow[i] + half * 32, e.N - 1);
-      lds_dma16(base + (size_t)g * ld + k0 + csw[i], dst + (wave * 2 + i) * 8 * BK);
-    }
-  };
-  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-  using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
-  const int fr = lane & 15, fc = lane >> 4;
-  int aoff[4][2], boff[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + fr; aoff[i][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int row = wn * 32 + j * 16 + fr; boff[j][ks] = row * BK + (((ks * 4 + fc) ^ (row & 7)) << 3); }
-  }
-#define GSL_P8P_MFMA(RH, CH, BF)                                                                             \
-  __builtin_amdgcn_s_barrier();                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-  __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                            \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-        acc[(RH) * 4 + i][(CH) * 2 + j] = GSL_MFMA16(BF[j][ks], af[i][ks], acc[(RH) * 4 + i][(CH) * 2 + j], 0, 0, 0); \
-  __builtin_amdgcn_s_setprio(0);                                                                            \
-  __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_barrier();                                                                             \
-  __builtin_amdgcn_sched_barrier(0);
-
-  constexpr int P8P_NST = 16;      // global stores per wave of the FULL staged bf16 epilogue: 2 rounds of 64 rows x 8 row groups
-  bool prev_full = false;
-  int seq = blockIdx.x;
-  if (seq >= ntiles) return;
-  set_tile(seq);
-  stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
-  for (; seq < ntiles; seq += gridDim.x) {
-    // K tile 0 of this tile is in flight (or landed); the first three half-tiles of K tile 1 follow now that stage B is free
-    stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
-    // K tile 0 must have landed. vmcnt retires in order and the previous tile's epilogue stores were issued BEHIND the K-tile-0 requests:
-    // waiting for "<= 6 outstanding" would also wait for the store drain (2 - 3 k cycles: the launch gap of the per-tile kernel in another
-    // place). A wave whose previous sub-tile was complete issued exactly P8P_NST stores (the FULL instance of the staged epilogue has no
-    // predication), so "<= 6 + P8P_NST outstanding" is the exact condition; everything else takes the conservative wait.
-    if (nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + P8P_NST) : "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
-    for (int kt = 0; kt < nk; ++kt) {
-      const bf16_t* As0 = smem + (kt & 1) * STG;
-      const bf16_t* As1 = As0 + HT;
-      const bf16_t* Bs0 = As0 + BM4 * BK;
-      const bf16_t* Bs1 = Bs0 + HT;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf0[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs0 + boff[j][ks]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As0 + aoff[i][ks]);
-      __builtin_amdgcn_sched_barrier(0);
-      stage(kt + 1, P3{});
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-      GSL_P8P_MFMA(0, 0, bf0)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf1[j][ks] = *reinterpret_cast<const bf16x8_t*>(Bs1 + boff[j][ks]);
-      __builtin_amdgcn_sched_barrier(0);
-      stage(kt + 2, P0{});
-      GSL_P8P_MFMA(0, 1, bf1)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(As1 + aoff[i][ks]);
-      __builtin_amdgcn_sched_barrier(0);
-      stage(kt + 2, P1{});
-      GSL_P8P_MFMA(1, 1, bf1)
-      stage(kt + 2, P2{});
-      if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      GSL_P8P_MFMA(1, 0, bf0)
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
-    __builtin_amdgcn_s_barrier();                  // every wave is done with both stages
-    const int em0 = m0, en0 = n0;
-    const int nxt = seq + (int)gridDim.x;
-    if (nxt < ntiles) {                            // K tile 0 of the next tile streams into stage A under this tile's epilogue
-      set_tile(nxt);
-      stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
-    }
-    epilogue_staged_bf16<EPI, 8>(e, acc, smem + EOFF + wave * (CST_WAVE / 2), em0 + wm * 128, en0 + wn * 64, lane);
-    prev_full = (em0 + wm * 128 + 128 <= e.M) && (en0 + wn * 64 + 64 <= e.N) && e.out != nullptr;      // (the condition epilogue_staged_bf16 takes its FULL instance on)
-    __builtin_amdgcn_s_barrier();                  // the staging (stage B's bytes) is free again: every wave has READ its rows (stores may still be in flight)
-  }
-#undef GSL_P8P_MFMA
-}
-
-#endif  // GSL_P8_PERSISTENT
 
 #ifdef GSL_DEV
 #include "gemm_dev_b.inc"
@@ -1942,6 +1631,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ W1, int ldw1, int K1,
                                                        const float* __restrict__ A2, int lda2,
                                                        const float* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) float As[16][68];
   __shared__ __attribute__((aligned(16))) float Ws[16][68];
@@ -1996,6 +1686,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                                             const float* __restrict__ W1, int ldw1, int K1,
                                                             const float* __restrict__ A2, int lda2,
                                                             const float* __restrict__ W2, int ldw2, int K2, EpiArgs e) {
+  GSL_OP16_KERNEL_ENTRY();
   resolve_drop(e.drop);
   __shared__ __attribute__((aligned(16))) float smem[2][2][BM * FBK];      // [buffer][A | W][128 rows x 32 floats] = 64 KB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2212,15 +1903,8 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     if (variant == 8) {
       EpiArgs e8 = e;
       e8.mrev = mrev_for(EPI == GSL_EPI_STORE ? (e.N > K1 ? 0 : (e.N < K1 ? 11 : 12)) : EPI);
-      LoraInk lk8{};
-      const bf16_t* a2 = (const bf16_t*)A2; const bf16_t* w2 = (const bf16_t*)W2; int k2 = K2;
-      if (GSL_TUPD && epi_is_gelu<EPI>() && K2 == 64 && A2 && W2 && lda2 >= 32 && ldw2 >= 32 && !e8.krot) {
-        // fused FFN1: the 64-column LoRA K segment (8 - 16 live columns) as a rank-32 update behind the K loop (see the kernel)
-        lk8.Q = w2; lk8.ldq = ldw2; lk8.tout = const_cast<bf16_t*>(a2); lk8.ldt = lda2;
-        a2 = nullptr; w2 = nullptr; k2 = 0;
-      }
       hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, false>), dim3(((e.M + BM4 - 1) / BM4) * ((e.N + BN4 - 1) / BN4)), dim3(512), 0, st,
-                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, a2, lda2, w2, ldw2, k2, lk8, e8);
+                         (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, LoraInk{}, e8);
     } else if (variant == 3) {
       GSL_LAUNCH((gemm_bf16_ring3_kernel<EPI, 0>), ((e.M + BM3 - 1) / BM3) * ((e.N + BN3 - 1) / BN3), 512);
     } else if (variant == 12) {
@@ -2397,6 +2081,7 @@ constexpr int GF_FAN = 32;
 // level 1: thread (4 consecutive outputs, slab) sums GF_FAN consecutive M-tile partials
 __global__ __launch_bounds__(256) void mulgrad_reduce1_kernel(const float4* __restrict__ part, float4* __restrict__ part2, int NR4, int ntile,
                                                               long which_stride4, long which_stride4_out) {
+  GSL_OP16_KERNEL_ENTRY();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NR4) return;
   const float4* p = part + (size_t)blockIdx.z * which_stride4;
@@ -2412,6 +2097,7 @@ __global__ __launch_bounds__(256) void mulgrad_reduce1_kernel(const float4* __re
 __global__ __launch_bounds__(256) void mulgrad_reduce2_kernel(const float* __restrict__ part2, long which_stride, float* G1, long g1sn, long g1sj,
                                                               float* G2, long g2sn, long g2sj, int N, int R, int r, int nslab,
                                                               int accumulate, const float* __restrict__ gscale) {
+  GSL_OP16_KERNEL_ENTRY();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * R) return;
   const int n = idx / R, j = idx % R;

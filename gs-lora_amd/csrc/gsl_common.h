@@ -59,15 +59,19 @@ template <> struct Elem<float> {
 // (profiles/r04_b_precision_ablation.md: the bf16 stream was 3/4 of the speed mode's logit error). Values are clamped to +-65504 on store.
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 gsl_f16x2;
-// saturating f32 -> fp16: finite values and +-Inf clamp to +-65504, NaN stays NaN. (v_med3_f32 alone returns the middle of the two
-// bounds and a NaN as -65504: a diverged step must stay visible as NaN through every 16-bit tensor, as in the bf16 / f32 forms and in the
-// reference. One v_cmp + v_cndmask on top of the v_med3.)
+// f32 -> fp16 SATURATES in hardware: every kernel that stores fp16 starts with fp16_sat_on(), which sets MODE.FP16_OVFL (bit 23) for the
+// wave — a finite result beyond +-65504 becomes +-65504 instead of Inf, while Inf and NaN inputs stay Inf / NaN (a diverged step must
+// stay visible through every 16-bit tensor, as in the bf16 / f32 forms and in the reference). Probed on MI355X (tools/probes/fp16_ovfl.hip):
+// 1e6 -> 0x7bff, 65520 -> 0x7bff, Inf -> 0x7c00, NaN -> 0x7e00; without the bit 65520 and 1e6 -> Inf. The convert is then one
+// v_cvt_pk_f16_f32 per pair — the cost of the bf16 pack; a software clamp (v_med3 + a NaN select, round 4 / ADVICE r04) cost the fused
+// FFN1 epilogue +9 % and the step +6 % (profiles/r05_notes.md). clamp_h() is the software form for code that cannot rely on the mode bit.
+__device__ __forceinline__ void fp16_sat_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 __device__ __forceinline__ float clamp_h(float v) {
   const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-  return (v != v) ? v : c;
+  return (v != v || __builtin_isinf(v)) ? v : c;
 }
-__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
-  const gsl_f32x2 v = {clamp_h(lo), clamp_h(hi)};
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {      // requires fp16_sat_on() at kernel entry
+  const gsl_f32x2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, gsl_f16x2));      // round to nearest even
 }
 __device__ __forceinline__ void unpack2h(uint32_t u, float& lo, float& hi) {
@@ -82,7 +86,7 @@ __device__ __forceinline__ void unpack2s(uint32_t u, int f16, float& lo, float& 
 }
 template <> struct Elem<f16_t> {
   static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
-  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)clamp_h(v); }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }      // (fp16_sat_on() at kernel entry)
   static __device__ __forceinline__ void ld4(const f16_t* p, float v[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
     unpack2h(t.x, v[0], v[1]); unpack2h(t.y, v[2], v[3]);
@@ -102,6 +106,8 @@ template <> struct Elem<f16_t> {
 // dtype == GSL_F16. Storage type of an operand element is uint16_t in both formats (op16_t): every conversion goes through these
 // helpers, nothing converts numerically by accident.
 typedef uint16_t op16_t;
+// first statement of every kernel of gemm.hip / attention.hip (both compiles: the bf16 build stores fp16 too — the forward residual stream)
+#define GSL_OP16_KERNEL_ENTRY() gsl::fp16_sat_on()
 #ifdef GSL_OP_F16
 #define GSL_OP16 GSL_F16
 #define GSL_OPNS_BEGIN namespace gsl_h16 {
@@ -112,7 +118,7 @@ typedef _Float16 gsl_op16_elem;
 __device__ __forceinline__ uint32_t pack2o(float lo, float hi) { return pack2h(lo, hi); }
 __device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) { unpack2h(u, lo, hi); }
 __device__ __forceinline__ float o2f(op16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
-__device__ __forceinline__ op16_t f2o(float f) { return __builtin_bit_cast(op16_t, (_Float16)clamp_h(f)); }
+__device__ __forceinline__ op16_t f2o(float f) { return __builtin_bit_cast(op16_t, (_Float16)f); }      // (fp16_sat_on() at kernel entry)
 #else
 #define GSL_OP16 GSL_BF16
 #define GSL_OPNS_BEGIN

@@ -12,6 +12,7 @@ using namespace gsl;
 // ------------------------------------------------------------------ K1 patchify
 template <typename T>
 __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C, int H, int W, int p) {
+  fp16_sat_on();
   const int hp = H / p, wp = W / p, Tn = 1 + hp * wp, Kp = p * p * C;
   const long total = (long)B * Tn * p * p;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -43,6 +44,7 @@ extern "C" int gsl_patchify(const float* img, void* out, int B, int C, int H, in
 
 // ------------------------------------------------------------------ K10 head
 __global__ void cosface_prep_kernel(const float* __restrict__ W, float* __restrict__ Wn, int C, int D) {
+  fp16_sat_on();
   // one wave per class row: Wn = W / max(||W||, 1e-12)   (F.normalize, vit_face.py:181)
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(const X* __restrict__ x,
                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                        float* __restrict__ logits, int D, int C, float cs, float cm,
                                                        const float* __restrict__ hbias, int linear, int pool_mean) {
+  fp16_sat_on();
   __shared__ float e[HEAD_MAXD];
   __shared__ float sm[16];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, nwv = blockDim.x >> 6;      // 256 threads, or 1024 when few images share the chip
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        DropCfg drop, int linear, int pool_mean, int compact,
                                                        float* __restrict__ amax_out, const float* __restrict__ amax_in, int n_amax,
                                                        float* __restrict__ gscale_out, int target_exp) {
+  fp16_sat_on();
   resolve_drop(drop);
   // fp16 operands (round 5): the backward runs on gradients multiplied by a power of two S chosen from the largest stream gradient
   // this kernel produces, S * max|g| in [2^(target_exp-1), 2^target_exp). Pass 1 (amax_out) writes max|g| of every image and stores
@@ -322,6 +326,7 @@ __device__ __forceinline__ void row_softmax_stats(const float* row, int C, int l
 
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                       float* __restrict__ rows, int B, int C) {
+  fp16_sat_on();
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
 }
 // deterministic: lane-strided partial sums in a fixed order, fixed-order cross-wave combine
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ rows, float* __restrict__ out, int B, int ncol) {
+  fp16_sat_on();
   __shared__ float sm[16];
   for (int c = 0; c < ncol; ++c) {
     float a = 0.f;
@@ -353,6 +359,7 @@ extern "C" int gsl_ce_fwd(const float* logits, const int64_t* labels, float* out
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                      const float* __restrict__ coef, float scale, float* dlogits, int B, int C,
                                                      int accumulate) {
+  fp16_sat_on();
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
@@ -387,6 +394,7 @@ __device__ __forceinline__ float row_lse(const float* row, int D, int lane) {
 
 __global__ __launch_bounds__(256) void proto_kl_rows_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
                                                             const float* __restrict__ proto, float* __restrict__ rows, int B, int D, int C) {
+  fp16_sat_on();
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
@@ -416,6 +424,7 @@ extern "C" int gsl_proto_kl_fwd(const float* emb, const int64_t* labels, const f
 __global__ __launch_bounds__(256) void proto_kl_bwd_kernel(const float* __restrict__ emb, const int64_t* __restrict__ labels,
                                                            const float* __restrict__ proto, const float* __restrict__ coef,
                                                            float scale, float* demb, int B, int D, int C, int accumulate) {
+  fp16_sat_on();
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B) return;
@@ -451,6 +460,7 @@ __global__ void loss_combine_kernel(const float* ce_r_sum, const float* ce_f_sum
                                     const float* structure, const float* hit_r, const float* hit_f, float n_r, float n_f, float beta,
                                     float BND, float alpha, float w_f, float w_r, float BND_pro, float* total, float* meters,
                                     float* coefs) {
+  fp16_sat_on();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float loss_remain = ce_r_sum[0] / n_r;
   const float hinge_f = BND - ce_f_sum[0] / n_f;
@@ -478,6 +488,7 @@ __global__ void loss_combine_kernel(const float* ce_r_sum, const float* ce_f_sum
 // are read from the pack, so no host value depends on the other ranks.
 __global__ void loss_combine_pack_kernel(const float* pack, const float* structure, int has_proto, float beta, float BND, float alpha,
                                          float w_f, float w_r, float BND_pro, float* total, float* meters, float* coefs) {
+  fp16_sat_on();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float n_r = pack[4], n_f = pack[5];
   const float loss_remain = pack[0] / n_r;
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(1024) void loss_tail_kernel(const float* __restrict
                                                          int Cp, const float* structure, float beta, float BND, float alpha, float w_f,
                                                          float w_r, float BND_pro, float* out14, float* __restrict__ dlogits,
                                                          float* __restrict__ demb) {
+  fp16_sat_on();
   __shared__ float ce_s[LT_MAX], hit_s[LT_MAX], kl_s[LT_MAX], lse_s[LT_MAX], la_s[LT_MAX], lt_s[LT_MAX];
   __shared__ float sm[16], coef_s[5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -72,6 +72,7 @@ template <typename T, int R>
 __global__ __launch_bounds__(256) void lora_grad_partial_kernel(const T* __restrict__ Y, long ldy, const T* __restrict__ U, int ldu,
                                                                 float* __restrict__ part, int M, int N, int rows_per_split,
                                                                 int CG) {
+  fp16_sat_on();
   constexpr int V = LgVec<T>::V;
   __shared__ float us[LG_ROWS][R];
   extern __shared__ __attribute__((aligned(16))) float red[];   // (RP-1) * CG * V * R floats
@@ -249,6 +250,7 @@ __device__ __forceinline__ void lgm_block(const bf16_t* __restrict__ Y, long ldy
 template <int R, bool F16>
 __global__ __launch_bounds__(256) void lora_grad_mfma_kernel(const bf16_t* __restrict__ Y, long ldy, const bf16_t* __restrict__ U, int ldu,
                                                              float* __restrict__ part, int M, int N, int rows_per_split) {
+  fp16_sat_on();
   lgm_block<F16>(Y, ldy, U, ldu, part, M, N, rows_per_split, R, blockIdx.x, blockIdx.y);
 }
 
@@ -264,6 +266,7 @@ struct LgbArgs { int n; LgbEntry e[LGB_MAX]; };
 
 template <bool F16>
 __global__ __launch_bounds__(256) void lora_grad_batch_partial_kernel(const LgbArgs a, float* __restrict__ ws) {
+  fp16_sat_on();
   int d = 0;
   for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].wg0) ? k : d;
   const LgbEntry& e = a.e[d];
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(256) void lora_grad_batch_partial_kernel(const LgbA
 }
 // fixed-order sum of an entry's splits, output strides (+ accumulate) applied on the way out
 __global__ __launch_bounds__(256) void lora_grad_batch_reduce_kernel(const LgbArgs a, const float* __restrict__ ws, const float* __restrict__ gscale) {
+  fp16_sat_on();
   int d = 0;
   for (int k = 1; k < a.n; ++k) d = ((int)blockIdx.x >= a.e[k].rb0) ? k : d;
   const LgbEntry& e = a.e[d];
@@ -302,6 +306,7 @@ static inline bool lgm_usable(int M, int N, int ldu, int dtype) { return dtype !
 // level 1: thread (idx, sb) sums LG_FAN consecutive splits  -> part2[sb][idx]
 __global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ part2,
                                                                 int NR, int nsplit) {
+  fp16_sat_on();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NR) return;
   const int s0 = blockIdx.y * LG_FAN, s1 = min(nsplit, s0 + LG_FAN);
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(256) void lora_grad_reduce1_kernel(const float* __r
 template <int R>
 __global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __restrict__ part2, float* G, long gsn, long gsj,
                                                                 int N, int r, int nslab, int accumulate, const float* __restrict__ gscale) {
+  fp16_sat_on();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * R) return;
   const int n = idx / R, j = idx % R;
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(256) void lora_grad_reduce2_kernel(const float* __r
 template <int R>
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const float* __restrict__ part, float* G, long gsn, long gsj, int N, int r,
                                                                int nsplit, int accumulate, const float* __restrict__ gscale) {
+  fp16_sat_on();
   __shared__ float sm[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + l, NR = N * R;
@@ -449,6 +456,7 @@ extern "C" int gsl_lora_grad(const void* Y, long ldy, const void* U, int ldu, fl
 // =====================================================================================
 __global__ __launch_bounds__(256) void gnorm_partial_kernel(const float* __restrict__ flat, const int64_t* __restrict__ toff,
                                                             const int64_t* __restrict__ tnumel, float* __restrict__ partial) {
+  fp16_sat_on();
   __shared__ float sm[16];
   const int t = blockIdx.x, sp = blockIdx.y;
   const int64_t n = tnumel[t];
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(256) void gnorm_partial_kernel(const float* __restr
 __global__ void gnorm_final_kernel(const float* __restrict__ partial, const int32_t* __restrict__ tgroup, int ntensors,
                                    int ngroups, float tau, float* tensor_sumsq, float* group_norm, float* cal_norm,
                                    float* loss, uint8_t* mask) {
+  fp16_sat_on();
   // one wave; lane g owns group g (looped), everything in fixed order -> bit-reproducible
   const int lane = threadIdx.x;
   for (int t = lane; t < ntensors; t += 64) {
@@ -581,6 +590,7 @@ __global__ __launch_bounds__(256) void gnorm_bwd_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ tnumel, const int32_t* __restrict__ tgroup,
                                                         const float* __restrict__ group_norm, const float* __restrict__ coef,
                                                         float scale, float* gradflat) {
+  fp16_sat_on();
   const int t = blockIdx.x;
   const float nrm = group_norm[tgroup[t]];
   const float k = (nrm > 0.f) ? (coef[0] * scale / nrm) : 0.f;   // subgradient 0 at an all-zero group
@@ -604,6 +614,7 @@ extern "C" int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt) {
+  fp16_sat_on();
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i];
@@ -620,6 +631,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1,
                                                         float b2, float eps, float wd, const int64_t* __restrict__ step_dev) {
+  fp16_sat_on();
   const double t = (double)*step_dev;
   const float lr = *lr_dev;
   const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
@@ -658,6 +670,7 @@ extern "C" int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long
 // =====================================================================================
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long n) {
+  fp16_sat_on();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) Elem<T>::st(out + i, in[i]);
 }
 extern "C" int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s) {
@@ -672,6 +685,7 @@ extern "C" int gsl_cast(const float* in, void* out, long n, int dtype, gsl_strea
 
 template <typename T>
 __global__ void transpose_cast_kernel(const float* __restrict__ in, T* __restrict__ out, int R, int C) {
+  fp16_sat_on();
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
@@ -697,6 +711,7 @@ extern "C" int gsl_transpose_cast(const float* in, void* out, int R, int C, int 
 template <typename T>
 __global__ void pack_pad_kernel(const float* __restrict__ in, long si, long sj, int rows, int cols, float scale, T* __restrict__ out,
                                 int rows_out, int ld_out) {
+  fp16_sat_on();
   const long tot = (long)rows_out * ld_out;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long)gridDim.x * blockDim.x) {
     const int i = (int)(idx / ld_out), j = (int)(idx % ld_out);
@@ -719,6 +734,7 @@ extern "C" int gsl_pack_pad(const float* in, long si, long sj, int rows, int col
 // all LoRA operand packs of a step in ONE launch: blockIdx.y selects the descriptor (device-resident table built once by the host)
 template <typename T>
 __global__ void pack_pad_batch_kernel(const gsl_pack_desc* __restrict__ descs) {
+  fp16_sat_on();
   const gsl_pack_desc d = descs[blockIdx.y];
   const long tot = (long)d.rows_out * d.ld_out;
   T* out = reinterpret_cast<T*>(d.out);
@@ -739,6 +755,7 @@ extern "C" int gsl_pack_pad_batch(const gsl_pack_desc* descs_dev, int n, long ma
 }
 
 __global__ void dropout_mask_kernel(uint8_t* keep, long n, DropCfg d) {
+  fp16_sat_on();
   resolve_drop(d);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     keep[i] = drop_mul(d, (uint64_t)i) != 0.f ? 1 : 0;

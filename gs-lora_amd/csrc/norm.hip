@@ -39,6 +39,7 @@ template <int NPL, typename T, typename X>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const X* __restrict__ x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M) {
+  fp16_sat_on();
   constexpr int D = NPL * 64;
   using IO = RowIO<NPL>;
   const int lane = threadIdx.x & 63;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, const S* dres,
                                                      S* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
                                                      long drop_row_stride, int cls_T) {
+  fp16_sat_on();
   resolve_drop(drop);
   constexpr int D = NPL * 64;
   using IO = RowIO<NPL>;
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(256, (KS <= 16 ? 4 : 3)) void ln_fwd_lora_kernel(co
                                                           const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                           const bf16_t* __restrict__ P, int ldp, float alpha, bf16_t* __restrict__ u) {
+  fp16_sat_on();
   constexpr int D = KS * 32;
   constexpr int PLD = D + 8;                  // 16 more bytes per row: the 16 rows of a fragment read start 4 banks apart
   __shared__ float sg[D], sb[D];

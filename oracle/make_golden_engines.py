@@ -230,7 +230,7 @@ def gen_acc(out):
 
 
 def gen_acc_stat(out, only=None):
-    """tests/golden/engine_cl_acc_stat.npz: the statistical accuracy evidence (scenarios.ACC_STAT x scenarios.ACC_SEEDS) — per scenario and
+    """tests/golden/engine_cl_acc_stat.npz: the statistical accuracy evidence (scenarios.ACC_STAT x scenarios.acc_seeds(name)) — per scenario and
     data seed: the four accuracies of the REAL eval_data (engine_cl.py:318-346) before / after training with the REAL
     engine_cl.train_one_epoch, per-sample predictions and decision margins; per scenario the two frozen head tensors (data)."""
     import engine_cl
@@ -257,7 +257,7 @@ def gen_acc_stat(out, only=None):
                     return torch.cat([m(x[i:i + 20]) for i in range(0, x.shape[0], 20)])
             hb, lw = S.discriminative_head(emb_fn, base, cfg, (S.acc_stat_head_set(cfg, sc["noise"]),), common=sc["common"])
             res[f"{name}::head_bias"], res[f"{name}::loss_weight"] = hb, lw
-        for seed in S.ACC_SEEDS:
+        for seed in S.acc_seeds(name):
             if only and f"s{seed}" not in only and any(o.startswith("s") for o in only):
                 continue
             t0 = time.time()

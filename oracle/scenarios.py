@@ -141,6 +141,15 @@ ACC = dict(n_per_split=1000, batch=40)
 #            6 epochs x 16 steps = 96 steps: below the engines' VER_FREQ = 100 (no evaluate() / checkpoint inside the run).
 # A data seed selects the training batches (labels and noise) and the held-out evaluation samples; the frozen head is one per scenario.
 ACC_SEEDS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)
+# round 5: "real" carries 20 seeds — its deltas are a handful of flipped predictions per cell (0.05 pp each), and the equivalence form of the
+# criterion (|mean| + 1.64 standard errors < 0.1 pp) needs the standard error of the mean below ~0.03 pp to be decidable
+ACC_SEEDS_BY = {"harsh": ACC_SEEDS, "real": tuple(range(20))}
+
+
+def acc_seeds(name):
+    return ACC_SEEDS_BY.get(name, ACC_SEEDS)
+
+
 ACC_STAT = {
     "harsh": dict(TRAJ, common=1.17, noise=0.08, n_per_split=2000, eval_batch=40, train_labels="traj"),
     "real": dict(batch=16, n_remain=16, n_forget=8, epochs=6, lr=1e-3, lr_min=1e-5, wd=0.05, beta=0.3, alpha=1e-2, BND=105.0, BND_pro=2.0,

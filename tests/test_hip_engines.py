@@ -354,7 +354,7 @@ def run_acc_stat(dtype, name, seed, golden_dir, report=None):
 def acc_stat_table(dtype, name, golden_dir, seeds=None):
     """Mean / std over the data seeds of the accuracy deltas (pp) per split, + the raw cells. Used by the test below and by
     tools/acc_stat_report.py (the committed table profiles/r04_acc_stat.md)."""
-    cells = {seed: run_acc_stat(dtype, name, seed, golden_dir) for seed in (seeds or S.ACC_SEEDS)}
+    cells = {seed: run_acc_stat(dtype, name, seed, golden_dir) for seed in (seeds or S.acc_seeds(name))}
     stat = {}
     for split in ("forget_before", "remain_before", "forget_after", "remain_after"):
         d = np.array([cells[s][split]["delta_pp"] for s in cells])
@@ -364,33 +364,55 @@ def acc_stat_table(dtype, name, golden_dir, seeds=None):
     return stat, cells
 
 
-@pytest.mark.parametrize("name", list(S.ACC_STAT))
-def test_accuracy_deltas_bf16_training_statistical(name, golden_dir):
-    """north_star: forget / retain accuracy deltas vs the reference < 0.1 pp — in the BENCHMARKED mode (bf16 training step), as statistics:
-    10 data seeds x 2 x 2 000 held-out samples per scenario ("harsh": accuracies 10 - 17 %, near-ties everywhere; "real": the reference's
-    operating regime, pre-forget accuracy 100 %, the task drives the forget accuracy to ~27 %), each cell against the REAL reference's
-    eval_data on the same samples after training with the REAL engine. The engines evaluate in f32 whatever mode they train in (product
-    default, engine_cl.EVAL_DTYPE), so the "before" deltas are those of the f32 parity kernels and the "after" deltas measure what the
-    bf16 TRAINING steps changed.
-    Measured (MI355X, round 4, profiles/r04_g_acc_stat_10seeds.md): both "before" splits and "forget after" are EXACT in every cell of both
-    scenarios (0.000 pp; 0 of 20 000 predictions differ before training). "remain after" is where bf16 training shows: +0.03 pp mean, std over
-    seeds 0.22 ("real", 65 of 20 000 predictions differ: the criterion holds for the mean) and -0.34 pp, std 0.52 ("harsh", 704 of 20 000: NOT
-    met); the f32 parity mode has 0 differing predictions. Cause and cost of the alternative: DESIGN.md section 7 (bf16 GEMM operands
-    leave a 0.3 % LoRA-gradient error at every batch size; AdamW's sign-like first steps turn it into different trajectories).
-    Asserted, per split: the exact splits |mean delta| < 0.1 pp with every cell < 0.1 pp; for "remain after" the fixed statistical rule
-    |mean| <= 0.1 + 2 standard errors of the mean (the data do not contradict a bias below 0.1 pp) — a rule, not a band fitted to the run."""
-    stat, cells = acc_stat_table("bf16", name, golden_dir)
-    n = len(cells)
+def _print_acc_stat(dtype, name, stat, n):
     for split, r in stat.items():
-        print(f"[acc-stat bf16 {name}] {split}: reference accuracy {r['ref_acc']:.2f} %, delta {r['mean']:+.3f} +- {r['std']:.3f} pp over "
-              f"{n} seeds (worst cell {r['worst']:.2f} pp), {r['flips']} of {n * S.ACC_STAT[name]['n_per_split']} predictions differ; "
-              f"criterion |mean| < 0.1 pp: {'met' if abs(r['mean']) < 0.1 else 'NOT met'}")
+        se = r["std"] / np.sqrt(n)
+        print(f"[acc-stat {dtype} {name}] {split}: reference accuracy {r['ref_acc']:.2f} %, delta {r['mean']:+.3f} +- {r['std']:.3f} pp over "
+              f"{n} seeds (standard error {se:.3f}, worst cell {r['worst']:.2f} pp), {r['flips']} of {n * S.ACC_STAT[name]['n_per_split']} predictions differ; "
+              f"equivalence |mean| + 1.64 SE = {abs(r['mean']) + 1.64 * se:.3f} pp (< 0.1: {'met' if abs(r['mean']) + 1.64 * se < 0.1 else 'NOT met'})")
+
+
+@pytest.mark.parametrize("name", list(S.ACC_STAT))
+def test_accuracy_deltas_fp16_training_equivalence(name, golden_dir):
+    """north_star: forget / retain accuracy deltas vs the reference < 0.1 pp — in the BENCHMARKED mode (fp16 operands, the default), as an
+    EQUIVALENCE test: the criterion is asserted, not merely not rejected. Scenarios x data seeds x 2 x 2 000 held-out samples ("harsh":
+    accuracies 10 - 17 %, near-ties everywhere, 10 seeds; "real": the reference's operating regime, pre-forget accuracy 100 %, the task drives
+    the forget accuracy to ~27 %, 20 seeds), each cell against the REAL reference's eval_data on the same samples after training with the
+    REAL engine (tests/golden/engine_cl_acc_stat.npz). The engines evaluate in f32 whatever mode they train in (engine_cl.EVAL_DTYPE), so
+    the "before" deltas are those of the f32 parity kernels and the "after" deltas measure what the 16-bit TRAINING steps changed.
+    Asserted per split: the three splits that are exact in practice — |mean delta| < 0.1 pp and every cell < 0.1 pp; "remain after" (the
+    split that carries the whole effect of 16-bit training): the one-sided 95 % bound |mean| + 1.64 standard errors of the mean < 0.1 pp.
+    A noisier build fails this rule; it cannot pass by scattering more (VERDICT r04 weak #1 / ADVICE r04).
+    Measured (MI355X, round 5, profiles/r05_b_acc_stat_fp16.md): "harsh" -0.025 +- 0.054 pp (bound 0.053), "real" +0.035 +- 0.120 pp over
+    the first 10 seeds; bf16 operands (round 4): -0.34 +- 0.52 / +0.03 +- 0.22."""
+    stat, cells = acc_stat_table("fp16", name, golden_dir)
+    n = len(cells)
+    _print_acc_stat("fp16", name, stat, n)
     for split in ("forget_before", "remain_before"):      # f32 evaluation of the untrained model: the parity kernels' own bar
         assert stat[split]["flips"] <= 2 and stat[split]["worst"] < 0.1, (name, split, stat[split])
     assert abs(stat["forget_after"]["mean"]) < 0.1 and stat["forget_after"]["worst"] < 0.1, (name, stat["forget_after"])
     r = stat["remain_after"]
-    assert abs(r["mean"]) <= 0.1 + 2.0 * r["std"] / np.sqrt(n), (name, r)
-    assert r["flips"] < 0.05 * n * S.ACC_STAT[name]["n_per_split"], (name, r)      # (sanity: the trajectories stay close, 95 % of the predictions agree)
+    assert abs(r["mean"]) + 1.64 * r["std"] / np.sqrt(n) < 0.1, (name, r)
+    assert r["worst"] <= 0.5, (name, r)      # no single run strays by more than half a point
+
+
+@pytest.mark.parametrize("name", list(S.ACC_STAT))
+def test_accuracy_deltas_bf16_training_fixed_caps(name, golden_dir):
+    """The bf16 operand mode (selectable, no longer the default) on the first 10 seeds: it does NOT meet the < 0.1 pp criterion under the
+    near-chance "harsh" conditions (round 4: -0.34 +- 0.52 pp, 704 of 20 000 predictions differ; "real": +0.03 +- 0.22) — which is why the
+    default moved to fp16 operands. What is asserted here are FIXED caps that a regression of the bf16 kernels' trajectory fidelity breaks
+    (they do not loosen with the observed scatter): the exact splits as in the fp16 test, "remain after" |mean| <= 0.6 / 0.15 pp
+    (harsh / real), worst cell <= 1.5 / 0.6 pp, differing predictions <= 5 % / 0.5 %."""
+    stat, cells = acc_stat_table("bf16", name, golden_dir, seeds=S.ACC_SEEDS)
+    n = len(cells)
+    _print_acc_stat("bf16", name, stat, n)
+    for split in ("forget_before", "remain_before"):
+        assert stat[split]["flips"] <= 2 and stat[split]["worst"] < 0.1, (name, split, stat[split])
+    assert abs(stat["forget_after"]["mean"]) < 0.1 and stat["forget_after"]["worst"] < 0.1, (name, stat["forget_after"])
+    r = stat["remain_after"]
+    cap_mean, cap_worst, cap_flips = {"harsh": (0.6, 1.5, 0.05), "real": (0.15, 0.6, 0.005)}[name]
+    assert abs(r["mean"]) <= cap_mean and r["worst"] <= cap_worst, (name, r)
+    assert r["flips"] <= cap_flips * n * S.ACC_STAT[name]["n_per_split"], (name, r)
 
 
 @pytest.mark.parametrize("name", list(S.ACC_STAT))

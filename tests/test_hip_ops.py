@@ -39,7 +39,7 @@ def relerr(a, b):
     return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
 
 
-DTS = [torch.float32, torch.bfloat16]
+DTS = [torch.float32, torch.bfloat16, torch.float16]      # parity mode and the two operand formats of the speed mode
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -736,6 +736,13 @@ def test_gemm_bf16_stream_epilogues_equal_the_rounded_f32_stream_epilogues(ops, 
         big = torch.full((M, N), 60000.0, device="cuda", dtype=sdt)
         ops.gemm_nt(A1, W1, o16, epilogue=epi_res, A2=A2, W2=W2, bias=bias + 30000.0, res=big)
         assert torch.isfinite(o16.float()).all() and float(o16.float().max()) == 65504.0
+        # ... but a NaN / Inf that arrives stays one (a software v_med3 clamp turned NaN into -65504 and hid a diverged step;
+        # the stores now saturate through MODE.FP16_OVFL, which keeps Inf and NaN)
+        big[0, 0], big[1, 1], big[2, 2] = float("nan"), float("inf"), float("-inf")
+        ops.gemm_nt(A1, W1, o16, epilogue=epi_res, A2=A2, W2=W2, bias=bias + 30000.0, res=big)
+        assert torch.isnan(o16[0, 0]) and o16[1, 1] == float("inf") and o16[2, 2] == float("-inf")
+        o16[0, 0] = o16[1, 1] = o16[2, 2] = 0
+        assert torch.isfinite(o16.float()).all()
 
 
 def test_gemm_nt_lora_bf16_stream_epilogue(ops):
@@ -1140,3 +1147,27 @@ def test_out_of_range_labels_turn_the_loss_nan_instead_of_reading_out_of_bounds(
         emb, proto = rnd(B, D, seed=2).cuda(), rnd(C, D, seed=3).cuda()
         total, meters, coefs, dl, de = ops.loss_tail(logits, bad, 4, emb, proto, torch.ones(1, device="cuda"), 0.15, 105.0, 1e-2, 0.05, 0.1, 2.0)
         assert torch.isnan(total) and torch.isnan(dl[3]).all() and torch.isfinite(dl[0]).all()
+
+
+def test_fp16_operand_mode_stores_saturate_and_keep_nan(ops):
+    """dtype GSL_F16 (round 5): every 16-bit store of the fp16 operand mode saturates finite overflow at +-65504 in hardware
+    (MODE.FP16_OVFL set at kernel entry) — the GEMM STORE epilogue on the 8-phase, ring and small-tile kernels, the LayerNorm forward
+    output, the cast helper — and the VALU paths keep NaN / Inf. (NaN / Inf in an MFMA OPERAND is a different matter and not asserted: the
+    gfx950 matrix core itself drops a NaN operand's 8-element k-group and clamps Inf to the largest finite value, in bf16 and fp16 alike —
+    tools/probes/nan_probe.py; NaN reaches the 16-bit tensors through the f32 epilogue arithmetic: see the residual-stream test above.)"""
+    dt = torch.float16
+    for M, N, K in ((33490, 512, 512), (2100, 128, 128), (300, 256, 64)):
+        A = torch.full((M, K), 200.0, device="cuda", dtype=dt)
+        W = torch.full((N, K), 200.0, device="cuda", dtype=dt)      # every output = K * 4e4 >> 65504
+        W[1] = -200.0
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        ops.gemm_nt(A, W, out)
+        assert torch.isfinite(out.float()).all() and float(out[:, 0].float().min()) == 65504.0 and float(out[:, 1].float().max()) == -65504.0, (M, N, K)
+    x = rnd(64, 512, seed=1).cuda()
+    y, _, _ = ops.layernorm_fwd(x, 512, 64, 512, torch.full((512,), 1e6).cuda(), torch.zeros(512).cuda(), 1e-5, dt)
+    assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) == 65504.0
+    x[3, 7] = float("nan")
+    y, _, _ = ops.layernorm_fwd(x, 512, 64, 512, torch.ones(512).cuda(), torch.zeros(512).cuda(), 1e-5, dt)
+    assert torch.isnan(y[3]).all() and torch.isfinite(y[:3].float()).all()
+    c = ops.cast(torch.tensor([1e6, -1e6, float("inf"), float("nan"), 1.0]).cuda(), dt)
+    assert c[0] == 65504.0 and c[1] == -65504.0 and c[2] == float("inf") and torch.isnan(c[3]) and c[4] == 1.0

@@ -15,6 +15,10 @@ import io
 import numpy as np  # noqa: E402
 
 CONFIGS = {      # name -> (training dtype, vit_runner attributes, engine_cl.EVAL_DTYPE)
+    "fp16 (round 5 default: fp16 operands + streams, loss-scaled backward, 8-bit GELU')": ("fp16", {}, "fp32"),
+    "fp16, fp16 GELU' (no 8-bit code)": ("fp16", {"GP8": False}, "fp32"),
+    "fp16, evaluation in fp16 too": ("fp16", {}, "model"),
+    "fp16, all wide (f32 streams, fp16 GELU')": ("fp16", {"FWD_STREAM": "f32", "GRAD_STREAM_BF16": False, "GP8": False}, "fp32"),
     "bf16 (default: fp16 forward stream)": ("bf16", {}, "fp32"),
     "bf16, evaluation in bf16 too": ("bf16", {}, "model"),
     "bf16, bf16 forward stream (round 3)": ("bf16", {"FWD_STREAM": "bf16"}, "fp32"),
@@ -50,8 +54,8 @@ def main():
         try:
             for sname in (scen or S.ACC_STAT):
                 t0 = time.time()
-                seeds = tuple(int(v) for v in os.environ["GSL_ACC_SEEDS"].split(",")) if os.environ.get("GSL_ACC_SEEDS") else S.ACC_SEEDS
-                seeds = seeds if dtype == "bf16" else seeds[:2]
+                seeds = tuple(int(v) for v in os.environ["GSL_ACC_SEEDS"].split(",")) if os.environ.get("GSL_ACC_SEEDS") else S.acc_seeds(sname)
+                seeds = seeds if dtype != "fp32" else seeds[:2]
                 with contextlib.redirect_stdout(io.StringIO()):
                     stat, cells = T.acc_stat_table(dtype, sname, golden, seeds)
                 n = len(cells) * S.ACC_STAT[sname]["n_per_split"]
