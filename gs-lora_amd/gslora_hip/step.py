@@ -437,6 +437,13 @@ class GraphedStep:
         calls0 = r.drop_calls
         torch.cuda.synchronize()
         self.optimizer.graph_mode, r.seed_dev = True, self.seed_dev
+        # No cyclic garbage collection while the stream is capturing: an older model's GraphedStep that the collector happens to free inside the
+        # capture destroys a hipGraph / events on a capturing thread and the runtime aborts the process (seen with 20 models built in sequence,
+        # tests/test_hip_engines.py acc-stat cells). Collect first, keep the collector off until the capture has ended.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             if _dp_active():
                 graph = _SegmentedCapture()
@@ -454,6 +461,8 @@ class GraphedStep:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static[4] = gs_lora_step(self.model, self.optimizer, self.criterion, *static[:4], **kw)
         finally:
+            if gc_was_on:
+                gc.enable()
             self.optimizer.graph_mode, r.seed_dev = False, None     # eager forwards keep passing the seed by value
             nfwd = r.drop_calls - calls0
             r.drop_calls = calls0                                     # nothing ran during capture
