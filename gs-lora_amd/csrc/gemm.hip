@@ -1613,6 +1613,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
 }
 
+// (a 4-wave, one-wave-per-SIMD 32x32x16 form of the plain-store GEMM — csrc/gemm_w4.inc, development build only — has the faster K loop at
+//  K = 512 and loses the tile on its epilogue: profiles/r05_e_kloop_4w32.md, r05_h_w4_stamps.md)
+#ifdef GSL_DEV
+#include "gemm_w4.inc"
+#endif
+
 // (a persistent form of this kernel — tiles walked per CU, the next tile's first K tile requested under the current epilogue — is
 //  bit-identical and time-neutral: csrc/gemm_dev_c.inc, development build only; profiles/r04_notes.md)
 #ifdef GSL_DEV
@@ -1897,6 +1903,17 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
         hipLaunchKernelGGL((gemm_bf16_p8p_kernel<EPI>), dim3(p8p_grid()), dim3(512), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, ldw1, K1,
                            (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, nt8, e);
         return check_launch("gsl_gemm_nt(p8p)");
+      }
+    }
+#endif
+#ifdef GSL_DEV
+    if constexpr (EPI == GSL_EPI_STORE) {
+      // development (GSL_W4=1): plain-store GEMMs on the 4-wave 32x32x16 kernel where its shape rules hold (gemm_w4.inc; measured alternative)
+      const char* w = getenv("GSL_W4");
+      if (w && atoi(w) == 1 && variant == 8 && w4_usable(e.M, e.N, K1, K2, lda1, ldw1, e.ldo)) {
+        hipLaunchKernelGGL((gemm_op16_w4_kernel<EPI>), dim3(((e.M + 255) / 256) * (e.N / 256)), dim3(256), 0, st, (const op16_t*)A1, lda1,
+                           (const op16_t*)W1, ldw1, K1, e);
+        return check_launch("gsl_gemm_nt(w4)");
       }
     }
 #endif

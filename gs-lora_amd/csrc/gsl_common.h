@@ -114,6 +114,7 @@ typedef uint16_t op16_t;
 #define GSL_OPNS_END }
 #define GSL_ENTRY(name) h16_##name
 #define GSL_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define GSL_MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_f16
 typedef _Float16 gsl_op16_elem;
 __device__ __forceinline__ uint32_t pack2o(float lo, float hi) { return pack2h(lo, hi); }
 __device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) { unpack2h(u, lo, hi); }
@@ -125,6 +126,7 @@ __device__ __forceinline__ op16_t f2o(float f) { return __builtin_bit_cast(op16_
 #define GSL_OPNS_END
 #define GSL_ENTRY(name) name
 #define GSL_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define GSL_MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 typedef __bf16 gsl_op16_elem;
 __device__ __forceinline__ uint32_t pack2o(float lo, float hi) { return pack2bf(lo, hi); }
 __device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }

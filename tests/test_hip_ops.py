@@ -1171,3 +1171,32 @@ def test_fp16_operand_mode_stores_saturate_and_keep_nan(ops):
     assert torch.isnan(y[3]).all() and torch.isfinite(y[:3].float()).all()
     c = ops.cast(torch.tensor([1e6, -1e6, float("inf"), float("nan"), 1.0]).cuda(), dt)
     assert c[0] == 65504.0 and c[1] == -65504.0 and c[2] == float("inf") and torch.isnan(c[3]) and c[4] == 1.0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,T,bias", [(33490, 512, 512, 0, False), (33490, 1536, 512, 197, False), (33490, 1536, 768, 197, True), (33490, 512, 1536, 0, False),
+                                          (4096, 512, 128, 0, True), (65536, 1024, 512, 0, False)])
+def test_gemm_w4_store_kernel(ops, dev_lib, monkeypatch, M, N, K, T, bias, dt):
+    """The 4-wave 32x32x16 kernel of the plain-store GEMMs (csrc/gemm_w4.inc: a measured alternative in the dev build, GSL_W4=1; N % 256 == 0, no K
+    segment, K >= 128) against torch fp32 on the operands the kernel sees, and against the product's 8-wave 8-phase kernel: same products,
+    another summation order (k in steps of 16 instead of 32) — equal within f32 accumulation noise, i.e. almost always the same 16-bit value.
+    Ragged last M tile, row-major and head-major (STORE_QKV_HM) outputs, optional bias, strided operand views."""
+    from gslora_hip import _lib as L
+    A = rnd(M, K, seed=1).cuda().to(dt)
+    Wfull = rnd(N, K + 64, seed=2, scale=K ** -0.5).cuda().to(dt)
+    W = Wfull[:, 32:32 + K]                                   # a column block: ldw != K
+    b = rnd(N, seed=3).cuda() if bias else None
+    epi = L.EPI_STORE_QKV_HM if T else L.EPI_STORE
+    old = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A, W, old, epilogue=epi, T=T, bias=b)         # product library: the 8-phase kernel
+    dev_lib(L)
+    monkeypatch.setenv("GSL_W4", "1")
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A, W, out, epilogue=epi, T=T, bias=b)
+    ref = A.float() @ W.float().t() + (b if bias else 0)
+    if T:
+        Bn, H = M // T, N // 192
+        ref = ref.view(Bn, T, 3, H, 64).permute(0, 3, 2, 1, 4).reshape(M, N)
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert ((out.float() - ref).abs() <= eps * ref.abs() + 1e-3).all()
+    assert (old != out).float().mean() < 0.02 and ((old.float() - out.float()).abs() <= 2 * eps * ref.abs() + 1e-3).all()
