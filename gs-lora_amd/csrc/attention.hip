@@ -836,6 +836,330 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_fused_bf16_kernel(const bf16_t
 #undef GSL_ATTN_STAMP
 
 // =====================================================================================
+// backward, MERGED (16-bit, 192 < T <= 208, at least two items per CU; round 5): persistent, one 16-wave workgroup per CU.
+// The fused kernel above computes the score tiles twice (S and dP in the dQ phase AND in the dK/dV phase: 7 matrix products and two
+// exponentials per score), runs 13 tiles on 8 waves (two rounds, the second 5/8 full) and re-stages its panels between the phases.
+// Here every score tile is computed ONCE, by the wave that owns its key tile:
+//   * waves 0..12 own one key tile each (K / V fragments in registers, dK / dV accumulators in registers) and walk the query pairs:
+//     S = Q K^T, dP = dO V^T, P, dS exactly as the dK/dV phase of the fused kernel — and park the 16-bit dS tile in an LDS buffer
+//     Ds[key][query] (one ds_write_b64 per tile: the C layout holds 4 consecutive queries of one key);
+//   * dQ^T += K^T dS^T then reads dS back with the LDS transpose read in the k-slot permutation of the dQ phase (the same MFMA operands
+//     in the same order as the fused kernel), as 52 units (query tile, 16 columns of dQ) dealt round-robin to the 13 waves. Ds holds
+//     128 queries, so the item runs as P1a (query pairs 0..3) | P2a (dQ tiles 0..7) | P1b (pairs 4..6) | P2b (dQ tiles 8..12): four
+//     workgroup barriers per item. The K panel P2 needs is deposited by the key owners from their fragments;
+//   * waves 13..15 move data one item ahead (registers, like the forward's loaders): dO and O during P1a, delta = rowsum(dO o O) and
+//     the Q request during P2a, the Q / dO deposit into the panels during P2b (nobody reads them there). delta is accumulated in the
+//     order of the fused kernel's lanes (chunk fc of the first 32 columns, then chunk fc of the second 32, then the xor-16 / xor-32
+//     sums), so every value of the kernel is the fused kernel's: bit-identical dqkv.
+// 5 matrix products instead of 7 (1 768 MFMAs per item instead of 2 548), one exponential per score instead of two, every byte of
+// q / k / v / dO / o read from HBM once. LDS: three 208-row panels (KLD) + Ds [208][DSLD] + lse / delta (double-buffered) = 163 072 B.
+// =====================================================================================
+constexpr int DSLD = 144;      // elements per Ds row: 288 B, the 8 rows of a transpose read land on 8 disjoint bank octets
+// lds_frag_trr for a panel with row stride LD; HALF: only rows pair*32 .. pair*32 + 15 exist (k-slots 4..7 are zero)
+template <int LD, bool HALF>
+__device__ __forceinline__ bf16x8_t lds_frag_trr_g(const bf16_t* base, int dt, int pair, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int row = pair * 32 + 4 * g + (i >> 2), col = dt * 16 + (i & 3) * 4;
+  union { v4s_t h[2]; bf16x8_t v; } f;
+  f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(base + row * LD + col));
+  if constexpr (HALF) f.h[1] = v4s_t{0, 0, 0, 0};
+  else f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(base + (row + 16) * LD + col));
+  return f.v;
+}
+
+// A 16 x 64 tile held in C layout (lane (fr, fc): row fr, columns dt * 16 + 4 fc .. + 3 of acc[dt]) leaves as FULL 128-byte rows: through a
+// wave-private LDS area (row stride LD elements), then 16 bytes per lane, 8 lanes per row, 2 store instructions per tile. The fragment-
+// layout store (store4bf: 8 bytes per lane, 16 rows x 32 bytes per instruction, 4 instructions per tile) costs ~115 cycles of the CU's
+// vector-memory pipe per instruction: 156 of them per item kept that pipe busy for ~18 k cycles and every load queued behind them
+// (profiles/r05_j_attn_merged.md). Same values (v * mul rounded once), rows >= nvalid are not written.
+template <int LD>
+__device__ __forceinline__ void store_tile_rows(bf16_t* stage, const f32x4_t (&acc)[4], float mul, bf16_t* gbase, long gld, int nvalid, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    *reinterpret_cast<uint2*>(stage + fr * LD + dt * 16 + fc * 4) =
+        make_uint2(pack2o(acc[dt][0] * mul, acc[dt][1] * mul), pack2o(acc[dt][2] * mul, acc[dt][3] * mul));
+  const int r = lane >> 3, c = lane & 7;
+  const uint4 v0 = *reinterpret_cast<const uint4*>(stage + r * LD + c * 8);
+  const uint4 v1 = *reinterpret_cast<const uint4*>(stage + (r + 8) * LD + c * 8);
+  if (r < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)r * gld + c * 8) = v0;
+  if (r + 8 < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)(r + 8) * gld + c * 8) = v1;
+}
+
+template <int NKT>      // (NKT - 2) * 16 < T <= (NKT - 1) * 16: T = 197 with NKT = 14
+__global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int T, int H, float scale, int nitems, int hm, int imap,
+                                                               unsigned long long* __restrict__ stamps, int stagger) {
+  GSL_OP16_KERNEL_ENTRY();
+  // development (GSL_ATTN_STAMPS = device address of 2048 u64): cycle stamps of the THIRD item of every 32nd workgroup, 16 slots per wave:
+  // item start | P1a | barrier | P2a | barrier | P1b pairs | P1b last pair | stores + next keys issued | barrier | P2b | barrier
+  unsigned long long* dbg = (stamps && (blockIdx.x & 31) == 0 && blockIdx.x < 256) ? stamps + (blockIdx.x >> 5) * 256 : nullptr;      // uniform
+#define GSL_MSTAMP(i) do { if (dbg && seq == (int)(blockIdx.x + 2 * gridDim.x) && lane == 0) dbg[wave * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+  constexpr int NCW = NKT - 1;            // compute waves = key tiles that can hold a valid key (13)
+  constexpr int TP = NCW * 16;            // panel rows (208)
+  constexpr int NST = 9;                  // loader steps per panel: 24 rows x 8 chunks per step
+  constexpr int NP = NKT / 2;             // query pairs (7); the last one holds a single tile
+  constexpr int NPA = 4;                  // pairs of the first half: queries 0 .. 127 = dQ tiles 0 .. 7
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Gs[TP * KLD];      // dO
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[TP * DSLD];     // dS [key][query of the half]
+  __shared__ __attribute__((aligned(16))) float lse_s[2][TP];       // log2 units; padded queries 1e30 -> p = 0
+  __shared__ __attribute__((aligned(16))) float del_s[2][TP];
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const long ld = 3L * H * HD, ldo = (long)H * HD;
+  const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fc = lane >> 4;
+  // rows >= T of the panels are zero and the padded queries' lse / delta are 1e30 / 0 for every item: written once
+  for (int idx = threadIdx.x; idx < (TP - T) * 8; idx += 1024) {
+    const int t = T + (idx >> 3), c = idx & 7;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Qs + lds_off(t, c * 8)) = z;
+    *reinterpret_cast<uint4*>(Gs + lds_off(t, c * 8)) = z;
+    *reinterpret_cast<uint4*>(Ks + lds_off(t, c * 8)) = z;
+  }
+  if ((int)threadIdx.x < TP - T) {
+    lse_s[0][T + threadIdx.x] = 1.0e30f; lse_s[1][T + threadIdx.x] = 1.0e30f;
+    del_s[0][T + threadIdx.x] = 0.f; del_s[1][T + threadIdx.x] = 0.f;
+  }
+  // Stagger (A/B, dev knob): every CU runs the same phases on the same clock, so the chip's HBM traffic comes in bursts (all dK / dV stores
+  // and all next-item loads inside one third of the item). Workgroups start a quarter of an item apart in four groups.
+  if (stagger > 0) for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ loader waves (see attn_fwd_bf16_pers_kernel for the register rules)
+    const int li = (wave - NCW) * 64 + lane, col = (li & 7) * 8, row0 = li >> 3, ch = li & 7;
+    u32x4_t rq[NST], rg[NST], ro[NST];
+    // (row0 is laundered through an empty asm in every helper: the 9 + 9 loop-invariant per-step offsets would otherwise be hoisted out
+    //  of the item loop and live next to 72 data registers — 13 spilled VGPRs)
+    auto req_go = [&](int seq) {
+      int r0 = row0; asm volatile("" : "+v"(r0));
+      const int it = item_remap(seq, H, imap), b = it / H, h = it % H;
+      const bf16_t* gb = d_o + (size_t)b * T * ldo + h * HD;
+      const bf16_t* ob = o + (size_t)b * T * ldo + h * HD;
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const size_t g = (size_t)min(r0 + 24 * k, T - 1) * ldo + col;
+        rg[k] = *reinterpret_cast<const u32x4_t*>(gb + g);
+        ro[k] = *reinterpret_cast<const u32x4_t*>(ob + g);
+      }
+    };
+    auto req_q = [&](int seq) {
+      int r0 = row0; asm volatile("" : "+v"(r0));
+      const int it = item_remap(seq, H, imap), b = it / H, h = it % H;
+      const bf16_t* qb = qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)b * T * ld + h * HD);
+#pragma unroll
+      for (int k = 0; k < NST; ++k) rq[k] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)min(r0 + 24 * k, T - 1) * ldi + col);
+    };
+    // delta of the rows this lane's 8-lane group holds, in the fused kernel's order: lanes ch < 4 hold chunk fc = ch of the first 32
+    // columns, lanes ch >= 4 chunk fc = ch - 4 of the second 32: the chain runs through the first, then through the second
+    auto chain = [&](float dl, const u32x4_t a, const u32x4_t c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a0, a1, c0, c1;
+        unpack2o(a[i], a0, a1); unpack2o(c[i], c0, c1);
+        dl += a0 * c0;      // (the fused kernel's source form: with fp16 operands the compiler turns each pair into one v_dot2_f32_f16,
+        dl += a1 * c1;      //  which rounds once — an explicit fmaf chain differs in the last bit of 0.02 % of the dS values)
+      }
+      return dl;
+    };
+    // lane exchanges inside the 8-lane row group as DPP moves (a __shfl is a ds_bpermute round trip through the LDS queue: 27 of them
+    // per item made the loaders the critical path of the phase — 13 - 16 k cycles, profiles/r05_j_attn_merged.md)
+    auto dpp = [&](float v, auto ctrl) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    auto put_delta_lse = [&](int seq, int pn) {
+      int r0 = row0; asm volatile("" : "+v"(r0));
+      __builtin_amdgcn_s_setprio(2);                    // ~600 instructions against the compute waves' ~5 000 per phase: do not queue behind them
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const float p1 = chain(0.f, rg[k], ro[k]);
+        const float init = dpp(p1, std::integral_constant<int, 0x114>{});       // row_shr:4: lane ch takes lane ch - 4 (used by ch >= 4 only)
+        float t = chain(init, rg[k], ro[k]);
+        t += dpp(t, std::integral_constant<int, 0xB1>{});                       // quad_perm [1,0,3,2]: lane ^ 1
+        t += dpp(t, std::integral_constant<int, 0x4E>{});                       // quad_perm [2,3,0,1]: lane ^ 2
+        const int r = r0 + 24 * k;
+        if (ch == 4 && r < T) del_s[pn][r] = t;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      const int it = item_remap(seq, H, imap);
+      const float* lp = lse + (size_t)it * T;      // lse is [B][H][T] = [item][T]
+      if (li < T) lse_s[pn][li] = lp[li] * LOG2E;
+      if (li + 192 < T) lse_s[pn][li + 192] = lp[li + 192] * LOG2E;
+    };
+    auto deposit = [&]() {
+      int r0 = row0; asm volatile("" : "+v"(r0));
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const int r = min(r0 + 24 * k, T - 1);      // rows past T - 1 re-write row T - 1 with its own data
+        *reinterpret_cast<u32x4_t*>(Qs + lds_off(r, col)) = rq[k];
+        *reinterpret_cast<u32x4_t*>(Gs + lds_off(r, col)) = rg[k];
+      }
+    };
+    int seq = blockIdx.x, p = 0;
+    req_go(seq);
+    put_delta_lse(seq, 0);
+    asm volatile("" ::: "memory");
+    req_q(seq);
+    deposit();
+    wg_barrier_lds();                                   // the first item's Q / dO panels, lse and delta are in LDS
+    for (; seq < nitems; seq += gridDim.x, p ^= 1) {
+      const int nxt = (seq + (int)gridDim.x < nitems) ? seq + (int)gridDim.x : seq;
+      GSL_MSTAMP(0);
+      req_go(nxt);                                      // P1a
+      GSL_MSTAMP(1);
+      wg_barrier_lds();
+      GSL_MSTAMP(2);
+      GSL_MSTAMP(3);
+      wg_barrier_lds();                                 // P2a
+      GSL_MSTAMP(4);
+      put_delta_lse(nxt, p ^ 1);                        // P1b (the longest phase): delta, then the Q request once the o registers are dead
+      GSL_MSTAMP(5);
+      asm volatile("" ::: "memory");
+      req_q(nxt);
+      GSL_MSTAMP(6);
+      GSL_MSTAMP(7);
+      wg_barrier_lds();
+      GSL_MSTAMP(8);
+      deposit();                                        // P2b
+      GSL_MSTAMP(9);
+      wg_barrier_lds();
+      GSL_MSTAMP(10);
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- compute waves: key tile = wave
+  const float c2 = scale * LOG2E;
+  const int kr = wave * 16 + fr, krc = min(kr, T - 1);
+  const bool kvalid = kr < T;
+  Frag kf[2], vf[2];
+  auto load_keys = [&](int seq) {
+    const int it = item_remap(seq, H, imap), b = it / H, h = it % H;
+    const bf16_t* qb = qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)b * T * ld + h * HD);
+    const bf16_t* krow = qb + (size_t)krc * ldi + ko;
+    const bf16_t* vrow = qb + (size_t)krc * ldi + 2 * ko;
+    kf[0].v = gl_frag(krow, 0, fc); kf[1].v = gl_frag(krow, 1, fc);
+    vf[0].v = gl_frag(vrow, 0, fc); vf[1].v = gl_frag(vrow, 1, fc);
+  };
+  load_keys(blockIdx.x);
+  wg_barrier_lds();
+  int p = 0;
+  for (int seq = blockIdx.x; seq < nitems; seq += gridDim.x, p ^= 1) {
+    const int item = item_remap(seq, H, imap);
+    const int b = item / H, h = item % H;
+    if (kvalid) {                                       // the K panel of P2 (rows >= T stay zero)
+      *reinterpret_cast<uint4*>(Ks + lds_off(kr, fc * 8)) = kf[0].u;
+      *reinterpret_cast<uint4*>(Ks + lds_off(kr, 32 + fc * 8)) = kf[1].u;
+    }
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    // one pair of query tiles (the dK/dV phase of the fused kernel + the dS deposit); qc0 = column of the pair's first query in Ds
+    auto pair_step = [&](int qp, int qc0, auto only_first) {
+      constexpr bool ONE = decltype(only_first)::value;
+      Frag pf, dsf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * qp + half;
+        if (ONE && half == 1) {
+          pf.u.z = 0u; pf.u.w = 0u; dsf.u.z = 0u; dsf.u.w = 0u;
+          continue;
+        }
+        const bf16x8_t q0 = lds_frag_rm(Qs, qt * 16 + fr, 0, fc), q1 = lds_frag_rm(Qs, qt * 16 + fr, 1, fc);
+        const bf16x8_t g0 = lds_frag_rm(Gs, qt * 16 + fr, 0, fc), g1 = lds_frag_rm(Gs, qt * 16 + fr, 1, fc);
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[p][qt * 16 + fc * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&del_s[p][qt * 16 + fc * 4]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sa = mfma16(q0, kf[0].v, sa);
+        sa = mfma16(q1, kf[1].v, sa);
+        dp = mfma16(g0, vf[0].v, dp);
+        dp = mfma16(g1, vf[1].v, dp);
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -lv[r]));
+          ds[r] = pr[r] * (dp[r] - dv[r]);
+        }
+        uint2 w;
+        if (half == 0) {
+          pf.u.x = pack2o(pr[0], pr[1]); pf.u.y = pack2o(pr[2], pr[3]);
+          dsf.u.x = pack2o(ds[0], ds[1]); dsf.u.y = pack2o(ds[2], ds[3]);
+          w = make_uint2(dsf.u.x, dsf.u.y);
+        } else {
+          pf.u.z = pack2o(pr[0], pr[1]); pf.u.w = pack2o(pr[2], pr[3]);
+          dsf.u.z = pack2o(ds[0], ds[1]); dsf.u.w = pack2o(ds[2], ds[3]);
+          w = make_uint2(dsf.u.z, dsf.u.w);
+        }
+        if (!kvalid) w = make_uint2(0u, 0u);            // a key past T contributes nothing to dQ (the fused kernel masks p there)
+        *reinterpret_cast<uint2*>(Ds + kr * DSLD + qc0 + half * 16 + fc * 4) = w;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8_t ot = lds_frag_trr_g<KLD, ONE>(Gs, dt, qp, lane), qtf = lds_frag_trr_g<KLD, ONE>(Qs, dt, qp, lane);
+        adv[dt] = mfma16(ot, pf.v, adv[dt]);
+        adk[dt] = mfma16(qtf, dsf.v, adk[dt]);
+      }
+    };
+    // dQ of query tile qt (tile qtl of the half in Ds): the dQ phase of the fused kernel with dS read back from LDS; the tile leaves as
+    // full rows through the wave-private staging area stg (row stride SLD)
+    auto dq_tile = [&](int qt, int qtl, bf16_t* stg, auto sld) {
+      f32x4_t acc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NP - 1; ++pr) {
+        const bf16x8_t bq = lds_frag_trr_g<DSLD, false>(Ds, qtl, pr, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(lds_frag_trr_g<KLD, false>(Ks, dt, pr, lane), bq, acc[dt]);
+      }
+      {
+        const bf16x8_t bq = lds_frag_trr_g<DSLD, true>(Ds, qtl, NP - 1, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(lds_frag_trr_g<KLD, true>(Ks, dt, NP - 1, lane), bq, acc[dt]);
+      }
+      store_tile_rows<decltype(sld)::value>(stg, acc, scale, dqkv + ((size_t)b * T + qt * 16) * ld + h * HD, ld, min(16, T - qt * 16), lane);
+    };
+    // ---- P1a
+    GSL_MSTAMP(0);
+#pragma unroll 1
+    for (int qp = 0; qp < NPA; ++qp) pair_step(qp, qp * 32, std::false_type{});
+    GSL_MSTAMP(1);
+    wg_barrier_lds();
+    GSL_MSTAMP(2);
+    // ---- P2a
+    if (wave < NPA * 2) dq_tile(wave, wave, Qs + lds_off(wave * 16, 0), std::integral_constant<int, KLD>{});      // (the Q panel is dead until the loaders' deposit in P2b)
+    GSL_MSTAMP(3);
+    wg_barrier_lds();
+    GSL_MSTAMP(4);
+    // ---- P1b
+#pragma unroll 1
+    for (int qp = NPA; qp < NP - 1; ++qp) pair_step(qp, (qp - NPA) * 32, std::false_type{});
+    GSL_MSTAMP(5);
+    pair_step(NP - 1, (NP - 1 - NPA) * 32, std::true_type{});
+    GSL_MSTAMP(6);
+    {       // dK / dV leave as full rows through columns 80 .. 143 of the wave's own Ds rows (dead since P2a; P2b reads columns 0 .. 79)
+      bf16_t* stg = Ds + wave * 16 * DSLD + 80;
+      bf16_t* gk = dqkv + ((size_t)b * T + wave * 16) * ld + h * HD + H * HD;
+      const int nv = min(16, T - wave * 16);
+      store_tile_rows<DSLD>(stg, adk, scale, gk, ld, nv, lane);
+      store_tile_rows<DSLD>(stg, adv, 1.0f, gk + H * HD, ld, nv, lane);
+    }
+    load_keys((seq + (int)gridDim.x < nitems) ? seq + (int)gridDim.x : seq);      // the next item's K / V fragments land under P2b
+    GSL_MSTAMP(7);
+    wg_barrier_lds();
+    GSL_MSTAMP(8);
+    // ---- P2b
+    if (wave < NCW - NPA * 2) dq_tile(NPA * 2 + wave, wave, Ds + wave * 16 * DSLD + 80, std::integral_constant<int, DSLD>{});      // (columns 80 .. 143 of Ds are unused in the second half)
+    GSL_MSTAMP(9);
+    wg_barrier_lds();
+    GSL_MSTAMP(10);
+  }
+}
+#undef GSL_MSTAMP
+
+// =====================================================================================
 // f32 parity kernels (matrix cores, round 4; the thread-per-row VALU kernels of rounds 1 - 3 are gone)
 // =====================================================================================
 // f32 forward on the matrix cores (round 4: the engines evaluate in f32 by default, and the thread-per-query kernel this replaces —
@@ -1377,6 +1701,10 @@ extern "C" int GSL_ENTRY(gsl_attention_bwd)(const void* qkv, const void* o, cons
       // (a persistent wave-specialised form like the forward's was measured slower here: 795 vs 736 us at B = 1024 — its four
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       unsigned long long* stp = attn_stamps();
+      // round 5: every score tile computed once (attn_bwd_merged_kernel; bit-identical to the fused kernel, GSL_ATTN_BWD_MERGED=0 in the dev build)
+      if (T > 192 && T <= 208 && B * H >= 2 * attn_num_cus() && attn_env("GSL_ATTN_BWD_MERGED", 1))
+        hipLaunchKernelGGL((attn_bwd_merged_kernel<14>), dim3(attn_num_cus()), dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, B * H, hm, (attn_num_cus() % 8 == 0) ? imap : 0, stp, attn_env("GSL_ATTN_STAGGER", 0));
+      else
       if (B * H < attn_num_cus()) {      // fewer items than CUs: sixteen waves per item
         if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);
         else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, false, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);

@@ -350,6 +350,34 @@ def test_attention_bwd_fused_bit_identical_to_two_kernel_form(ops, B, T, H, monk
     assert torch.equal(fused, split)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,H,hm", [(70, 197, 8, 0), (67, 197, 8, 1), (64, 208, 8, 0), (128, 193, 4, 1), (43, 197, 12, 1), (72, 200, 8, 0)])
+def test_attention_bwd_merged_bit_identical_to_fused_kernel(ops, dt, B, T, H, hm, monkeypatch):
+    """16-bit, 192 < T <= 208, at least two items per CU: the merged backward (every score tile computed once by the wave that owns its
+    key tile, dS parked in LDS for the dQ products, loader waves one item ahead) must reproduce the fused two-phase kernel bit for bit:
+    same MFMA operands in the same order, delta accumulated in the same order. Ragged last round of items (B*H not a multiple of the
+    CU count), batch sizes with and without the XCD item remap, both input layouts, and against the fp32 torch reference."""
+    scale = 64 ** -0.5
+    qkv32 = rnd(B * T, 3 * H * 64, seed=41, scale=1.3)
+    qkv = qkv32.cuda().to(dt)
+    qin = _to_head_major(qkv, B, T, H) if hm else qkv
+    o, lse = ops.attention_fwd(qin, B, T, H, scale, layout=hm)
+    d_o32 = rnd(B * T, H * 64, seed=42)
+    d_o = d_o32.cuda().to(dt)
+    merged = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
+    again = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_ATTN_BWD_MERGED", "0")      # a knob of the development build only
+    with L.use_dev():
+        fused = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
+    assert torch.equal(merged, again)
+    assert torch.equal(merged, fused)
+    q = as_dt(qkv32, dt).requires_grad_(True)
+    attn_ref(q, B, T, H, scale).backward(as_dt(d_o32, dt))
+    err = (merged.float().cpu() - q.grad).abs().max().item()
+    assert err < 3e-2 * max(1.0, q.grad.abs().max().item()), err
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_layernorm_bwd_strided_inplace(ops, dt):
     """cls-row form: x / dres / dx rows are T*D apart, dy and the masked copy are compact."""
