@@ -251,6 +251,25 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void attn_fwd_bf16_kernel(
 // The loader waves hold up to 72 VGPRs of in-flight data, the compute waves none: the two roles share one register budget (128).
 // Barriers are raw s_barrier + lgkmcnt waits: a __syncthreads() would also drain the loaders' outstanding global loads (vmcnt).
 // =====================================================================================
+// A 16 x 64 tile held in C layout (lane (fr, fc): row fr, columns dt * 16 + 4 fc .. + 3 of acc[dt]) leaves as FULL 128-byte rows: through a
+// wave-private LDS area (row stride LD elements), then 16 bytes per lane, 8 lanes per row, 2 store instructions per tile. The fragment-
+// layout store (store4bf: 8 bytes per lane, 16 rows x 32 bytes per instruction, 4 instructions per tile) costs ~115 cycles of the CU's
+// vector-memory pipe per instruction: 156 of them per item kept that pipe busy for ~18 k cycles and every load queued behind them
+// (profiles/r05_j_attn_merged.md). Same values (v * mul rounded once), rows >= nvalid are not written.
+template <int LD>
+__device__ __forceinline__ void store_tile_rows(bf16_t* stage, const f32x4_t (&acc)[4], float mul, bf16_t* gbase, long gld, int nvalid, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    *reinterpret_cast<uint2*>(stage + fr * LD + dt * 16 + fc * 4) =
+        make_uint2(pack2o(acc[dt][0] * mul, acc[dt][1] * mul), pack2o(acc[dt][2] * mul, acc[dt][3] * mul));
+  const int r = lane >> 3, c = lane & 7;
+  const uint4 v0 = *reinterpret_cast<const uint4*>(stage + r * LD + c * 8);
+  const uint4 v1 = *reinterpret_cast<const uint4*>(stage + (r + 8) * LD + c * 8);
+  if (r < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)r * gld + c * 8) = v0;
+  if (r + 8 < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)(r + 8) * gld + c * 8) = v1;
+}
+
 __device__ __forceinline__ void wg_barrier_lds() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -270,6 +289,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
   __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[TP * KLD];
+  constexpr int OLD = 72;                 // row stride of the output staging tiles (144 B)
+  __shared__ __attribute__((aligned(16))) bf16_t Os[NCW * 16 * OLD];      // one 16 x 64 tile per compute wave: outputs leave as full rows (store_tile_rows)
   const long ld = hm ? (long)HD : 3L * H * HD, ko = hm ? (long)T * HD : (long)H * HD;      // row stride / K-panel offset of the qkv input
   auto item_base = [&](int seq) { const int it = item_remap(seq, H, imap); return qkv + (hm ? (size_t)it * 3 * T * HD : (size_t)(it / H) * T * ld + (it % H) * HD); };
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fc = lane >> 4;
@@ -379,13 +400,16 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
     }
     const float inv = 1.0f / l;
     wg_barrier_lds();                                   // V(item) is in LDS; Q / K panels may be overwritten from here on
+    f32x4_t acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int pr = 0; pr < NKT / 2; ++pr) acc = mfma16(lds_frag_trr(Vs, dt, pr, lane), pf[pr].v, acc);
-      if (qr < T) store4bf(o + ((size_t)b * T + qr) * (H * HD) + h * HD + dt * 16 + fc * 4, acc, inv);
+      for (int pr = 0; pr < NKT / 2; ++pr) acc[dt] = mfma16(lds_frag_trr(Vs, dt, pr, lane), pf[pr].v, acc[dt]);
     }
+    // (round 5: 2 full-row store instructions per tile instead of 4 fragment-layout ones; `inv` is per ROW of the tile = per lane column fr here:
+    //  the scaling happens before the staging, in the accumulator layout, exactly as store4bf did)
+    store_tile_rows<OLD>(Os + wave * 16 * OLD, acc, inv, o + ((size_t)b * T + wave * 16) * (H * HD) + h * HD, (long)H * HD, min(16, T - wave * 16), lane);
     if (fc == 0 && qr < T) lse[((size_t)b * H + h) * T + qr] = m * scale + __logf(l);
     wg_barrier_lds();                                   // Q, K of the next item are in LDS; V may be overwritten
   }
@@ -865,25 +889,6 @@ __device__ __forceinline__ bf16x8_t lds_frag_trr_g(const bf16_t* base, int dt, i
   if constexpr (HALF) f.h[1] = v4s_t{0, 0, 0, 0};
   else f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(base + (row + 16) * LD + col));
   return f.v;
-}
-
-// A 16 x 64 tile held in C layout (lane (fr, fc): row fr, columns dt * 16 + 4 fc .. + 3 of acc[dt]) leaves as FULL 128-byte rows: through a
-// wave-private LDS area (row stride LD elements), then 16 bytes per lane, 8 lanes per row, 2 store instructions per tile. The fragment-
-// layout store (store4bf: 8 bytes per lane, 16 rows x 32 bytes per instruction, 4 instructions per tile) costs ~115 cycles of the CU's
-// vector-memory pipe per instruction: 156 of them per item kept that pipe busy for ~18 k cycles and every load queued behind them
-// (profiles/r05_j_attn_merged.md). Same values (v * mul rounded once), rows >= nvalid are not written.
-template <int LD>
-__device__ __forceinline__ void store_tile_rows(bf16_t* stage, const f32x4_t (&acc)[4], float mul, bf16_t* gbase, long gld, int nvalid, int lane) {
-  const int fr = lane & 15, fc = lane >> 4;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-    *reinterpret_cast<uint2*>(stage + fr * LD + dt * 16 + fc * 4) =
-        make_uint2(pack2o(acc[dt][0] * mul, acc[dt][1] * mul), pack2o(acc[dt][2] * mul, acc[dt][3] * mul));
-  const int r = lane >> 3, c = lane & 7;
-  const uint4 v0 = *reinterpret_cast<const uint4*>(stage + r * LD + c * 8);
-  const uint4 v1 = *reinterpret_cast<const uint4*>(stage + (r + 8) * LD + c * 8);
-  if (r < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)r * gld + c * 8) = v0;
-  if (r + 8 < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)(r + 8) * gld + c * 8) = v1;
 }
 
 template <int NKT>      // (NKT - 2) * 16 < T <= (NKT - 1) * 16: T = 197 with NKT = 14
