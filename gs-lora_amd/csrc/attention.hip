@@ -907,12 +907,16 @@ __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __r
   constexpr int NP = NKT / 2;             // query pairs (7); the last one holds a single tile
   constexpr int NPA = 4;                  // pairs of the first half: queries 0 .. 127 = dQ tiles 0 .. 7
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[TP * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Gs[TP * KLD];      // dO
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[TP * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Ds[TP * DSLD];     // dS [key][query of the half]
-  __shared__ __attribute__((aligned(16))) float lse_s[2][TP];       // log2 units; padded queries 1e30 -> p = 0
-  __shared__ __attribute__((aligned(16))) float del_s[2][TP];
+  // ONE array in a fixed order: what a phase touches together sits within the 16-bit immediate offset of a DS instruction from one per-lane
+  // base register (Q | dO | lse | delta for P1, Ds | K for P2). As separate arrays the linker's order put the panels > 64 KB apart and every
+  // pair step re-derived its addresses with 20 v_add_u32 (of 56 VALU instructions); now 10.
+  __shared__ __attribute__((aligned(16))) bf16_t smem[3 * TP * KLD + TP * DSLD + 8 * TP];
+  bf16_t* const Qs = smem;                                           // [TP][KLD]
+  bf16_t* const Gs = Qs + TP * KLD;                                  // dO
+  float (*const lse_s)[TP] = reinterpret_cast<float (*)[TP]>(Gs + TP * KLD);      // [2][TP], log2 units; padded queries 1e30 -> p = 0
+  float (*const del_s)[TP] = lse_s + 2;                              // [2][TP]
+  bf16_t* const Ds = reinterpret_cast<bf16_t*>(del_s + 2);           // dS [key][query of the half], [TP][DSLD]
+  bf16_t* const Ks = Ds + TP * DSLD;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   const long ld = 3L * H * HD, ldo = (long)H * HD;
   const long ldi = hm ? (long)HD : ld, ko = hm ? (long)T * HD : (long)H * HD;      // qkv INPUT: row stride, K-panel offset (V at 2 ko)
