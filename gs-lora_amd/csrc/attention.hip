@@ -895,7 +895,7 @@ template <int NKT>      // (NKT - 2) * 16 < T <= (NKT - 1) * 16: T = 197 with NK
 __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale, int nitems, int hm, int imap,
-                                                               unsigned long long* __restrict__ stamps, int stagger) {
+                                                               unsigned long long* __restrict__ stamps) {
   GSL_OP16_KERNEL_ENTRY();
   // development (GSL_ATTN_STAMPS = device address of 2048 u64): cycle stamps of the THIRD item of every 32nd workgroup, 16 slots per wave:
   // item start | P1a | barrier | P2a | barrier | P1b pairs | P1b last pair | stores + next keys issued | barrier | P2b | barrier
@@ -933,9 +933,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __r
     lse_s[0][T + threadIdx.x] = 1.0e30f; lse_s[1][T + threadIdx.x] = 1.0e30f;
     del_s[0][T + threadIdx.x] = 0.f; del_s[1][T + threadIdx.x] = 0.f;
   }
-  // Stagger (A/B, dev knob): every CU runs the same phases on the same clock, so the chip's HBM traffic comes in bursts (all dK / dV stores
-  // and all next-item loads inside one third of the item). Workgroups start a quarter of an item apart in four groups.
-  if (stagger > 0) for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * stagger; ++i) __builtin_amdgcn_s_sleep(64);
   if (wave >= NCW) {
     // ------------------------------------------------------------------ loader waves (see attn_fwd_bf16_pers_kernel for the register rules)
     const int li = (wave - NCW) * 64 + lane, col = (li & 7) * 8, row0 = li >> 3, ch = li & 7;
@@ -1636,7 +1633,8 @@ extern "C" int GSL_ENTRY(gsl_attention_bwd_cls)(const void* qkv, const void* q_c
 
 // Development knobs (libgslora_hip_dev.so only; the product library reads nothing from the environment):
 //   GSL_ATTN_PERSISTENT=0 one item per workgroup; GSL_ATTN_ABL=1 staging only, 2 no staging; GSL_ATTN_BWD_SPLIT=1 the two-kernel backward;
-//   GSL_ATTN_NT key tiles per wave of the dK/dV kernel; GSL_ATTN_STAMPS device address of a cycle-stamp buffer.
+//   GSL_ATTN_NT key tiles per wave of the dK/dV kernel; GSL_ATTN_STAMPS device address of a cycle-stamp buffer;
+//   GSL_ATTN_BWD_MERGED=0 the fused two-phase backward instead of the merged one, GSL_ATTN_BWD_MERGED_MIN items per CU from which the merged one runs.
 #ifdef GSL_DEV
 static inline int attn_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline unsigned long long* attn_stamps() { const char* sp = getenv("GSL_ATTN_STAMPS"); return sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr; }
@@ -1711,8 +1709,10 @@ extern "C" int GSL_ENTRY(gsl_attention_bwd)(const void* qkv, const void* o, cons
       //  workgroup-wide barriers per item cost more than the hidden staging saves; profiles/r01_gemm_ab.md)
       unsigned long long* stp = attn_stamps();
       // round 5: every score tile computed once (attn_bwd_merged_kernel; bit-identical to the fused kernel, GSL_ATTN_BWD_MERGED=0 in the dev build)
-      if (T > 192 && T <= 208 && B * H >= 2 * attn_num_cus() && attn_env("GSL_ATTN_BWD_MERGED", 1))
-        hipLaunchKernelGGL((attn_bwd_merged_kernel<14>), dim3(attn_num_cus()), dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, B * H, hm, (attn_num_cus() % 8 == 0) ? imap : 0, stp, attn_env("GSL_ATTN_STAGGER", 0));
+      // (from 8 items per CU: a persistent workgroup pays its prologue and a ragged last round — at 4.5 items per CU, ViT-B/16 48 + 48 x 12
+      //  heads, the fused kernel is 4 % faster per launch: profiles/r05_notes.md)
+      if (T > 192 && T <= 208 && B * H >= attn_env("GSL_ATTN_BWD_MERGED_MIN", 8) * attn_num_cus() && attn_env("GSL_ATTN_BWD_MERGED", 1))
+        hipLaunchKernelGGL((attn_bwd_merged_kernel<14>), dim3(attn_num_cus()), dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, B * H, hm, (attn_num_cus() % 8 == 0) ? imap : 0, stp);
       else
       if (B * H < attn_num_cus()) {      // fewer items than CUs: sixteen waves per item
         if (T > 192 && T <= 208) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<14, true, 1024>), grid, dim3(1024), 0, st, q, oo, g, lse, dq, T, H, scale, stp, hm, imap);

@@ -364,10 +364,13 @@ def test_attention_bwd_merged_bit_identical_to_fused_kernel(ops, dt, B, T, H, hm
     o, lse = ops.attention_fwd(qin, B, T, H, scale, layout=hm)
     d_o32 = rnd(B * T, H * 64, seed=42)
     d_o = d_o32.cuda().to(dt)
-    merged = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
-    again = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
     from gslora_hip import _lib as L
-    monkeypatch.setenv("GSL_ATTN_BWD_MERGED", "0")      # a knob of the development build only
+    # (the product library takes the merged kernel from 8 items per CU; the development build's knob lowers that to 2 for these sizes)
+    monkeypatch.setenv("GSL_ATTN_BWD_MERGED_MIN", "2")
+    with L.use_dev():
+        merged = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
+        again = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
+    monkeypatch.setenv("GSL_ATTN_BWD_MERGED", "0")
     with L.use_dev():
         fused = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=hm)
     assert torch.equal(merged, again)
@@ -376,6 +379,24 @@ def test_attention_bwd_merged_bit_identical_to_fused_kernel(ops, dt, B, T, H, hm
     attn_ref(q, B, T, H, scale).backward(as_dt(d_o32, dt))
     err = (merged.float().cpu() - q.grad).abs().max().item()
     assert err < 3e-2 * max(1.0, q.grad.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_attention_bwd_product_library_at_step_size_equals_fused_kernel(ops, dt, monkeypatch):
+    """The PRODUCT library at a batch that takes the merged kernel there (8 items per CU: 264 images x 8 heads), head-major input as in the step,
+    against the development build's fused kernel: bit-identical."""
+    B, T, H = 264, 197, 8
+    scale = 64 ** -0.5
+    qkv = rnd(B * T, 3 * H * 64, seed=51, scale=1.2).cuda().to(dt)
+    qin = _to_head_major(qkv, B, T, H)
+    o, lse = ops.attention_fwd(qin, B, T, H, scale, layout=1)
+    d_o = rnd(B * T, H * 64, seed=52).cuda().to(dt)
+    prod = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=1)
+    from gslora_hip import _lib as L
+    monkeypatch.setenv("GSL_ATTN_BWD_MERGED", "0")      # a knob of the development build only
+    with L.use_dev():
+        fused = ops.attention_bwd(qin, o, d_o, lse, B, T, H, scale, layout=1)
+    assert torch.equal(prod, fused)
 
 
 @pytest.mark.parametrize("dt", DTS)
