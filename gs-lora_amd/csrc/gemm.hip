@@ -488,7 +488,7 @@ template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {      /
   }
 }
 // global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
-struct GfOperands { uint4 ax[4], hx[4], u1a, u1b; };
+struct GfOperands { uint4 ax[4], hx[4], u1; };
 template <bool G8>
 __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int mw, int nw, int ic, int lane) {
   const int crow = lane >> 3, cch = lane & 7;
@@ -508,9 +508,10 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
     }
     g.hx[r] = gf_ld<uint4>(e.gy2 + (size_t)m * e.ldo + ncl);
   }
-  const bf16_t* up = e.gu1 + (size_t)min(mw + ic * 32 + (lane & 31), e.M - 1) * e.ldgu1;
-  g.u1a = *reinterpret_cast<const uint4*>(up);
-  g.u1b = *reinterpret_cast<const uint4*>(up + 8);
+  // U1: 32 rows x 16 columns per round as ONE instruction (lane l: row l / 2, columns 8 (l % 2) ..): every vector-memory instruction
+  // costs the CU's in-order memory pipe time in proportion to the lines it touches (profiles/r05_j_attn_merged.md); two instructions with
+  // lanes 32..63 duplicating lanes 0..31 touched the same 32 lines twice (FFN2-dX 0.814 -> 0.80 ms; with a compact [M, 16] U1: 0.79)
+  g.u1 = *reinterpret_cast<const uint4*>(e.gu1 + (size_t)min(mw + ic * 32 + (lane >> 1), e.M - 1) * e.ldgu1 + (lane & 1) * 8);
 }
 // go: the operands of round 0, requested by the caller (right after the K loop, in front of the rank-r tail)
 template <int NI, bool G8>
@@ -543,7 +544,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
     GfOperands& op = (ic & 1) ? gob : go;      // (the loop is fully unrolled: a compile-time choice)
     uint4 (&ax)[4] = op.ax;
     uint4 (&hx)[4] = op.hx;
-    uint4 &u1a = op.u1a, &u1b = op.u1b;
+    uint4 &u1 = op.u1;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -583,10 +584,9 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       // not where it was requested, so that no wait for the loads sits in front of the staging above
       *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = (m < e.M) ? hx[r] : make_uint4(0u, 0u, 0u, 0u);
     }
-    if (lane < 32) {
-      const bool in = mw + ic * 32 + lane < e.M;
-      *reinterpret_cast<uint4*>(ub + lane * 16) = in ? u1a : make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4*>(ub + lane * 16 + 8) = in ? u1b : make_uint4(0u, 0u, 0u, 0u);
+    {
+      const bool in = mw + ic * 32 + (lane >> 1) < e.M;
+      *reinterpret_cast<uint4*>(ub + lane * 8) = in ? u1 : make_uint4(0u, 0u, 0u, 0u);      // row lane / 2, half lane % 2: 16 bytes per lane, contiguous
     }
     asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
     // this round's set is consumed: refill it for the round that uses it next
@@ -1209,6 +1209,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring3_kernel(const bf16_t* __re
       }
     }
   }
+  if constexpr (EPI == GSL_EPI_STORE) {
+    // STORE with out2: a COMPACT [M, 16] copy (row stride 16) of output columns 0 .. 15 — the LoRA down-projection u1 is a [M, 64] K segment
+    // for the forward GEMM and a 16-column operand for the gradient-fused FFN2-dX epilogue, which then reads 32 contiguous rows with one
+    // 1 KB instruction instead of 32 rows x 32 B of 128-byte lines (FFN2-dX 0.80 -> 0.78 ms). A lane's 4 columns of 16 rows: 512 contiguous bytes.
+    if (e.out2 && n0 == 0 && wn == 0) {
+      bf16_t* o2 = reinterpret_cast<bf16_t*>(e.out2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const f32x4_t v = acc[i][0] * e.alpha;
+        if (m < e.M) *reinterpret_cast<uint2*>(o2 + (size_t)m * 16 + fc * 4) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
+      }
+    }
+  }
   if constexpr (!epi_out_is_f32<EPI>()) {
     static_assert(3 * ST3 >= CST_BLOCK8, "C staging must fit in the stage ring");
     if (ABL == 0 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && (EPI != GSL_EPI_BIAS_GELU_G8 || ((e.N % 16) == 0 && (e.ldo % 16) == 0))) {
@@ -1817,6 +1831,7 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
     // up to ~256 tiles of 128x128 (one per CU) leave CUs idle and serialise the K loop: 64x64 tiles with a 4-stage ring (12). Measured at
     // M = 1 576 (tools/probes/small_m_gemm.py, profiles/r03_c_small_m.md).
     if (variant == 1 && (long)nblk <= 256) variant = 12;
+    if (EPI == GSL_EPI_STORE && e.out2) variant = 3;      // the compact second output lives on the ring kernel (checked by the caller: N <= 128, no bias)
 #define GSL_LAUNCH(KERNEL, NB, NT) hipLaunchKernelGGL(KERNEL, dim3(NB), dim3(NT), 0, st, (const bf16_t*)A1, lda1, (const bf16_t*)W1, \
                                                       ldw1, K1, (const bf16_t*)A2, lda2, (const bf16_t*)W2, ldw2, K2, e)
 #ifdef GSL_DEV
@@ -1981,7 +1996,9 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
   e.hmT = 0; e.hmH = 0;
   hipStream_t st = as_stream(s);
   switch (epilogue) {
-    case GSL_EPI_STORE: return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_STORE:
+      if (out2) GSL_CHECK_ARG(dtype != GSL_F32 && N >= 16 && N <= 128 && !bias, "STORE with out2 (compact [M,16] copy of columns 0..15): 16-bit operands, 16 <= N <= 128, no bias");
+      return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_F32: return launch_gemm<GSL_EPI_STORE_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
       GSL_CHECK_ARG(dtype == GSL_OP16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");

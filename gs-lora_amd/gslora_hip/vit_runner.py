@@ -443,7 +443,7 @@ class ViTRunner:
             if lora_on and (abs(l1.scaling * r - 1.0) > 1e-9 or abs(l2.scaling * r - 1.0) > 1e-9):
                 raise NotImplementedError("gs-lora_amd: the fused LoRA path uses scaling = 1 / r (lora_alpha = 1, the only value GS-LoRA "
                                           f"passes); got scaling {l1.scaling} / {l2.scaling} for r = {r}")
-            u1 = u2 = None
+            u1 = u2 = u1c = None
             h = torch.empty(Mr, mlp, device=img.device, dtype=dt)
             gp8 = GP8 and dt in OP16 and save and mlp % 64 == 0
             epi_gelu = L.EPI_BIAS_GELU_G8 if gp8 else L.EPI_BIAS_GELU
@@ -461,7 +461,10 @@ class ViTRunner:
                         u1 = u1_ln
                     else:
                         u1 = torch.empty(Mr, PADK, device=img.device, dtype=dt)
-                        ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora)
+                        # (16-bit modes: the GEMM also writes u1's first 16 columns as a compact [M, 16] tensor — the operand form the
+                        #  gradient-fused FFN2-dX epilogue reads 32 rows of with one contiguous 1 KB load; rank <= 16)
+                        u1c = torch.empty(Mr, 16, device=img.device, dtype=dt) if (save and dt in OP16 and r <= 16 and Mr >= INK_MIN_ROWS) else None
+                        ops.gemm_nt(xn2, self.lora_pack(f"A1_{i}", l1.lora_A, "A_rows", dt), u1, alpha=s_lora, out2=u1c)
                     ops.gemm_nt(xn2, self.w(f"w1_{i}", l1.weight, dt), h, epilogue=epi_gelu, A2=u1,
                                 W2=self.lora_pack(f"B1_{i}", l1.lora_B, "B_cols", dt), bias=l1.bias.detach(), out2=gp,
                                 p_drop=p_drop, seed=seed, site=(4 * i + 1) | sflag, tag="ffn1")
@@ -482,7 +485,7 @@ class ViTRunner:
                             bias=l2.bias.detach(), res=x1, p_drop=p_drop, seed=seed, site=(4 * i + 2) | sflag)
             if save:
                 stash.append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, qkv_hm=hm, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2,
-                                  xn2=xn2, u1=u1, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq, tail=tail, q_cls=q_cls))
+                                  xn2=xn2, u1=u1, u1c=u1c, h=h, gp=gp, u2=u2, lora_on=lora_on, xn=xn_keep, uq=uq, tail=tail, q_cls=q_cls))
             x = x2
         hn = sp.final_ln
         Th = x.shape[0] // B      # rows per image of the stream that reaches the head: T, or 1 after a cls-row-only last block
@@ -572,6 +575,7 @@ class ViTRunner:
                                            cls_rows(st["u1"], PADK), cls_rows(st["u2"], PADK))
             else:
                 dyb, xn2, h, gp, u1, u2 = dxb, st["xn2"], st["h"], st["gp"], st["u1"], st["u2"]
+            u1c = None if (sparse and not tail) else st.get("u1c")      # the compact [M, 16] form of u1 (16-bit modes, full-size blocks)
             Mrows = dyb.shape[0]
             # ---- FFN sub-layer: y = x1 + drop(W2' h + b2), h = drop(gelu(W1' xn2 + b1)) -------------
             ink = self.lora_in_kernel(dt, Mrows, mlp)       # FFN2-dX (N = mlp)
@@ -585,7 +589,7 @@ class ViTRunner:
                 # [M, mlp] tiles (dB1 from the da it produces, dA2 from h and the v2 it holds) ride in its epilogue
                 ops.gemm_nt_lora_mulgrad(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),
                                          self.lora_pack(f"A2_{i}", l2.lora_A, "AT_cols32", dt), s_lora, v2, da, gp,
-                                         u1, gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx", p_drop=p_drop,
+                                         (u1c if u1c is not None else u1), gv[id(l1.lora_B)], (r, 1), h, gv[id(l2.lora_A)], (1, mlp), r, tag="ffn2dx", p_drop=p_drop,
                                          gscale=gscale)
             elif ink:    # v2 = s*dy*B2 is produced inside the dX GEMM
                 ops.gemm_nt_lora(dyb, self.wT(f"w2_{i}", l2.weight, dt), self.lora_pack(f"B2_{i}", l2.lora_B, "BT_rows16", dt),

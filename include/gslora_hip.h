@@ -46,7 +46,9 @@ enum gsl_status {
 
 /* GEMM epilogues (gsl_gemm_nt). acc = alpha * (A1*W1^T + A2*W2^T)  */
 enum gsl_epilogue {
-  GSL_EPI_STORE = 0,        /* out[dtype]  = acc (+ bias)                                       */
+  GSL_EPI_STORE = 0,        /* out[dtype]  = acc (+ bias); out2 (nullable; 16-bit operands, 16 <= N <= 128, no bias): a COMPACT [M,16] copy
+                               (row stride 16) of output columns 0..15 — the 16-column operand form of a LoRA down-projection for
+                               gsl_gemm_nt_lora_mulgrad's U1 (32 rows = one contiguous 1 KB read)                                   */
   GSL_EPI_BIAS_RES_F32 = 1, /* outf32      = dropout(acc + bias) + res                          */
   GSL_EPI_BIAS_GELU = 2,    /* out[dtype]  = dropout(gelu(acc+bias)); out2[dtype] = gelu'(acc+bias)*dropmask */
   GSL_EPI_MUL = 3,          /* out[dtype]  = acc * aux[dtype]                                   */

@@ -382,6 +382,33 @@ def test_attention_bwd_merged_bit_identical_to_fused_kernel(ops, dt, B, T, H, hm
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [9000, 1000, 300])
+def test_gemm_store_compact_second_output(ops, dt, M):
+    """EPI_STORE with out2: a compact [M, 16] copy of output columns 0..15 (the operand form of the LoRA down-projection u1 that the
+    gradient-fused FFN2-dX epilogue reads as contiguous 1 KB pieces): bit-identical to the primary output's columns at every M (the call
+    is routed to the ring kernel whatever the row count), and rejected where it is not defined."""
+    from gslora_hip import _lib as L
+    K, N = 512, 64
+    A = rnd(M, K, seed=3).cuda().to(dt)
+    W = (rnd(N, K, seed=4) * 0.05).cuda().to(dt)
+    W[8:] = 0                                   # rank 8 zero-padded, as lora_pack("A_rows") delivers it
+    out = torch.zeros(M, N, device="cuda", dtype=dt)
+    out2 = torch.full((M, 16), 7.0, device="cuda", dtype=dt)
+    ref = torch.zeros(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A, W, ref, alpha=0.125)
+    ops.gemm_nt(A, W, out, alpha=0.125, out2=out2)
+    assert torch.equal(out, ref)
+    assert torch.equal(out2, ref[:, :16])
+    exp = (A.float() @ W.float().t()) * 0.125
+    assert (out2.float() - exp[:, :16]).abs().max() < 2e-2 * max(1.0, exp.abs().max().item())
+    Wb = torch.zeros(256, K, device="cuda", dtype=dt)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A, Wb, torch.zeros(M, 256, device="cuda", dtype=dt), out2=out2)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A, W, out, bias=torch.zeros(N, device="cuda"), out2=out2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_attention_bwd_product_library_at_step_size_equals_fused_kernel(ops, dt, monkeypatch):
     """The PRODUCT library at a batch that takes the merged kernel there (8 items per CU: 264 images x 8 heads), head-major input as in the step,
     against the development build's fused kernel: bit-identical."""
