@@ -243,6 +243,11 @@ template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false>
 __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
                                                           const float* bias_lds, uint32_t tab_lds = 0u) {
   static_assert(!TAB || EPI == GSL_EPI_BIAS_GELU_G8, "the GELU table serves the 8-bit-code epilogue");
+  // A dropped element's table entry is GT_DROPPED = 0x0000001A: the code byte of g' = 0 and, read as a float, a DENORMAL. From here to the end of
+  // the wave f32 denormals are flushed (MODE.FP_DENORM[5:4] = 0), so the product (a * scale) * entry is EXACTLY +-0 for every finite a — without
+  // the flush it was a ~3.6e-44 denormal times a: +-0 after the 16-bit rounding for |a| < ~1e3 only — and NaN for a = +-Inf / NaN
+  // (torch: Inf * 0). No per-element instruction.
+  if constexpr (TAB) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 0");
   const float tab_c4 = GT_C4 + (float)tab_lds;
   constexpr int NOUT = epi_is_gelu<EPI>() ? 2 : 1;
   constexpr bool G8 = (EPI == GSL_EPI_BIAS_GELU_G8);      // second output as the 8-bit GELU' code: staged as bytes (80-byte rows: conflict-free
@@ -1959,7 +1964,15 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
   else {
     // parity mode: the matrix-core kernel wherever its 128x128 tiles are not mostly padding (skinny N = 64 LoRA projections, a handful of
     // rows: the 64x64 VALU kernel); the two are bit-identical, the choice is speed only
-    if (e.N >= 128 && e.M >= 64) {
+    // (development build: GSL_F32_VALU=1 forces the VALU kernel at every shape — the switch for parity debugging should the MFMA's 4-term
+    //  accumulation ever stop being a k-ordered fmaf chain on another part or compiler; tests/test_hip_ops.py compares the two directly)
+#ifdef GSL_DEV
+    const char* fv = getenv("GSL_F32_VALU");
+    const bool force_valu = fv && atoi(fv) != 0;
+#else
+    constexpr bool force_valu = false;
+#endif
+    if (e.N >= 128 && e.M >= 64 && !force_valu) {
       EpiArgs ef = e;
       ef.remap = 1;
       const int nblk = ((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);

@@ -996,6 +996,36 @@ def test_gemm_gelu_g8_code_of_the_derivative(ops, M, N, K1, K2, p):
     assert ((out.float() - want).abs() - 2.0 ** -8 * want.abs()).max() < 1e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_gelu_table_epilogue_dropped_elements_are_exact_zeros_for_any_finite_preactivation(ops, dt):
+    """the table epilogue of the 8-phase kernel multiplies a / (1 - p) by the table entry, and a dropped element's entry is the
+    bit pattern 0x0000001A (code 26 | a float DENORMAL). With f32 denormals flushed for the epilogue the product is exactly +-0 for every
+    finite pre-activation — here |a| up to 3e4 — and a non-finite pre-activation stays non-finite (kept: +-Inf / NaN; dropped: NaN, as
+    torch's Inf * 0), never a silent finite value. Kept large values: GELU(a) = a for a >> 0, ~0 for a << 0 (the table clamps at +-4.5)."""
+    from gslora_hip import _lib as L
+    M, N, K, p = 33490, 2048, 512, 0.1            # the 8-phase kernel (table path): full and partial M tiles
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    A[1::7] *= 40.0                                # |a| up to ~200
+    bias = torch.randn(N, generator=g)
+    bias[3], bias[64 + 5], bias[300], bias[301], bias[700] = 3.0e4, -3.0e4, float("inf"), float("-inf"), float("nan")
+    h = torch.empty(M, N, device="cuda", dtype=dt); q = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    ops.gemm_nt(A.cuda().to(dt), W.cuda().to(dt), h, epilogue=L.EPI_BIAS_GELU_G8, bias=bias.cuda(), out2=q, p_drop=p, seed=11, site=2)
+    keep = ops.dropout_mask(M * N, p, 11, 2, "cuda").reshape(M, N).bool()
+    q = _unslab(q)
+    finite_col = torch.ones(N, dtype=torch.bool, device="cuda"); finite_col[[300, 301, 700]] = False
+    hd = h[:, finite_col][~keep[:, finite_col]]
+    assert hd.numel() > 1000 and (hd == 0).all()                          # exactly +-0, also at a = +-3e4
+    assert (q[~keep] == 26).all()
+    for col in (300, 301, 700):
+        assert not torch.isfinite(h[:, col].float()).any(), col          # kept or dropped: never a finite value
+    big = h[:, 3].float()[keep[:, 3]]
+    assert ((big / (3.0e4 / (1 - p)) - 1).abs() < 2e-2).all()             # GELU(a) = a
+    neg = h[:, 64 + 5].float()[keep[:, 64 + 5]]
+    assert (neg.abs() <= 3.0e4 / (1 - p) * 3.5e-6 * 1.05).all()           # a * Phi(-4.5): the table's clamp, |error| <= |a| 3.4e-6
+
+
 @pytest.mark.parametrize("M,N,K,r,p", [(1000, 512, 256, 8, 0.1), (4099, 2048, 512, 8, 0.1), (1300, 640, 192, 5, 0.0)])
 def test_gemm_nt_lora_mulgrad_with_the_8bit_gelu_derivative(ops, M, N, K, r, p):
     """gsl_gemm_nt_lora_mulgrad(aux_u8): `out` / `tout` bit-identical to the unfused in-kernel-LoRA GEMM with GSL_EPI_MUL_G8, gradients
@@ -1150,6 +1180,37 @@ def test_fused_ffn1_rank_update_equals_the_k_segment_form(ops, r):
     keep = ops.dropout_mask(M * N, 0.1, 11, 5, "cuda").view(M, N).float() / 0.9
     ref = F.gelu(A.float() @ W.float().t() + u.float() @ B.float().t() + bias) * keep
     assert relerr(outs[0][0].float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,N,K1,K2,epi", [(333, 200, 192, 64, "store"), (130, 384, 128, 0, "res"), (257, 512, 64, 64, "gelu"), (700, 768, 768, 0, "mul"),
+                                           (65, 136, 2048, 0, "store"), (1000, 2048, 512, 64, "gelu")])
+def test_f32_gemm_mfma_equals_forced_valu_kernel_bitwise(ops, M, N, K1, K2, epi, monkeypatch):
+    """the development build's GSL_F32_VALU=1 forces the VALU f32 GEMM at every shape (the parity-debugging switch). The
+    matrix-core kernel of the product library must equal it bit for bit — partial tiles in M and N, the K1 | K2 split, every epilogue of
+    the parity mode."""
+    from gslora_hip import _lib as L
+    A1, W1 = rnd(M, K1, seed=11).cuda(), rnd(N, K1, seed=12, scale=K1 ** -0.5).cuda()
+    A2 = W2 = None
+    if K2:
+        A2, W2 = rnd(M, K2, seed=13).cuda(), rnd(N, K2, seed=14, scale=0.1).cuda()
+    bias, res, aux = rnd(N, seed=15).cuda(), rnd(M, N, seed=16).cuda(), rnd(M, N, seed=17).cuda()
+
+    def call():
+        out, out2 = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+        if epi == "store":
+            ops.gemm_nt(A1, W1, out, A2=A2, W2=W2, alpha=0.5)
+        elif epi == "gelu":
+            ops.gemm_nt(A1, W1, out, epilogue=L.EPI_BIAS_GELU, A2=A2, W2=W2, bias=bias, out2=out2, p_drop=0.1, seed=5, site=3)
+        elif epi == "mul":
+            ops.gemm_nt(A1, W1, out, epilogue=L.EPI_MUL, A2=A2, W2=W2, aux=aux)
+        else:
+            ops.gemm_nt(A1, W1, out, epilogue=L.EPI_BIAS_RES_F32, A2=A2, W2=W2, bias=bias, res=res, p_drop=0.1, seed=5, site=2)
+        return out, out2
+    mf, mf2 = call()
+    monkeypatch.setenv("GSL_F32_VALU", "1")      # a knob of the development build only
+    with L.use_dev():
+        va, va2 = call()
+    assert torch.equal(mf, va) and torch.equal(mf2, va2)
 
 
 @pytest.mark.parametrize("M,N,K1,K2,epi", [(300, 512, 192, 0, "store"), (1576, 2048, 512, 64, "gelu"), (1000, 512, 2048, 64, "res"), (197 * 3, 1536, 512, 0, "store")])
