@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512) void probe(char* buf, int R, int reps, unsigne
 }
 
 int main() {
-  const int cus = 256, reps = 32;
+  const int cus = (getenv("CUS") ? atoi(getenv("CUS")) : 256), reps = 32;
   char* buf; unsigned long long* out;
   const size_t bytes = (size_t)cus * 8 * 32768;
   hipMalloc(&buf, bytes); hipMemset(buf, 1, bytes);
