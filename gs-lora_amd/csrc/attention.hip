@@ -270,18 +270,6 @@ __device__ __forceinline__ void store_tile_rows(bf16_t* stage, const f32x4_t (&a
   if (r + 8 < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)(r + 8) * gld + c * 8) = v1;
 }
 
-// the same for a 16 x 32 half tile (acc[0], acc[1] = 16-column blocks c0, c0 + 1 of the tile): 16 bytes per lane, 4 lanes per 64-byte row piece, one store
-template <int LD>
-__device__ __forceinline__ void store_half_tile_rows(bf16_t* stage, const f32x4_t (&acc)[2], float mul, bf16_t* gbase, long gld, int nvalid, int lane) {
-  const int fr = lane & 15, fc = lane >> 4;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-    *reinterpret_cast<uint2*>(stage + fr * LD + dt * 16 + fc * 4) =
-        make_uint2(pack2o(acc[dt][0] * mul, acc[dt][1] * mul), pack2o(acc[dt][2] * mul, acc[dt][3] * mul));
-  const int r = lane >> 2, c = lane & 3;
-  const uint4 v = *reinterpret_cast<const uint4*>(stage + r * LD + c * 8);
-  if (r < nvalid) *reinterpret_cast<uint4*>(gbase + (size_t)r * gld + c * 8) = v;
-}
 __device__ __forceinline__ void wg_barrier_lds() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1122,10 +1110,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __r
     };
     // dQ of query tile qt (tile qtl of the half in Ds): the dQ phase of the fused kernel with dS read back from LDS; the tile leaves as
     // full rows through the wave-private staging area stg (row stride SLD)
-    // (the lane index is laundered through an empty asm in the two P2 helpers: their per-lane LDS / global offsets are then recomputed in P2 — a
-    //  dozen VALU instructions — instead of living in registers across P1, where they cost 10 spilled VGPRs, i.e. scratch traffic in the memory pipe)
     auto dq_tile = [&](int qt, int qtl, bf16_t* stg, auto sld) {
-      int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane));
       f32x4_t acc[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1141,23 +1126,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __r
         for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(lds_frag_trr_g<KLD, true>(Ks, dt, NP - 1, lane), bq, acc[dt]);
       }
       store_tile_rows<decltype(sld)::value>(stg, acc, scale, dqkv + ((size_t)b * T + qt * 16) * ld + h * HD, ld, min(16, T - qt * 16), lane);
-    };
-    // the two 16-column blocks dt0, dt0 + 1 of the same tile (P2b: 5 tiles on 13 waves — as 10 half tiles the phase is a 14-MFMA chain, not a 28-MFMA one)
-    auto dq_half = [&](int qt, int qtl, int dt0, bf16_t* stg) {
-      int lane = threadIdx.x & 63; asm volatile("" : "+v"(lane));
-      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int pr = 0; pr < NP - 1; ++pr) {
-        const bf16x8_t bq = lds_frag_trr_g<DSLD, false>(Ds, qtl, pr, lane);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) acc[d] = mfma16(lds_frag_trr_g<KLD, false>(Ks, dt0 + d, pr, lane), bq, acc[d]);
-      }
-      {
-        const bf16x8_t bq = lds_frag_trr_g<DSLD, true>(Ds, qtl, NP - 1, lane);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) acc[d] = mfma16(lds_frag_trr_g<KLD, true>(Ks, dt0 + d, NP - 1, lane), bq, acc[d]);
-      }
-      store_half_tile_rows<DSLD>(stg, acc, scale, dqkv + ((size_t)b * T + qt * 16) * ld + h * HD + dt0 * 16, ld, min(16, T - qt * 16), lane);
     };
     // ---- P1a
     GSL_MSTAMP(0);
@@ -1189,7 +1157,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_merged_kernel(const bf16_t* __r
     wg_barrier_lds();
     GSL_MSTAMP(8);
     // ---- P2b
-    if (wave < 2 * (NCW - NPA * 2)) dq_half(NPA * 2 + (wave >> 1), wave >> 1, (wave & 1) * 2, Ds + wave * 16 * DSLD + 80);      // (columns 80 .. 143 of Ds are unused in the second half)
+    if (wave < NCW - NPA * 2) dq_tile(NPA * 2 + wave, wave, Ds + wave * 16 * DSLD + 80, std::integral_constant<int, DSLD>{});      // (columns 80 .. 143 of Ds are unused in the second half)
     GSL_MSTAMP(9);
     wg_barrier_lds();
     GSL_MSTAMP(10);
