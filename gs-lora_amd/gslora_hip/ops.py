@@ -54,6 +54,24 @@ def patchify(img, p, dtype):
 PROFILE = None
 
 
+def _profiled(tag, shape_of):
+    """bench.py: when PROFILE holds `tag`, bracket the launch with HIP events on the launch stream and record (ev0, ev1, *shape_of(args)).
+    (The GEMM wrappers do this per call-site tag; these are the memory-bound kernels of the step: LayerNorm and attention.)"""
+    def deco(fn):
+        def wrapped(*a, **kw):
+            if PROFILE is None or tag not in PROFILE:
+                return fn(*a, **kw)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            out = fn(*a, **kw)
+            ev[1].record()
+            PROFILE[tag].append((ev[0], ev[1]) + tuple(shape_of(*a, **kw)))
+            return out
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 def gemm_nt(A1, W1, out, *, epilogue=L.EPI_STORE, A2=None, W2=None, alpha=1.0, bias=None, res=None, aux=None, out2=None,
             pos=None, cls=None, T=0, p_drop=0.0, seed=0, site=0, tag=None):
     _need(A2, W2, bias, aux, out2, pos, cls)
@@ -133,6 +151,7 @@ def gemm_nt_lora_mulgrad(A, W, P, Q, lora_scale, tout, out, aux, U1, G1, g1s, Y2
     return out
 
 
+@_profiled("ln_fwd", lambda x, row_stride, M, D, *a, **k: (M, D, 0, 0))
 def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     """x: the residual stream, f32 or (bf16 mode) bf16 — its dtype is handed to the kernel."""
     _need(x, gamma, beta)
@@ -159,6 +178,7 @@ def layernorm_fwd_lora(x, row_stride, M, D, gamma, beta, eps, P, alpha, pad=64):
     return y, mean, rstd, u
 
 
+@_profiled("ln_bwd", lambda dy, *a, **k: (dy.shape[0], dy.shape[1], 0, 0))
 def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
                   io_row_stride=0, drop_row_stride=0, dres_cls_T=0):
     """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the
@@ -183,6 +203,7 @@ def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_
     return dx, (dx if alias else dxb)
 
 
+@_profiled("attn_fwd", lambda qkv, B, T, H, *a, **k: (B * T, H * 64, T, H))
 def attention_fwd(qkv, B, T, H, scale, layout=0):
     """layout: 0 = qkv token-major [B*T, 3*H*64], 1 = head-major [B][H][3][T][64] (bf16; see gemm_nt(epilogue=EPI_STORE_QKV_HM))."""
     _need(qkv)
@@ -193,6 +214,7 @@ def attention_fwd(qkv, B, T, H, scale, layout=0):
     return o, lse
 
 
+@_profiled("attn_bwd", lambda qkv, o, d_o, lse, B, T, H, *a, **k: (B * T, H * 64, T, H))
 def attention_bwd(qkv, o, d_o, lse, B, T, H, scale, layout=0):
     """dqkv is token-major [B*T, 3*H*64] whatever the layout of the qkv input."""
     _need(qkv, o, d_o, lse)

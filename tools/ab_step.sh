@@ -11,5 +11,5 @@ python - <<PY
 import json,glob
 for k,e in (("A","$a"),("B","$b")):
     v=[json.load(open(f)) for f in sorted(glob.glob("$out/%s_*.json"%k))]
-    print(k, e, "ms/step:", [x["ms_per_step"] for x in v], "ffn1 ms:", [x["roofline"]["avg_ms"] for x in v], "ffn2dx ms:", [x["roofline"]["kernels"][1]["avg_ms"] for x in v], "loss:", [round(x["last_step_meters"]["total"],4) for x in v])
+    print(k, e, "ms/step:", [x["ms_per_step"] for x in v], "ffn1 ms:", [x["roofline"]["avg_ms"] for x in v], "ffn2dx ms:", [[k["avg_ms"] for k in x["roofline"]["kernels"] if "mulgrad" in k["kernel"]][0] for x in v], "loss:", [round(x["last_step_meters"]["total"],4) for x in v])
 PY
