@@ -48,6 +48,9 @@ struct EpiArgs {
   int f16;     // BIAS_RES_BF16 / PATCH_BF16 templates: the residual stream (res in, out) is IEEE fp16 instead of bf16 (GSL_EPI_BIAS_RES_F16 / PATCH_F16)
   int krot;    // 8-phase kernel: N-tile j starts its K loop at K tile j (mod nk), so sibling tiles of one A panel do not miss on the same lines
   // gradient-fused MUL epilogue (gsl_gemm_nt_lora_mulgrad): operands of the two LoRA-gradient reductions that consume this tile
+  // STORE with a consumer-side LayerNorm (GSL_EPI_STORE_LN / STORE_QKV_HM_LN): A is the RAW residual stream x, W the weight with gamma folded in
+  // (W' = W * gamma along K), and the epilogue finishes the normalisation: out = rstd[m] * (acc - mean[m] * c[n]) + d[n], c = rowsum(W'), d = W beta (+ bias)
+  const float* ln_mean; const float* ln_rstd; const float* ln_c; const float* ln_d;
   const bf16_t* gu1; int ldgu1;   // U1 [M, >= 16]: G1[n, j] = sum_m out[m, n] * U1[m, j]
   const bf16_t* gy2;              // Y2 [M, N] (row stride ldo): G2[n, j] = sum_m Y2[m, n] * t[m, j]
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
@@ -139,7 +142,13 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
     for (int i = 0; i < 4; ++i) bq[i] = bp ? bp[i] : e.bias[n + i];
   }
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32) {
-    if (e.bias) {
+    if (e.ln_rstd) {          // consumer-side LayerNorm (fragment-path kernels; the staged epilogue applies it from preloaded values and passes bp)
+      if (!bp) {
+        const float rs = e.ln_rstd[m], rm = rs * e.ln_mean[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], rs, fmaf(-rm, e.ln_c[n + i], e.ln_d[n + i]));
+      }
+    } else if (e.bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += e.bias[n + i];
     }
@@ -257,12 +266,19 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
   float bj[4][4];        // this lane's bias values for its 4 column fragments
+  // consumer-side LayerNorm (STORE only, EpiArgs::ln_*): bj holds d[n], cj the column sums c[n]; the row statistics are loaded per 64-row chunk
+  const bool ln = (EPI == GSL_EPI_STORE) && e.ln_rstd != nullptr;      // wave-uniform
+  float cj[4][4];
   if (!bias_lds) {
+    const float* bsrc = ln ? e.ln_d : e.bias;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nw + j * 16 + fc * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bj[j][i] = (e.bias && (FULL || n < e.N)) ? e.bias[n + i] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        bj[j][i] = (bsrc && (FULL || n < e.N)) ? bsrc[n + i] : 0.f;
+        if constexpr (EPI == GSL_EPI_STORE) cj[j][i] = (ln && (FULL || n < e.N)) ? e.ln_c[n + i] : 0.f;
+      }
     }
   }
   // dropout: first-stage hash value of this lane's first fragment; fragment (i, j) is 16 i rows and 16 j columns further, i.e.
@@ -293,6 +309,17 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
     uint2 held[4][4];   // second output, packed, when SEQ
+    float rsv[4] = {0.f, 0.f, 0.f, 0.f}, rmv[4] = {0.f, 0.f, 0.f, 0.f};      // consumer-side LayerNorm: rstd and rstd * mean of this lane's 4 rows of the chunk
+    if constexpr (EPI == GSL_EPI_STORE) {
+      if (ln) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int mr = min(mw + (ib + ii) * 16 + fr, e.M - 1);
+          rsv[ii] = e.ln_rstd[mr];
+          rmv[ii] = rsv[ii] * e.ln_mean[mr];
+        }
+      }
+    }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -300,6 +327,12 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         const int i = ib + ii;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
         const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
+        if constexpr (EPI == GSL_EPI_STORE) {
+          if (ln) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], rsv[ii], fmaf(-rmv[ii], cj[j][q], bj[j][q]));
+          }
+        }
         if constexpr (TAB) {      // (rows / columns outside the matrix run the same arithmetic on finite values and are not copied out)
           uint32_t ent[4];
 #pragma unroll
@@ -1783,6 +1816,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 #endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
   e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
+  e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
@@ -2013,6 +2047,12 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
       if (out2) GSL_CHECK_ARG(dtype != GSL_F32 && N >= 16 && N <= 128 && !bias, "STORE with out2 (compact [M,16] copy of columns 0..15): 16-bit operands, 16 <= N <= 128, no bias");
       return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_STORE_F32: return launch_gemm<GSL_EPI_STORE_F32>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+    case GSL_EPI_STORE_QKV_HM_LN:
+    case GSL_EPI_STORE_LN:          // consumer-side LayerNorm: pos = mean [M], cls = rstd [M], aux = c [N] (f32), bias = d [N] (required)
+      GSL_CHECK_ARG(pos && cls && aux && bias && !out2 && alpha == 1.0f, "STORE_LN: pos = mean[M], cls = rstd[M], aux = c[N], bias = d[N] (all f32), alpha 1, no out2");
+      e.ln_mean = pos; e.ln_rstd = cls; e.ln_c = reinterpret_cast<const float*>(aux); e.ln_d = bias; e.bias = nullptr; e.aux = nullptr; e.pos = nullptr; e.cls = nullptr;
+      if (epilogue == GSL_EPI_STORE_LN) return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+      [[fallthrough]];
     case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
       GSL_CHECK_ARG(dtype == GSL_OP16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");
       e.hmT = T; e.hmH = N / 192;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const X* __restrict__ x, lo
     const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
 #pragma unroll
     for (int i = 0; i < NPL; ++i) v[i] = v[i] * rs * g[i] + b[i];
-    IO::store(y + (size_t)row * D, lane, v);
+    if (y) IO::store(y + (size_t)row * D, lane, v);      // (y == nullptr: row statistics only — timing experiments of a consumer-side LayerNorm)
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, (KS <= 16 ? 4 : 3)) void ln_fwd_lora_kernel(co
 
 extern "C" int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                                  void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s) {
-  GSL_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0, "null/size");
+  GSL_CHECK_ARG(x && gamma && beta && mean && rstd && M > 0, "null/size");      // y == nullptr: statistics only
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16 || dtype == GSL_F16, "dtype");
   GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16) || (x_dtype == GSL_F16 && dtype == GSL_F16),
                 "x dtype (a 16-bit stream only in a 16-bit mode; bf16 stream only with bf16 operands)");

@@ -18,7 +18,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "libgslora_hip_dev.so")
 
 F32, BF16, F16 = 0, 1, 2      # F16: IEEE fp16 MFMA operands (round 5) — and, as an x_dtype, the forward residual stream format of both 16-bit modes
 EPI_STORE, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_MUL, EPI_PATCH, EPI_STORE_F32, EPI_STORE_QKV_HM, EPI_BIAS_RES_BF16, EPI_PATCH_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
-EPI_MUL_G8, EPI_BIAS_GELU_G8, EPI_BIAS_RES_F16, EPI_PATCH_F16 = 9, 10, 11, 12
+EPI_MUL_G8, EPI_BIAS_GELU_G8, EPI_BIAS_RES_F16, EPI_PATCH_F16, EPI_STORE_LN, EPI_STORE_QKV_HM_LN = 9, 10, 11, 12, 13, 14
 NORM_SPLIT = 8
 SEED_ON_DEVICE = 0x80000000   # flag bit of a `site` argument: `seed` is a device pointer to a uint64 (HIP-graph replays)
 

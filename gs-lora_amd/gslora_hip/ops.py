@@ -163,6 +163,18 @@ def layernorm_fwd(x, row_stride, M, D, gamma, beta, eps, dtype):
     return y, mean, rstd
 
 
+@_profiled("ln_stats", lambda x, row_stride, M, D, *a, **k: (M, D, 0, 0))
+def layernorm_stats(x, row_stride, M, D, gamma, beta, eps, dtype):
+    """(mean, rstd) of the rows of x — gsl_layernorm_fwd without its output: the row statistics a GEMM with a consumer-side LayerNorm
+    (EPI_STORE_LN) finishes the normalisation with, and what the LayerNorm backward needs. One read of x, no write of LN(x)."""
+    _need(x, gamma, beta)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    L.check(L.load().gsl_layernorm_fwd(_p(x), row_stride, _p(gamma), _p(beta), float(eps), None, _p(mean), _p(rstd), M, D,
+                                       code(dtype), code(x.dtype), _stream()), "gsl_layernorm_fwd(stats)")
+    return mean, rstd
+
+
 def layernorm_fwd_lora(x, row_stride, M, D, gamma, beta, eps, P, alpha, pad=64):
     """bf16 mode: (LN(x), mean, rstd, u) with u = alpha * LN(x) P[:16]^T in a [M, 64] K-segment buffer (columns >= 16 zero): LayerNorm and
     the LoRA down-projection of the layer that consumes it in one pass over x (gsl_layernorm_fwd_lora)."""

@@ -50,6 +50,10 @@ QSPLIT = True
 # rows from which the LoRA down-projections are computed inside the 256x256 GEMM kernels (below: a separate N = 64 GEMM + a K segment
 # on the small-tile kernels). Measured: profiles/r03_c_small_m.md.
 INK_MIN_ROWS = 8192
+# LayerNorm 1 folded into the QKV projection (16-bit modes whose forward stream has the operand format, i.e. the fp16 default): the GEMM reads
+# the stream x itself with gamma folded into the weight and finishes the normalisation in its epilogue (EPI_STORE_LN); LayerNorm 1 shrinks to
+# its row statistics (one read of x, no LN(x) tensor). GSLORA_LN1_FOLD=0: the LayerNorm kernel + plain GEMM of rounds 1 - 4.
+LN1_FOLD = os.environ.get("GSLORA_LN1_FOLD", "1") != "0"
 INK_SMALL = True      # the in-kernel form on the small-tile kernel (few rows)
 # The LoRA-gradient reductions of a backward pass that do not ride in the FFN2-dX epilogue are collected and issued as ONE batched pair of
 # launches (gsl_lora_grad_batch) instead of two to three launches each; their operands stay alive until the end of the backward (or until
@@ -203,6 +207,24 @@ class ViTRunner:
         if dtype == torch.float32:
             return param.detach()
         return self._cached(self._wcache, (name, "n", dtype), param, lambda p: ops.cast(p.contiguous(), dtype))
+
+    def w_ln(self, name, weight, gamma, beta, bias, dtype):
+        """Operands of a GEMM with a consumer-side LayerNorm in front (EPI_STORE_LN): W' = W * gamma along K in the operand format,
+        c = rowsum(W') of the ROUNDED W' (so that the mean term cancels against what the matrix cores actually multiply), d = W beta (+ bias).
+        Cached on the four parameters' versions (all frozen in GS-LoRA: built once)."""
+        key = (name, "ln", dtype)
+        ps = [weight, gamma, beta] + ([bias] if bias is not None else [])
+        tag = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != tag:
+            with torch.no_grad():
+                w32 = weight.detach().float()
+                wf = ops.cast((w32 * gamma.detach().float()[None, :]).contiguous(), dtype)
+                c = wf.float().sum(1).contiguous()
+                d = (w32 @ beta.detach().float()) + (bias.detach().float() if bias is not None else 0.0)
+                ent = (tag, (wf, c, d.contiguous()))
+            self._wcache[key] = ent
+        return ent[1]
 
     def w_conv(self, name, param, dtype):
         """conv_proj weight [D, C, p, p] as the [D, p*p*C] operand matching gsl_patchify's (p1 p2 c) feature order."""
@@ -392,14 +414,28 @@ class ViTRunner:
         stash = []
         for i, blk in enumerate(sp.blocks):
             n1, n2 = blk.ln1, blk.ln2
-            xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
+            attn_lora_live = attn_site and not blk.qkv_lora.merged      # the q / k / v adapters read LN1's output: no fold
+            fold = LN1_FOLD and dt in OP16 and x.dtype == dt and not attn_lora_live
+            if fold:
+                mean1, rstd1 = ops.layernorm_stats(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
+                xn = None
+            else:
+                xn, mean1, rstd1 = ops.layernorm_fwd(x, D, M, D, n1.weight.detach(), n1.bias.detach(), eps, dt)
             tail = TAIL_CLS and i == len(sp.blocks) - 1 and sp.pool == "cls"
             qsplit = tail and QSPLIT and not attn_site
             inner = H * 64
             hm = 1 if (QKV_HEAD_MAJOR and dt in OP16) else 0
             epi_qkv = L.EPI_STORE_QKV_HM if hm else L.EPI_STORE
             uq = q_cls = None
-            if qsplit:      # K and V for every token, Q for the cls rows only (rows inner .. 3*inner of the fused weight are K | V)
+            if qsplit and fold:      # the same two GEMMs on the stream itself (W', c, d sliced like the weight; the cls rows' statistics gathered)
+                wf, cq, dq_ = self.w_ln(f"qkv{i}", blk.qkv_w, n1.weight, n1.bias, blk.qkv_b, dt)
+                qkv = torch.empty(M, 2 * inner, device=img.device, dtype=dt)
+                ops.gemm_nt(x, wf[inner:], qkv, epilogue=L.EPI_STORE_LN, pos=mean1, cls=rstd1, aux=cq[inner:], bias=dq_[inner:])
+                q_cls = torch.empty(B, inner, device=img.device, dtype=dt)
+                ops.gemm_nt(x.view(B, T * D)[:, :D], wf[:inner], q_cls, epilogue=L.EPI_STORE_LN, pos=mean1.view(B, T)[:, 0].contiguous(),
+                            cls=rstd1.view(B, T)[:, 0].contiguous(), aux=cq[:inner].contiguous(), bias=dq_[:inner].contiguous())
+                hm = 2
+            elif qsplit:      # K and V for every token, Q for the cls rows only (rows inner .. 3*inner of the fused weight are K | V)
                 wq = self.w(f"qkv{i}", blk.qkv_w, dt)
                 qb_ = None if blk.qkv_b is None else blk.qkv_b.detach()
                 qkv = torch.empty(M, 2 * inner, device=img.device, dtype=dt)
@@ -414,6 +450,10 @@ class ViTRunner:
                 ops.gemm_nt(xn, qo["A_rows"], uq, alpha=s_lora)
                 ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, A2=uq, W2=qo["Bblk"], epilogue=epi_qkv, T=T,
                             bias=None if blk.qkv_b is None else blk.qkv_b.detach())
+            elif fold:
+                wf, cq, dq_ = self.w_ln(f"qkv{i}", blk.qkv_w, n1.weight, n1.bias, blk.qkv_b, dt)
+                qkv = torch.empty(M, 3 * inner, device=img.device, dtype=dt)
+                ops.gemm_nt(x, wf, qkv, epilogue=L.EPI_STORE_QKV_HM_LN if hm else L.EPI_STORE_LN, T=T, pos=mean1, cls=rstd1, aux=cq, bias=dq_)
             else:
                 qkv = torch.empty(M, 3 * inner, device=img.device, dtype=dt)
                 ops.gemm_nt(xn, self.w(f"qkv{i}", blk.qkv_w, dt), qkv, epilogue=epi_qkv, T=T,

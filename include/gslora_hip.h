@@ -63,6 +63,12 @@ enum gsl_epilogue {
                                p_drop = the dropout rate of the forward that wrote it (decode scale 1/(1-p); no mask is applied here) */
   GSL_EPI_BIAS_RES_F16 = 11,/* bf16 only: BIAS_RES_BF16 with the forward residual stream (res in, out) in IEEE fp16 (clamped to +-65504 on store) */
   GSL_EPI_PATCH_F16 = 12,   /* bf16 only: PATCH with an fp16 output */
+  GSL_EPI_STORE_LN = 13,    /* STORE with a CONSUMER-SIDE LayerNorm (reference vit_face.py:316-323 PreNorm + :358-360 to_qkv; modified_VIT.py: ln_1 -> in_proj): A1 is the RAW
+                               residual stream x (not LN(x)), W1 the weight with gamma folded in (W'[n,k] = W[n,k] gamma[k], operand format), and
+                               out[dtype] = rstd[m] * (acc - mean[m] * c[n]) + d[n]   with pos = mean [M], cls = rstd [M] (gsl_layernorm_fwd with
+                               y = NULL), aux = c [N] = rowsum_k W' (f32, of the ROUNDED W'), bias = d [N] = W beta (+ the layer's bias) (f32).
+                               One pass over x replaces LayerNorm's read + write and the GEMM reads the stream itself. alpha = 1, no out2. */
+  GSL_EPI_STORE_QKV_HM_LN = 14, /* the same with the head-major copy-out of GSL_EPI_STORE_QKV_HM */
   GSL_EPI_BIAS_GELU_G8 = 10 /* bf16 only: BIAS_GELU whose second output is the 8-bit fixed-point code of gelu'(acc+bias)*dropmask:
                                q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p); gelu' lies in [-0.129, 1.129]:
                                absolute error <= 0.0025/(1-p), a dropped element decodes to exactly 0. out2 is M*N bytes in SLAB-MAJOR
@@ -126,7 +132,7 @@ GSL_API int gsl_gemm_nt_lora_mulgrad(const void* A, int lda, const void* W, int 
 
 /* ---- K2 LayerNorm (nn.LayerNorm, vit_face.py:316-323, 498-500). x — the residual stream — is `x_dtype` (f32; bf16 when the bf16
  * speed mode carries the forward stream in bf16), rows of length D at stride x_row_stride (elements); y[dtype] [M,D]; mean/rstd f32 [M].
- * D in {64,128,256,512,768,1024}. */
+ * D in {64,128,256,512,768,1024}. y may be NULL: row statistics only (the input of GSL_EPI_STORE_LN, whose GEMM normalises in its epilogue). */
 GSL_API int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
                       void* y, float* mean, float* rstd, int M, int D, int dtype, int x_dtype, gsl_stream_t s);
 /* LayerNorm forward + the LoRA down-projection that reads its output, in one pass (bf16 mode): y = LN(x) [M,D] bf16 and

@@ -382,6 +382,41 @@ def test_attention_bwd_merged_bit_identical_to_fused_kernel(ops, dt, B, T, H, hm
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,D,hmT,mu,outlier", [(4096, 1536, 512, 0, 0.5, 0.0), (197 * 24, 1536, 512, 197, 2.0, 8.0), (300, 512, 768, 0, 0.5, 0.0), (70, 256, 128, 0, 0.0, 0.0)])
+def test_gemm_store_with_consumer_side_layernorm(ops, dt, M, N, D, hmT, mu, outlier):
+    """EPI_STORE_LN / EPI_STORE_QKV_HM_LN: out = rstd (x W'^T - mean c) + d with W' = W gamma, c = rowsum(W') of the rounded W', d = W beta + bias,
+    on the RAW stream x — against LN(x) W^T + bias in f64, and against the two-kernel form (LayerNorm kernel, then the plain GEMM): the folded form
+    must be at least as accurate (it skips one 16-bit rounding of LN(x)), also with row means of 2 sigma and 8-sigma outlier channels; partial
+    tiles, the small-tile and the 8-phase kernels, the head-major copy-out; the statistics-only LayerNorm call returns the LayerNorm kernel's."""
+    from gslora_hip import _lib as L
+    g = torch.Generator().manual_seed(3)
+    x32 = torch.randn(M, D, generator=g) + mu * torch.randn(M, 1, generator=g)
+    if outlier:
+        x32[:, 7] += outlier; x32[:, D // 2] -= outlier
+    x = x32.to(dt).cuda()
+    gam = (1 + 0.2 * torch.randn(D, generator=g)).cuda(); bet = (0.1 * torch.randn(D, generator=g)).cuda()
+    W = (torch.randn(N, D, generator=g) * D ** -0.5).cuda(); bias = (0.1 * torch.randn(N, generator=g)).cuda()
+    xd = x.double(); m1 = xd.mean(1, keepdim=True); v1 = ((xd - m1) ** 2).mean(1, keepdim=True)
+    ref = (((xd - m1) / (v1 + 1e-5).sqrt()) * gam.double() + bet.double()) @ W.double().t() + bias.double()
+    xn, mean, rstd = ops.layernorm_fwd(x, D, M, D, gam, bet, 1e-5, dt)
+    mean2, rstd2 = ops.layernorm_stats(x, D, M, D, gam, bet, 1e-5, dt)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    y0 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(xn, W.to(dt), y0, bias=bias, epilogue=L.EPI_STORE_QKV_HM if hmT else L.EPI_STORE, T=hmT)
+    wf = (W * gam[None, :]).to(dt); c = wf.float().sum(1).contiguous(); d = (W @ bet + bias).contiguous()
+    y1 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(x, wf, y1, epilogue=L.EPI_STORE_QKV_HM_LN if hmT else L.EPI_STORE_LN, T=hmT, pos=mean2, cls=rstd2, aux=c, bias=d)
+    if hmT:      # both outputs are head-major [B][H][3][T][64]: compare in that layout against the permuted reference
+        ref = _to_head_major(ref, M // hmT, hmT, N // 192)
+    e0 = (y0.double() - ref).pow(2).mean().sqrt().item(); e1 = (y1.double() - ref).pow(2).mean().sqrt().item()
+    print(f"[LN fold {dt} M={M}] rms error vs f64: two kernels {e0:.3e}, folded {e1:.3e}")
+    assert e1 <= e0 * 1.02
+    assert (y1.double() - ref).abs().max().item() < (3e-2 if dt == torch.bfloat16 else 4e-3) * max(1.0, ref.abs().max().item() / 4)
+    with pytest.raises(RuntimeError):      # the four f32 vectors are required
+        ops.gemm_nt(x, wf, y1, epilogue=L.EPI_STORE_LN, pos=mean2, cls=rstd2, aux=c)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [9000, 1000, 300])
 def test_gemm_store_compact_second_output(ops, dt, M):
     """EPI_STORE with out2: a compact [M, 16] copy of output columns 0..15 (the operand form of the LoRA down-projection u1 that the
