@@ -50,7 +50,7 @@ struct EpiArgs {
   // gradient-fused MUL epilogue (gsl_gemm_nt_lora_mulgrad): operands of the two LoRA-gradient reductions that consume this tile
   // STORE with a consumer-side LayerNorm (GSL_EPI_STORE_LN / STORE_QKV_HM_LN): A is the RAW residual stream x, W the weight with gamma folded in
   // (W' = W * gamma along K), and the epilogue finishes the normalisation: out = rstd[m] * (acc - mean[m] * c[n]) + d[n], c = rowsum(W'), d = W beta (+ bias)
-  const float* ln_mean; const float* ln_rstd; const float* ln_c; const float* ln_d;
+  const float* ln_mean; const float* ln_rstd; const float* ln_c; const float* ln_d; int ln_rs;      // ln_rs: row m reads mean / rstd [m * ln_rs] (1, or T for the cls rows of a [B*T] tensor)
   const bf16_t* gu1; int ldgu1;   // U1 [M, >= 16]: G1[n, j] = sum_m out[m, n] * U1[m, j]
   const bf16_t* gy2;              // Y2 [M, N] (row stride ldo): G2[n, j] = sum_m Y2[m, n] * t[m, j]
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
@@ -144,7 +144,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32) {
     if (e.ln_rstd) {          // consumer-side LayerNorm (fragment-path kernels; the staged epilogue applies it from preloaded values and passes bp)
       if (!bp) {
-        const float rs = e.ln_rstd[m], rm = rs * e.ln_mean[m];
+        const float rs = e.ln_rstd[(size_t)m * e.ln_rs], rm = rs * e.ln_mean[(size_t)m * e.ln_rs];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], rs, fmaf(-rm, e.ln_c[n + i], e.ln_d[n + i]));
       }
@@ -315,8 +315,8 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int mr = min(mw + (ib + ii) * 16 + fr, e.M - 1);
-          rsv[ii] = e.ln_rstd[mr];
-          rmv[ii] = rsv[ii] * e.ln_mean[mr];
+          rsv[ii] = e.ln_rstd[(size_t)mr * e.ln_rs];
+          rmv[ii] = rsv[ii] * e.ln_mean[(size_t)mr * e.ln_rs];
         }
       }
     }
@@ -1816,7 +1816,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 #endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
   e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0;
-  e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr;
+  e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr; e.ln_rs = 1;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
   { const char* kr = getenv("GSL_KROT"); if (kr && allow_krot) e.krot = atoi(kr); }
@@ -2051,7 +2051,11 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
     case GSL_EPI_STORE_LN:          // consumer-side LayerNorm: pos = mean [M], cls = rstd [M], aux = c [N] (f32), bias = d [N] (required)
       GSL_CHECK_ARG(pos && cls && aux && bias && !out2 && alpha == 1.0f, "STORE_LN: pos = mean[M], cls = rstd[M], aux = c[N], bias = d[N] (all f32), alpha 1, no out2");
       e.ln_mean = pos; e.ln_rstd = cls; e.ln_c = reinterpret_cast<const float*>(aux); e.ln_d = bias; e.bias = nullptr; e.aux = nullptr; e.pos = nullptr; e.cls = nullptr;
-      if (epilogue == GSL_EPI_STORE_LN) return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+      if (epilogue == GSL_EPI_STORE_LN) {
+        GSL_CHECK_ARG(T >= 0, "STORE_LN: T = 0, or the row stride of mean / rstd (row m reads element m * T: the cls rows of a [B * T] tensor)");
+        e.ln_rs = T > 0 ? T : 1;
+        return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
+      }
       [[fallthrough]];
     case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
       GSL_CHECK_ARG(dtype == GSL_OP16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");

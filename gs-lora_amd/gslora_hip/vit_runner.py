@@ -432,8 +432,8 @@ class ViTRunner:
                 qkv = torch.empty(M, 2 * inner, device=img.device, dtype=dt)
                 ops.gemm_nt(x, wf[inner:], qkv, epilogue=L.EPI_STORE_LN, pos=mean1, cls=rstd1, aux=cq[inner:], bias=dq_[inner:])
                 q_cls = torch.empty(B, inner, device=img.device, dtype=dt)
-                ops.gemm_nt(x.view(B, T * D)[:, :D], wf[:inner], q_cls, epilogue=L.EPI_STORE_LN, pos=mean1.view(B, T)[:, 0].contiguous(),
-                            cls=rstd1.view(B, T)[:, 0].contiguous(), aux=cq[:inner].contiguous(), bias=dq_[:inner].contiguous())
+                ops.gemm_nt(x.view(B, T * D)[:, :D], wf[:inner], q_cls, epilogue=L.EPI_STORE_LN, T=T, pos=mean1, cls=rstd1,      # (T: the cls rows' statistics, T apart)
+                            aux=cq[:inner], bias=dq_[:inner])
                 hm = 2
             elif qsplit:      # K and V for every token, Q for the cls rows only (rows inner .. 3*inner of the fused weight are K | V)
                 wq = self.w(f"qkv{i}", blk.qkv_w, dt)

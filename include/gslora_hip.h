@@ -67,7 +67,8 @@ enum gsl_epilogue {
                                residual stream x (not LN(x)), W1 the weight with gamma folded in (W'[n,k] = W[n,k] gamma[k], operand format), and
                                out[dtype] = rstd[m] * (acc - mean[m] * c[n]) + d[n]   with pos = mean [M], cls = rstd [M] (gsl_layernorm_fwd with
                                y = NULL), aux = c [N] = rowsum_k W' (f32, of the ROUNDED W'), bias = d [N] = W beta (+ the layer's bias) (f32).
-                               One pass over x replaces LayerNorm's read + write and the GEMM reads the stream itself. alpha = 1, no out2. */
+                               One pass over x replaces LayerNorm's read + write and the GEMM reads the stream itself. alpha = 1, no out2. T > 0: row m takes
+                               mean[m*T], rstd[m*T] — the statistics of every T-th row of a larger tensor (A1 = its cls rows at lda1 = T*D). */
   GSL_EPI_STORE_QKV_HM_LN = 14, /* the same with the head-major copy-out of GSL_EPI_STORE_QKV_HM */
   GSL_EPI_BIAS_GELU_G8 = 10 /* bf16 only: BIAS_GELU whose second output is the 8-bit fixed-point code of gelu'(acc+bias)*dropmask:
                                q = round(gelu' * keep * 200 + 26), decoded as (q - 26) * 0.005 / (1 - p); gelu' lies in [-0.129, 1.129]:

@@ -417,6 +417,28 @@ def test_gemm_store_with_consumer_side_layernorm(ops, dt, M, N, D, hmT, mu, outl
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_store_ln_on_the_cls_rows_with_strided_statistics(ops, dt):
+    """EPI_STORE_LN with T > 0: A = the cls rows of a [B*T, D] stream (lda = T*D) and row m takes mean[m*T], rstd[m*T] of the full-tensor
+    statistics — the last block's Q projection (cls rows only) without a gather: identical to the call on gathered rows / statistics."""
+    from gslora_hip import _lib as L
+    B, T, D, N = 96, 197, 512, 512
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(B * T, D, generator=g) + 0.5).to(dt).cuda()
+    gam = (1 + 0.2 * torch.randn(D, generator=g)).cuda(); bet = (0.1 * torch.randn(D, generator=g)).cuda()
+    W = (torch.randn(N, D, generator=g) * D ** -0.5).cuda()
+    mean, rstd = ops.layernorm_stats(x, D, B * T, D, gam, bet, 1e-5, dt)
+    wf = (W * gam[None, :]).to(dt); c = wf.float().sum(1).contiguous(); d = (W @ bet).contiguous()
+    a = torch.empty(B, N, device="cuda", dtype=dt); b = torch.empty(B, N, device="cuda", dtype=dt)
+    ops.gemm_nt(x.view(B, T * D)[:, :D], wf, a, epilogue=L.EPI_STORE_LN, T=T, pos=mean, cls=rstd, aux=c, bias=d)
+    ops.gemm_nt(x.view(B, T, D)[:, 0].contiguous(), wf, b, epilogue=L.EPI_STORE_LN, pos=mean.view(B, T)[:, 0].contiguous(),
+                cls=rstd.view(B, T)[:, 0].contiguous(), aux=c, bias=d)
+    assert torch.equal(a, b)
+    xd = x.view(B, T, D)[:, 0].double(); m1 = xd.mean(1, keepdim=True); v1 = ((xd - m1) ** 2).mean(1, keepdim=True)
+    ref = (((xd - m1) / (v1 + 1e-5).sqrt()) * gam.double() + bet.double()) @ W.double().t()
+    assert (a.double() - ref).abs().max().item() < (3e-2 if dt == torch.bfloat16 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [9000, 1000, 300])
 def test_gemm_store_compact_second_output(ops, dt, M):
     """EPI_STORE with out2: a compact [M, 16] copy of output columns 0..15 (the operand form of the LoRA down-projection u1 that the
