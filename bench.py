@@ -304,6 +304,7 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval_data leg (N = 1 only: test-set evaluation throughput, batches of 5 x batch)")
     ap.add_argument("--eval-batches", type=int, default=3)
+    ap.add_argument("--no-mem-kernels", action="store_true", help="skip the two extra steps after the timed region that time the LayerNorm / attention launches (roofline.memory_bound_kernels); the profiling scripts pass it so that a trace holds warmup + steps only")
     args = ap.parse_args()
     C = CONFIGS[args.config]
     args.batch = C["batch"] if args.batch is None else args.batch
@@ -394,7 +395,7 @@ def main():
         # north_star: "achieved HBM GB/s on the norm/softmax kernels": LayerNorm and attention launches bracketed by HIP events in TWO extra
         # steps AFTER the timed region (31 more event pairs per step inside it would serialise kernel hand-overs the step otherwise overlaps)
         mem_prof = None
-        if world == 1 and not args.graph:
+        if world == 1 and not args.graph and not args.no_mem_kernels:
             ops.PROFILE = {"ln_fwd": [], "ln_bwd": [], "attn_fwd": [], "attn_bwd": []}
             for _ in range(2):
                 wl.step()
