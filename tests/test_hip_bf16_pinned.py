@@ -89,17 +89,23 @@ def _build_full(dtype, dropout=0.0):
     return build(recipe.cfg_full(), dtype, dropout=dropout)
 
 
-def test_full_model_bf16_grads_and_meters_vs_reference_golden(golden_dir):
-    """bf16 speed mode on the FULL ViT-P8S8 against the golden of the real reference engine (f32 CPU): first-step LoRA gradients
-    (relative Frobenius error per tensor < 6 %, cosine > 0.995 — the declared bf16 band of DESIGN.md section 1) and the meters of
-    the first step / the 3-step averages (losses within 2e-2 relative, top-1 exact at batch 2)."""
+# declared per-tensor LoRA-gradient bands of the two speed modes against the REAL reference (f32 CPU): (relative Frobenius, cosine)
+GRAD_BAND = {"bf16": (0.06, 0.995), "fp16": (0.01, 0.9999)}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_full_model_speed_mode_grads_and_meters_vs_reference_golden(golden_dir, mode):
+    """Both speed modes (fp16 = the benchmarked default, with its device-picked loss scale; bf16) on the FULL ViT-P8S8 against the golden of
+    the real reference engine (f32 CPU, /root/reference engine_cl.py:59-125 -> tests/golden/full_b2.npz): first-step LoRA gradients
+    (relative Frobenius error per tensor < 6 % / cosine > 0.995 for bf16, < 1 % / > 0.9999 for fp16 — the declared bands of DESIGN.md
+    section 1) and the meters of the first step / the 3-step averages (losses within 2e-2 relative, top-1 exact at batch 2)."""
     import engine_cl
     from gslora_hip.optim import FusedAdamW
     from test_hip_model import batches, lora_grads
     from util.utils import AverageMeter
     cfg, b = recipe.cfg_full(), 2
     g = np.load(os.path.join(golden_dir, "full_b2.npz"))
-    m = _build_full("bf16")
+    m = _build_full(mode)
     opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=HYPER["lr"], weight_decay=HYPER["wd"], eps=1e-8)
     crit = torch.nn.CrossEntropyLoss()
     meters = {k: AverageMeter() for k in NAMES}
@@ -129,15 +135,20 @@ def test_full_model_bf16_grads_and_meters_vs_reference_golden(golden_dir):
                 rel = np.linalg.norm(a - r) / np.linalg.norm(r)
                 cos = float(a @ r) / (np.linalg.norm(a) * np.linalg.norm(r))
                 worst = max(worst, rel)
-                assert rel < 0.06 and cos > 0.995, (k, rel, cos)
-            print(f"[bf16 vs reference golden] worst per-tensor relative Frobenius gradient error {worst:.4f}")
+                assert rel < GRAD_BAND[mode][0] and cos > GRAD_BAND[mode][1], (mode, k, rel, cos)
+            print(f"[{mode} vs reference golden] worst per-tensor relative Frobenius gradient error {worst:.4f}")
     got = np.array([meters[k].avg for k in NAMES])
     ref = g["meters3_avg"]
     assert np.abs(got - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max()), (got, ref)
 
 
-def test_full_model_bf16_vs_f32_batch64():
-    """tools/bf16_vs_fp32.py as a test: FULL ViT-P8S8, batch 64+64 (M = 25 216 rows: the 256x256 kernels with ragged tiles), same weights /
+# (logits, emb, gradient relative Frobenius, cosine) bounds of a speed mode against the path's own f32 mode at 64+64
+VS_F32_BAND = {"bf16": (0.09, 0.075, 0.015, 0.9999), "fp16": (0.03, 0.03, 0.003, 0.99999)}
+
+
+@pytest.mark.parametrize("mode16", ["bf16", "fp16"])
+def test_full_model_speed_mode_vs_f32_batch64(mode16):
+    """tools/bf16_vs_fp32.py as a test (fp16 measured in round 5: logits 0.008, emb 0.008, gradient 0.10 %): FULL ViT-P8S8, batch 64+64 (M = 25 216 rows: the 256x256 kernels with ragged tiles), same weights /
     batch / loss in both modes. Measured in round 1: logits max |d| 0.014, embedding 0.0057, loss 42.5464 vs 42.5468, LoRA gradient
     relative Frobenius error 0.38 %, cosine 0.999993. Bounds below leave ~3x headroom."""
     import loralib as lora
@@ -158,7 +169,7 @@ def test_full_model_bf16_vs_f32_batch64():
     y = torch.randint(0, 100, (2 * B,), generator=gen).cuda()
     proto = torch.randn(100, 512, generator=gen).cuda()
     res = {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", mode16):
         mm = copy.deepcopy(m).set_compute_dtype(mode)
         lo, em = mm(x, y)
         ce_r = losses.ce_sum_top1(lo[:B], y[:B])[0] / B
@@ -168,17 +179,18 @@ def test_full_model_bf16_vs_f32_batch64():
         total.backward()
         res[mode] = (lo.detach().float(), em.detach().float(), torch.cat([p.grad.reshape(-1) for p in mm.parameters() if p.requires_grad]),
                      total.item())
-    a, b = res["fp32"], res["bf16"]
+    a, b = res["fp32"], res[mode16]
     d_logit = float((a[0] - b[0]).abs().max())
     d_emb = float((a[1] - b[1]).abs().max())
     rel = float((a[2] - b[2]).norm() / a[2].norm())
     cos = float(torch.dot(a[2], b[2]) / (a[2].norm() * b[2].norm()))
     top1_same = float((a[0].argmax(1) == b[0].argmax(1)).float().mean())
-    print(f"[bf16 vs f32, B=64+64] logits {d_logit:.4f} emb {d_emb:.4f} loss {a[3]:.5f}/{b[3]:.5f} grad rel {rel:.4f} cos {cos:.6f} "
+    print(f"[{mode16} vs f32, B=64+64] logits {d_logit:.4f} emb {d_emb:.4f} loss {a[3]:.5f}/{b[3]:.5f} grad rel {rel:.4f} cos {cos:.6f} "
           f"top-1 agreement {top1_same:.4f}")
     # round 3 (forward residual stream in bf16, twelve more roundings of the [M, dim] stream per forward): measured logits 0.060, emb 0.049,
     # gradient relative error 0.55 %, cosine 0.999985, top-1 agreement 1.0 (round 2, f32 stream: 0.016 / 0.0056 / 0.32 % / 0.999995)
-    assert d_logit < 0.09 and d_emb < 0.075
+    bl, be, br, bc = VS_F32_BAND[mode16]
+    assert d_logit < bl and d_emb < be
     assert abs(a[3] - b[3]) < 5e-3 * max(1.0, abs(a[3]))
-    assert rel < 0.015 and cos > 0.9999
+    assert rel < br and cos > bc
     assert top1_same >= 0.99

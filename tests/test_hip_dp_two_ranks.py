@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2), ("fp16", 4e-3)])
 def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, dtype, tol):
     sys.path.insert(0, HERE)
     import dp_gloo_gpu_child as C

@@ -478,14 +478,16 @@ def test_engine_single_f32_matches_reference(name, golden_dir):
         assert all(torch.equal(before[n], p) for n, p in model.named_parameters())
 
 
-def test_engine_single_fewshot_graph_replay_equals_eager(golden_dir):
-    """The few-shot regime is the launch-bound one: the same inverted epoch through the HIP-graph stepper gives the eager meters."""
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_engine_single_fewshot_graph_replay_equals_eager(golden_dir, dtype):
+    """The few-shot regime is the launch-bound one: the same inverted epoch through the HIP-graph stepper gives the eager meters (f32, and
+    the benchmarked fp16 mode whose loss scale the replay reads from device memory)."""
     import engine as eng
     from gslora_hip.optim import FusedAdamW
     cfg, sc, H = recipe.cfg_small2(), S.SINGLE["fewshot"], S.SINGLE_HYPER
     res = {}
     for mode in (False, True):
-        model = build_model(cfg, "fp32", recipe.make_state(cfg))
+        model = build_model(cfg, dtype, recipe.make_state(cfg))
         rem, forg = S.loaders(cfg, sc["n_remain"], sc["n_forget"], sc["batch"], seed=sc["seed"])
         opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=H["lr"], weight_decay=H["wd"], eps=1e-8)
         cfgd = {"few_shot": True, "ALPHA_EPOCH": 0, "NUM_LAYERS": cfg["depth"], "GROUP_TYPE": "lora", "GROUP_POS": "FFN",

@@ -29,7 +29,7 @@ def batch(cfg, b, s):
             mk(recipe.make_images(cfg, b, seed=200 + s, tag="xf")), mk(recipe.make_labels(cfg, b, seed=200 + s, tag="yf", lo=cfg["num_class"] - nf, hi=cfg["num_class"])))
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 def test_graph_replay_bit_identical_to_eager(dtype):
     from gslora_hip.optim import FusedAdamW
     from gslora_hip.step import GraphedStep, gs_lora_step
@@ -66,7 +66,8 @@ def test_graph_replay_bit_identical_to_eager(dtype):
     assert o2._flat[0]["step"] == o1._flat[0]["step"] == 9
 
 
-def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path):
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path, dtype):
     """engine_cl.train_one_epoch with cfg HIP_GRAPH 'auto' (batch 5+5 -> graph) vs HIP_GRAPH False: identical meters / parameters."""
     import engine_cl
     from gslora_hip.optim import FusedAdamW
@@ -76,7 +77,7 @@ def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path):
     proto = {c: torch.tensor(proto_np[c]) for c in range(cfg["num_class"])}
     res = {}
     for mode in (False, "auto"):
-        m = build(cfg, "bf16", 0.1)
+        m = build(cfg, dtype, 0.1)
         opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
         crit = torch.nn.CrossEntropyLoss()
         cfgd = {"DATA_ROOT": "./data/casia100/", "BND_pro": 2.0, "MULTI_GPU": False, "WORK_PATH": str(tmp_path), "BACKBONE_NAME": "VIT",
@@ -100,13 +101,14 @@ def test_engine_uses_graph_for_small_batches_and_matches_eager(tmp_path):
         assert torch.equal(res[False][1][n], res["auto"][1][n]), n
 
 
-def test_graphs_of_several_batch_shapes_are_kept():
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_graphs_of_several_batch_shapes_are_kept(dtype):
     """A ragged last batch does not throw away the graph of the regular batch: both configurations are captured once and replayed,
     bit-identical to eager steps on a twin model."""
     from gslora_hip.optim import FusedAdamW
     from gslora_hip.step import GraphedStep, gs_lora_step
     cfg = recipe.cfg_small2()
-    m1 = build(cfg, "bf16", 0.1)
+    m1 = build(cfg, dtype, 0.1)
     m2 = copy.deepcopy(m1)
     mk_opt = lambda m: FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
     o1, o2 = mk_opt(m1), mk_opt(m2)
