@@ -56,7 +56,7 @@ struct EpiArgs {
   float* gpart1; float* gpart2;   // per-M-tile partial sums [M tiles][N][gR]
   int gR;                         // 8 or 16
   int hmT, hmH;                   // STORE_QKV_HM: tokens per image and heads (0 = plain row-major output)
-  int o4_delay;                   // overlap GEMM (gemm_o4.inc): cycles the second workgroup of a CU's first round holds back (0 = none)
+  int o4_delay;                   // development, overlap GEMM (gemm_o4.inc, GSL_O4_DELAY): cycles the second workgroup of a CU's first round holds back (0 = none)
   int stamps_all;                 // development (GSL_P8_STAMPS_ALL): every workgroup stamps
   unsigned long long* stamps;     // development (GSL_P8_STAMPS = device address of 256 x 4 u64): cycle stamps of every 64th workgroup of the 8-phase kernel
 };
@@ -1666,7 +1666,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     }
 }
 
+// (the OVERLAP GEMM of round 6 — 4-wave workgroups on 256 x 128 tiles, two resident per CU so that one's epilogue runs under the other's K loop,
+//  csrc/gemm_o4.inc, development build only, GSL_O4=1 — ties this kernel on every shape of the step and loses 1 % on the step: two 256 x 128 tiles
+//  need 1.5x the operand bytes of one 256 x 256 tile, and the L2 -> LDS stream is what bounds these K loops: profiles/r06_e_overlap_gemm.md)
+#ifdef GSL_DEV
 #include "gemm_o4.inc"
+#endif
 
 // (a 4-wave, one-wave-per-SIMD 32x32x16 form of the plain-store GEMM — csrc/gemm_w4.inc, development build only — has the faster K loop at
 //  K = 512 and loses the tile on its epilogue: profiles/r05_e_kloop_4w32.md, r05_h_w4_stamps.md)
@@ -1814,17 +1819,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 // Launch knobs. The product library has none: block-id remap on, K rotation off, non-temporal output stores, no stamps, and the
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
-#ifndef GSL_O4
-#define GSL_O4 1          // plain-store and fused-FFN1 GEMMs of the 8-phase class on the overlap kernel (gemm_o4.inc) where its shape rules hold
-#endif
-#ifndef GSL_O4_DELAY
-#define GSL_O4_DELAY 6000 // cycles the second workgroup of a CU's first round holds back (out-of-phase start)
-#endif
 #ifndef GSL_STMODE
 #define GSL_STMODE 1      // output stores of the staged epilogues: 0 plain, 1 non-temporal, 2 sc1 (store_stream16)
 #endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0; e.o4_delay = GSL_O4_DELAY;
+  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0; e.o4_delay = 0;
   e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr; e.ln_rs = 1;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
@@ -1981,17 +1980,20 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
       }
     }
 #endif
-    if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU_G8) {
-      bool o4 = GSL_O4 != 0;
 #ifdef GSL_DEV
-      { const char* o = getenv("GSL_O4"); if (o) o4 = atoi(o) != 0; }
-#endif
-      if (o4 && variant == 8 && !(EPI == GSL_EPI_STORE && e.out2) && o4_usable(e.M, e.N, K1, K2, lda1, ldw1, lda2, ldw2, e.ldo)) {
-        hipLaunchKernelGGL((gemm_op16_o4_kernel<EPI>), dim3(((e.M + O4_BM - 1) / O4_BM) * (e.N / O4_BN)), dim3(256), 0, st, (const op16_t*)A1, lda1,
+    if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_BIAS_GELU_G8) {
+      // development (GSL_O4=1): the plain-store and fused-FFN1 GEMMs of the 8-phase class on the overlap kernel where its shape rules hold
+      // (gemm_o4.inc; a measured alternative). GSL_O4_ONE_PER_CU=1: 16 KB of dynamic LDS on top = one workgroup per CU.
+      const char* o = getenv("GSL_O4");
+      if (o && atoi(o) != 0 && variant == 8 && !(EPI == GSL_EPI_STORE && e.out2) && o4_usable(e.M, e.N, K1, K2, lda1, ldw1, lda2, ldw2, e.ldo)) {
+        const char* o1 = getenv("GSL_O4_ONE_PER_CU");
+        const int o4_dyn = (o1 && atoi(o1)) ? 16384 : 0;
+        hipLaunchKernelGGL((gemm_op16_o4_kernel<EPI>), dim3(((e.M + O4_BM - 1) / O4_BM) * (e.N / O4_BN)), dim3(256), o4_dyn, st, (const op16_t*)A1, lda1,
                            (const op16_t*)W1, ldw1, K1, (const op16_t*)A2, lda2, (const op16_t*)W2, ldw2, K2, e);
         return check_launch("gsl_gemm_nt(o4)");
       }
     }
+#endif
     if (variant == 8) {
       EpiArgs e8 = e;
       e8.mrev = mrev_for(EPI == GSL_EPI_STORE ? (e.N > K1 ? 0 : (e.N < K1 ? 11 : 12)) : EPI);

@@ -18,8 +18,8 @@ SOURCES = ["gemm.hip", "norm.hip", "lora.hip", "head.hip", "attention.hip"]
 # translation units that are compiled a second time with -DGSL_OP_F16: the same kernels with IEEE fp16 MFMA operands (dtype GSL_F16), in
 # namespace gsl_h16, behind hidden h16_<entry> symbols that the exported entry points forward to (csrc/gsl_common.h, csrc/gsl_h16.h)
 SOURCES_F16 = ["gemm.hip", "attention.hip"]
-HEADERS = ["gsl_common.h", "gsl_h16.h", "exports.map", "gelu_g8_table.inc", "gemm_o4.inc"]
-DEV_ONLY = ["gemm_dev_a.inc", "gemm_dev_b.inc", "gemm_dev_c.inc", "gemm_w4.inc"]
+HEADERS = ["gsl_common.h", "gsl_h16.h", "exports.map", "gelu_g8_table.inc"]
+DEV_ONLY = ["gemm_dev_a.inc", "gemm_dev_b.inc", "gemm_dev_c.inc", "gemm_w4.inc", "gemm_o4.inc"]
 OUT = os.path.join(HERE, "libgslora_hip.so")
 OUT_DEV = os.path.join(HERE, "libgslora_hip_dev.so")
 

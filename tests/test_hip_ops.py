@@ -1402,10 +1402,9 @@ def test_gemm_w4_store_kernel(ops, dev_lib, monkeypatch, M, N, K, T, bias, dt):
                                                (33490, 1536, 512, 0, 197, "hm_ln"), (33490, 512, 512, 0, 0, "ln"), (33490, 512, 128, 64, 0, "alpha"),
                                                (201728, 512, 512, 0, 0, "plain"), (65536, 1024, 64, 64, 0, "bias")])
 def test_gemm_o4_overlap_kernel_store(ops, dev_lib, monkeypatch, M, N, K1, K2, T, mode, dt):
-    """The overlap GEMM (csrc/gemm_o4.inc: 4-wave workgroups on 256 x 128 tiles of v_mfma_f32_32x32x16, two resident per CU — the product's
-    kernel for the plain-store class from 128 tiles of 256 x 256 on) against torch on the operands the kernel sees, and against the 8-phase kernel
-    it replaced (dev build, GSL_O4=0): same products, another summation order — equal within f32 accumulation noise, i.e. almost always the
-    same 16-bit value. Ragged last M tile (33490 = 130 x 256 + 210), K segments, bias, alpha, the consumer-side LayerNorm, the head-major
+    """The overlap GEMM (csrc/gemm_o4.inc: 4-wave workgroups on 256 x 128 tiles of v_mfma_f32_32x32x16, two resident per CU — a measured alternative
+    in the dev build, GSL_O4=1, for the 8-phase class) against torch on the operands the kernel sees, and against the product's 8-phase kernel:
+    same products, another summation order — equal within f32 accumulation noise, i.e. almost always the same 16-bit value. Ragged last M tile (33490 = 130 x 256 + 210), K segments, bias, alpha, the consumer-side LayerNorm, the head-major
     QKV copy-out, strided operand views. Reference: F.linear of vit_pytorch_face/vit_face.py:349-356."""
     from gslora_hip import _lib as L
     g = torch.Generator().manual_seed(11)
@@ -1434,27 +1433,24 @@ def test_gemm_o4_overlap_kernel_store(ops, dev_lib, monkeypatch, M, N, K1, K2, T
         A, ref = A[:M], _to_head_major(ref[:M], M // T, T, N // 192)
         if "ln" in mode:
             kw["pos"], kw["cls"] = kw["pos"][:M].contiguous(), kw["cls"][:M].contiguous()
+    old = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(A, W, old, epilogue=epi, T=T, **kw)            # product library: the 8-phase kernel
+    dev_lib(L)
+    monkeypatch.setenv("GSL_O4", "1")
     out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
-    ops.gemm_nt(A, W, out, epilogue=epi, T=T, **kw)            # product library: the overlap kernel
+    ops.gemm_nt(A, W, out, epilogue=epi, T=T, **kw)            # dev build, GSL_O4=1: the overlap kernel
     eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
     assert torch.isfinite(out.float()).all()
     assert ((out.double() - ref).abs() <= eps * ref.abs() + 2e-3).all(), float((out.double() - ref).abs().max())
-    dev_lib(L)
-    monkeypatch.setenv("GSL_O4", "0")
-    old = torch.empty(M, N, device="cuda", dtype=dt)
-    ops.gemm_nt(A, W, old, epilogue=epi, T=T, **kw)            # dev build, GSL_O4=0: the 8-phase kernel
+    assert (old != out).any()                                  # (the knob took: another summation order)
     assert (old != out).float().mean() < 0.03 and ((old.float() - out.float()).abs() <= 2 * eps * ref.abs().float() + 2e-3).all()
-    monkeypatch.setenv("GSL_O4", "1")
-    again = torch.empty(M, N, device="cuda", dtype=dt)
-    ops.gemm_nt(A, W, again, epilogue=epi, T=T, **kw)          # dev build of the overlap kernel: bit-identical to the product's
-    assert torch.equal(again, out)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K1,K2,p", [(33490, 2048, 512, 64, 0.1), (33490, 512, 512, 0, 0.0), (201728, 2048, 512, 64, 0.1), (40000, 1024, 64, 64, 0.25)])
 def test_gemm_o4_overlap_kernel_fused_ffn1(ops, dev_lib, monkeypatch, M, N, K1, K2, p, dt):
-    """BIAS_GELU_G8 on the overlap GEMM (the fused FFN1 of the benchmark: bias + table GELU + 8-bit GELU' code + dropout, two outputs) against the
-    8-phase kernel's epilogue (dev build, GSL_O4=0): the SAME dropout mask (dropped elements exactly 0 / code 26 in both), h within one 16-bit
+    """BIAS_GELU_G8 on the overlap GEMM (dev build, GSL_O4=1; the fused FFN1 of the benchmark: bias + table GELU + 8-bit GELU' code + dropout, two
+    outputs) against the product's 8-phase kernel: the SAME dropout mask (dropped elements exactly 0 / code 26 in both), h within one 16-bit
     ulp + the table step where the f32 sums differ in the last bits, codes equal or one step apart; and against GELU in f64 on the operands the
     kernel sees. Reference: vit_pytorch_face/vit_face.py:326-338."""
     from gslora_hip import _lib as L
@@ -1465,6 +1461,10 @@ def test_gemm_o4_overlap_kernel_fused_ffn1(ops, dev_lib, monkeypatch, M, N, K1, 
         a2 = rnd(M, K2, seed=3); a2[:, 8:] = 0
         A2, W2 = c(a2), c(rnd(N, K2, seed=4, scale=0.1))
     bias = rnd(N, seed=5).cuda()
+    h0 = torch.empty(M, N, device="cuda", dtype=dt); q0 = torch.full((M, N), 255, device="cuda", dtype=torch.uint8)
+    ops.gemm_nt(A1, W1, h0, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q0, p_drop=p, seed=7, site=5)      # product: the 8-phase kernel
+    dev_lib(L)
+    monkeypatch.setenv("GSL_O4", "1")
     h1 = torch.full((M, N), float("nan"), device="cuda", dtype=dt); q1 = torch.full((M, N), 255, device="cuda", dtype=torch.uint8)
     ops.gemm_nt(A1, W1, h1, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q1, p_drop=p, seed=7, site=5)
     keep = ops.dropout_mask(M * N, p, 7, 5, "cuda").reshape(M, N).bool() if p > 0 else torch.ones(M, N, device="cuda", dtype=torch.bool)
@@ -1484,11 +1484,8 @@ def test_gemm_o4_overlap_kernel_fused_ffn1(ops, dev_lib, monkeypatch, M, N, K1, 
         assert ((h1[sl].double() - want_h).abs() - eps * want_h.abs()).max().item() <= tab + 1e-3
         dec = (qr[sl].double() - 26.0) * (0.005 / (1 - p))
         assert (dec - want_g).abs().max().item() <= (half + gtab) * 1.05 + 1e-3
-    dev_lib(L)
-    monkeypatch.setenv("GSL_O4", "0")
-    h0 = torch.empty(M, N, device="cuda", dtype=dt); q0 = torch.full((M, N), 255, device="cuda", dtype=torch.uint8)
-    ops.gemm_nt(A1, W1, h0, epilogue=L.EPI_BIAS_GELU_G8, A2=A2, W2=W2, bias=bias, out2=q0, p_drop=p, seed=7, site=5)
     q0 = _unslab(q0)
+    assert (h0 != h1).any()
     assert torch.equal(q0 == 26, qr == 26) or ((q0 == 26) != (qr == 26)).float().mean() < 1e-3      # (a kept element may also code to 26: GELU' = 0)
     assert ((q0.int() - qr.int()).abs() <= 1).all() and (q0 != qr).float().mean() < 0.02
     assert (h0 != h1).float().mean() < 0.05 and ((h0.float() - h1.float()).abs() <= 2 * eps * h0.float().abs() + 2 * tab).all()

@@ -5,7 +5,6 @@ epilogue done). GSL_O4_DELAY=<cycles> sets the out-of-phase start of the second 
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gs-lora_amd")]
-os.environ["GSLORA_HIP_LIB"] = os.path.join(ROOT, "gs-lora_amd", "gslora_hip", "libgslora_hip_dev.so")
 import torch
 from gslora_hip import _lib as L, ops
 M = int(os.environ.get("M", 201728))
@@ -28,26 +27,33 @@ for name, N, K, K2, kind in SHAPES:
     else:
         call = lambda: ops.gemm_nt(A, W, out, epilogue=L.EPI_STORE)
     flops = 2.0 * M * N * (K + (8 if K2 else 0))
-    variants = [("8-wave 8-phase", "0", 0)] + [(f"overlap 4-wave x2, delay {dl}", "1", dl) for dl in delays]
+    # the 8-phase kernel and the stamped overlap kernel run from the dev build; "product" = the overlap kernel of the product library (the dev
+    # build's ablation branches sit inside its pinned MFMA groups and cost it ~15 %)
+    variants = [("8-wave 8-phase", "0", 0)] + [(f"overlap 4-wave x2, delay {dl} (dev build)", "1", dl) for dl in delays] 
     res = {v[0]: [] for v in variants}
     stamps = {}
     for rnd_ in range(3):
         for vname, o4, dl in variants:
             os.environ["GSL_O4"] = o4; os.environ["GSL_O4_DELAY"] = str(dl)
-            for _ in range(2):
-                dbg.zero_(); call()
-            torch.cuda.synchronize()
-            st = dbg.cpu().view(-1, 4); st = st[(st != 0).all(1)]
-            stamps[vname] = st
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                call()
-            e1.record(); torch.cuda.synchronize()
+            import contextlib
+            with (contextlib.nullcontext() if o4 == "P" else L.use_dev()):
+                for _ in range(2):
+                    dbg.zero_(); call()
+                torch.cuda.synchronize()
+                st = dbg.cpu().view(-1, 4); st = st[(st != 0).all(1)]
+                stamps[vname] = st
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    call()
+                e1.record(); torch.cuda.synchronize()
             res[vname].append(e0.elapsed_time(e1) / 5 * 1e3)
     for vname, _, _ in variants:
         st = stamps[vname]
-        d = (st[:, 1:] - st[:, :-1]).double(); tot = (st[:, 3] - st[:, 0]).double()
         t = sorted(res[vname])[1]
+        if st.shape[0] == 0:
+            print(f"| {name} | {vname} | {t:.0f} us ({min(res[vname]):.0f} - {max(res[vname]):.0f}) | {flops / t / 1e6:.0f} TF/s = {flops / t / 1e6 / 2500:.3f} | (no stamps) |", flush=True)
+            continue
+        d = (st[:, 1:] - st[:, :-1]).double(); tot = (st[:, 3] - st[:, 0]).double()
         print(f"| {name} | {vname} | {t:.0f} us ({min(res[vname]):.0f} - {max(res[vname]):.0f}) | {flops / t / 1e6:.0f} TF/s = {flops / t / 1e6 / 2500:.3f} | {st.shape[0]} wgs: prologue {d[:, 0].median():.0f}, "
               f"K loop {d[:, 1].median():.0f}, epilogue {d[:, 2].median():.0f}, total {tot.median():.0f} cycles |", flush=True)
