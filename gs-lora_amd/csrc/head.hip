@@ -171,12 +171,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < n_amax; i += 256) am = fmaxf(am, amax_in[i]);
     __shared__ float sma[16];
     am = block_max(am, sma);
+    // the exponent in use: gscale[3], settled by pass 1 (overflow guard, see below); a caller without the guard's state passes target_exp alone
+    const int tex = gscale_out ? (int)gscale_out[3] : target_exp;
     if (am > 0.f && am < 3.0e38f) {
       int ex;
       (void)frexpf(am, &ex);                 // am = m 2^ex, m in [0.5, 1)
-      gs = ldexpf(1.0f, min(max(target_exp - ex, -60), 60));
+      gs = ldexpf(1.0f, min(max(tex - ex, -60), 60));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && gscale_out) { gscale_out[0] = gs; gscale_out[1] = 1.0f / gs; }
+  }
+  // Overflow guard (round 6): pass 1's block 0 settles the exponent E of THIS backward from what the PREVIOUS one saw — gscale[2] = the largest
+  // |scaled gradient| its LayerNorm backwards read or stored: saturated (>= 65504) or non-finite -> E - 2 (floor 4); below 2^9 and E under the
+  // target -> E + 1; E outside [4, 15] (a freshly zeroed buffer) -> the target — and clears gscale[2] for this backward. Pass 2 (a later launch)
+  // reads E from gscale[3]. No host sync; replays of a captured graph carry the state in the buffer.
+  if (amax_out && gscale_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float seen = gscale_out[2];
+    int E = (int)gscale_out[3];
+    if (!(gscale_out[3] >= 4.0f && gscale_out[3] <= 15.0f)) E = target_exp;
+    else if (!(seen < 65504.0f)) E = max(E - 2, 4);
+    else if (seen < 512.0f && seen > 0.f && E < target_exp) E = E + 1;
+    gscale_out[3] = (float)E;
+    gscale_out[2] = 0.0f;
   }
   __shared__ float de[HEAD_MAXD];   // d emb
   __shared__ float dl[1024];        // s * dlogits row (C <= 1024)
@@ -272,12 +287,14 @@ constexpr int GSL_GRAD_TARGET_EXP = 11;
 extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const void* x, int x_dtype, int T, const float* gamma,
                             const float* mean, const float* rstd, const float* emb, const float* Wn, void* dx, void* dxb,
                             int B, int D, int C, float cos_s, int dtype, int stream_dtype, float p_drop, uint64_t seed, uint32_t site,
-                            int linear_head, int pool_mean, int compact, float* gscale, float* amax_ws, gsl_stream_t s) {
+                            int linear_head, int pool_mean, int compact, float* gscale, float* amax_ws, int target_exp, gsl_stream_t s) {
   GSL_CHECK_ARG(x && gamma && mean && rstd && emb && dx && B > 0 && T >= 1, "null/size");
   GSL_CHECK_ARG(D > 0 && D <= HEAD_MAXD && (D % 4) == 0 && C <= 1024, "D <= 1024, D%4==0, C <= 1024");
   GSL_CHECK_ARG(!dlogits || Wn, "Wn required with dlogits");
   GSL_CHECK_ARG(!(compact && pool_mean), "compact cls-row gradients need pool = 'cls'");
   GSL_CHECK_ARG(!gscale || amax_ws, "gscale (loss-scaled gradients) needs amax_ws [B]");
+  GSL_CHECK_ARG(target_exp == 0 || (target_exp >= 4 && target_exp <= 15), "target_exp: 0 (default 11) or 4 .. 15");
+  const int texp = target_exp ? target_exp : GSL_GRAD_TARGET_EXP;
   const DropCfg drop = make_drop(p_drop, seed, site);
   GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == dtype && dtype != GSL_F32), "stream dtype (f32, or the operand format of a 16-bit mode)");
   GSL_CHECK_ARG(x_dtype == GSL_F32 || ((x_dtype == GSL_BF16 || x_dtype == GSL_F16) && dtype == GSL_BF16) || (x_dtype == GSL_F16 && dtype == GSL_F16),
@@ -287,10 +304,10 @@ extern "C" int gsl_head_bwd(const float* dlogits, const float* demb, const void*
     if (gscale)                                                                                                                     \
       hipLaunchKernelGGL((head_bwd_kernel<T_, S_, X_>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, (const X_*)x, T, gamma, mean, \
                          rstd, emb, Wn, (S_*)dx, (T_*)dxb, D, C, cos_s, drop, linear_head, pool_mean, compact, amax_ws, (const float*)nullptr, 0, \
-                         (float*)nullptr, 0);                                                                                       \
+                         gscale, texp);                                                                                             \
     hipLaunchKernelGGL((head_bwd_kernel<T_, S_, X_>), dim3(B), dim3(256), 0, as_stream(s), dlogits, demb, (const X_*)x, T, gamma, mean, \
                        rstd, emb, Wn, (S_*)dx, (T_*)dxb, D, C, cos_s, drop, linear_head, pool_mean, compact, (float*)nullptr,       \
-                       (const float*)(gscale ? amax_ws : nullptr), B, gscale, GSL_GRAD_TARGET_EXP);                                 \
+                       (const float*)(gscale ? amax_ws : nullptr), B, gscale, texp);                                 \
   } while (0)
   if (dtype == GSL_F16 && stream_dtype == GSL_F16 && x_dtype == GSL_F16) GSL_HB(f16_t, f16_t, f16_t);
   else if (dtype == GSL_F16 && stream_dtype == GSL_F16) GSL_HB(f16_t, f16_t, float);

@@ -613,8 +613,9 @@ extern "C" int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const
 // =====================================================================================
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2_sqrt) {
+                                                    float wd, float bc1, float bc2_sqrt, const float* __restrict__ guard) {
   fp16_sat_on();
+  if (guard && !(*guard < 65504.0f)) return;      // a gradient of this step was clipped by a saturating fp16 store (or is not finite): skip the update
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i];
@@ -630,8 +631,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // HIP-graph form: the step count and the learning rate live in device memory (a captured graph replays with fresh values)
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1,
-                                                        float b2, float eps, float wd, const int64_t* __restrict__ step_dev) {
+                                                        float b2, float eps, float wd, const int64_t* __restrict__ step_dev,
+                                                        const float* __restrict__ guard) {
   fp16_sat_on();
+  if (guard && !(*guard < 65504.0f)) return;
   const double t = (double)*step_dev;
   const float lr = *lr_dev;
   const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
@@ -647,21 +650,21 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
   }
 }
 extern "C" int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1,
-                                  float beta2, float eps, float wd, const int64_t* step_dev, gsl_stream_t s) {
+                                  float beta2, float eps, float wd, const int64_t* step_dev, const float* guard, gsl_stream_t s) {
   GSL_CHECK_ARG(p && g && m && v && n > 0 && lr_dev && step_dev, "null/size");
   const int grid = (int)min((n + 255) / 256, (long)(256 * 8));
-  hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid), dim3(256), 0, as_stream(s), p, g, m, v, n, lr_dev, beta1, beta2, eps, wd, step_dev);
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid), dim3(256), 0, as_stream(s), p, g, m, v, n, lr_dev, beta1, beta2, eps, wd, step_dev, guard);
   return check_launch("gsl_adamw_flat_dev");
 }
 
 extern "C" int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                              float eps, float wd, int step, gsl_stream_t s) {
+                              float eps, float wd, int step, const float* guard, gsl_stream_t s) {
   GSL_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "null/size/step");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int grid = (int)min((n + 255) / 256, (long)(256 * 8));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps, wd, (float)bc1,
-                     (float)sqrt(bc2));
+                     (float)sqrt(bc2), guard);
   return check_launch("gsl_adamw_flat");
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const S* dres,
                                                      S* dx, long ios, T* __restrict__ dxb, int M, DropCfg drop,
-                                                     long drop_row_stride, int cls_T) {
+                                                     long drop_row_stride, int cls_T, float* gmax) {
   fp16_sat_on();
   resolve_drop(drop);
   constexpr int D = NPL * 64;
@@ -84,12 +84,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int wpb = blockDim.x >> 6;
   float g[NPL];
   IO::load(gamma, lane, g);
+  float am = 0.f;      // overflow guard: largest |dy| read and |dx| stored by this wave (gmax != nullptr)
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
     float xv[NPL], gy[NPL];
     IO::load(x + (size_t)row * xs, lane, xv);
     IO::load(dy + (size_t)row * D, lane, gy);
     const float mu = mean[row], rs = rstd[row];
     float s1 = 0.f, s2 = 0.f;
+    if (gmax) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) am = fmaxf(am, fabsf(gy[i]));
+    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       xv[i] = (xv[i] - mu) * rs;   // x-hat
@@ -105,6 +110,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       IO::load(dres + (size_t)(cls_T ? row / cls_T : row) * ios, lane, r);
 #pragma unroll
       for (int i = 0; i < NPL; ++i) gy[i] += r[i];
+    }
+    if (gmax) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) am = fmaxf(am, fabsf(gy[i]));
     }
     IO::store(dx + (size_t)row * (cls_T ? (long)D : ios), lane, gy);
     if (dxb) {
@@ -123,6 +132,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
       IO::store(dxb + (size_t)row * D, lane, gy);
     }
+  }
+  if (gmax) {      // non-negative floats order like their bit patterns; the plain read keeps the atomics to the few waves that raise the maximum
+    am = wave_max(am);
+    if (lane == 0 && !(am <= *gmax)) atomicMax(reinterpret_cast<unsigned int*>(gmax), __float_as_uint(am));
   }
 }
 
@@ -145,11 +158,11 @@ static int ln_fwd_launch(const void* x, long xs, const float* gamma, const float
 template <int NPL>
 static int ln_bwd_launch(const void* dy, const void* x, long xs, const float* gamma, const float* mean, const float* rstd,
                          const void* dres, void* dx, long ios, void* dxb, int M, int dtype, int sdtype, int xdtype, DropCfg drop, long drs,
-                         int cls_T, hipStream_t st) {
+                         int cls_T, float* gmax, hipStream_t st) {
   const int grid = min((M + 3) / 4, 256 * 8);
 #define GSL_LNB(T, S, X)                                                                                                            \
   hipLaunchKernelGGL((ln_bwd_kernel<NPL, T, S, X>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const X*)x, xs, gamma, mean, rstd, \
-                     (const S*)dres, (S*)dx, ios, (T*)dxb, M, drop, drs, cls_T)
+                     (const S*)dres, (S*)dx, ios, (T*)dxb, M, drop, drs, cls_T, gmax)
   if (dtype == GSL_F16 && sdtype == GSL_F16 && xdtype == GSL_F16) GSL_LNB(f16_t, f16_t, f16_t);      // fp16 operands: loss-scaled gradients
   else if (dtype == GSL_F16 && sdtype == GSL_F16) GSL_LNB(f16_t, f16_t, float);
   else if (dtype == GSL_F16 && xdtype == GSL_F16) GSL_LNB(f16_t, float, f16_t);
@@ -291,7 +304,7 @@ extern "C" int gsl_layernorm_fwd(const void* x, long x_row_stride, const float* 
 extern "C" int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_stride, const float* gamma, const float* mean,
                                  const float* rstd, const void* dres, void* dx, long io_row_stride, void* dxb, int M, int D,
                                  int dtype, int stream_dtype, int x_dtype, float p_drop, uint64_t seed, uint32_t site,
-                                 long drop_row_stride, int dres_cls_T, gsl_stream_t s) {
+                                 long drop_row_stride, int dres_cls_T, float* gmax, gsl_stream_t s) {
   GSL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && M > 0, "null/size");
   GSL_CHECK_ARG(dtype == GSL_F32 || dtype == GSL_BF16 || dtype == GSL_F16, "dtype");
   GSL_CHECK_ARG(stream_dtype == GSL_F32 || (stream_dtype == dtype && dtype != GSL_F32), "stream dtype (f32, or the operand format of a 16-bit mode)");
@@ -302,7 +315,7 @@ extern "C" int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_strid
   const DropCfg drop = make_drop(p_drop, seed, site);
   const long ios = io_row_stride > 0 ? io_row_stride : D, drs = drop_row_stride > 0 ? drop_row_stride : D;
   GSL_CHECK_ARG((ios % 4) == 0, "io row stride alignment");
-#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, x_dtype, drop, drs, dres_cls_T, as_stream(s))
+#define CALL(N) ln_bwd_launch<N>(dy, x, x_row_stride, gamma, mean, rstd, dres, dx, ios, dxb, M, dtype, stream_dtype, x_dtype, drop, drs, dres_cls_T, gmax, as_stream(s))
   GSL_DISPATCH_D(D, CALL)
 #undef CALL
 }

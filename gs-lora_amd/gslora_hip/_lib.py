@@ -38,7 +38,7 @@ SIGNATURES = {
                                  _vp, _i, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _vp, _i, _f, _i, _vp, _vp],
     "gsl_layernorm_fwd": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gsl_layernorm_fwd_lora": [_vp, _l, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
-    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp],
+    "gsl_layernorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _f, _u64, _u32, _l, _i, _vp, _vp],
     "gsl_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
     "gsl_attention_fwd_cls": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp],
@@ -49,7 +49,7 @@ SIGNATURES = {
     "gsl_lora_grad_batch": [_vp, _i, _vp, _i, _vp, _vp],
     "gsl_cosface_prep": [_vp, _vp, _i, _i, _vp],
     "gsl_head_fwd": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
-    "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp, _vp, _vp],
+    "gsl_head_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f, _u64, _u32, _i, _i, _i, _vp, _vp, _i, _vp],
     "gsl_ce_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gsl_ce_bwd": [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
     "gsl_proto_kl_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -60,8 +60,8 @@ SIGNATURES = {
     "gsl_proto_kl_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "gsl_group_norms_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gsl_group_norms_bwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp],
-    "gsl_adamw_flat": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp],
-    "gsl_adamw_flat_dev": [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp],
+    "gsl_adamw_flat": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _vp],
+    "gsl_adamw_flat_dev": [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp, _vp],
     "gsl_cast": [_vp, _vp, _l, _i, _vp],
     "gsl_transpose_cast": [_vp, _vp, _i, _i, _i, _vp],
     "gsl_pack_pad": [_vp, _l, _l, _i, _i, _f, _vp, _i, _i, _i, _vp],

@@ -192,8 +192,8 @@ def layernorm_fwd_lora(x, row_stride, M, D, gamma, beta, eps, P, alpha, pad=64):
 
 @_profiled("ln_bwd", lambda dy, *a, **k: (dy.shape[0], dy.shape[1], 0, 0))
 def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_drop=0.0, seed=0, site=0, dx=None,
-                  io_row_stride=0, drop_row_stride=0, dres_cls_T=0):
-    """dx = dres + LN'(dy). With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the
+                  io_row_stride=0, drop_row_stride=0, dres_cls_T=0, gmax=None):
+    """dx = dres + LN'(dy). gmax: f32 device element (gscale[2:] of head_bwd) raised to the largest |dy| read / |dx| stored: the overflow guard. With dx given (and io_row_stride), the rows of an existing buffer are updated in place. The dtype of the
     residual-gradient stream (dres / dx: f32, or bf16 in bf16 mode) is taken from dres / dx, the dtype of the saved forward stream from x.
     dres_cls_T > 0: dres holds the cls rows only ([M / T, D]); the other rows of the incoming stream gradient are zero."""
     _need(dy, x, gamma, mean, rstd)
@@ -211,7 +211,7 @@ def layernorm_bwd(dy, x, row_stride, gamma, mean, rstd, dres, want_copy=True, p_
     dxb = torch.empty(M, D, device=dy.device, dtype=dy.dtype) if (want_copy and not alias) else None
     L.check(L.load().gsl_layernorm_bwd(_p(dy), _p(x), row_stride, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
                                        int(io_row_stride), _p(dxb), M, D, code(dy.dtype), code(sdt), code(x.dtype), float(p_drop),
-                                       int(seed), int(site), int(drop_row_stride), int(dres_cls_T), _stream()), "gsl_layernorm_bwd")
+                                       int(seed), int(site), int(drop_row_stride), int(dres_cls_T), _p(gmax), _stream()), "gsl_layernorm_bwd")
     return dx, (dx if alias else dxb)
 
 
@@ -383,11 +383,15 @@ def head_fwd(x, B, T, D, gamma, beta, eps, Wn, label, cos_s, cos_m, head_bias=No
 
 
 def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype, p_drop=0.0, seed=0, site=0, linear=False,
-             pool_mean=False, stream_dtype=torch.float32, compact=False, gscale=None):
+             pool_mean=False, stream_dtype=torch.float32, compact=False, gscale=None, target_exp=0):
     """compact (pool='cls' only): dx / dxb are [B, D] — the cls rows alone, nothing zero-filled.
-    gscale: f32 [2] device tensor -> loss-scaled gradients (fp16 operands): dx / dxb come out multiplied by the power of two S the
-    kernel picks from their largest magnitude, and gscale receives {S, 1/S} for the LoRA-gradient reductions (gsl_head_bwd)."""
+    gscale: f32 [4] device tensor that persists across steps (zeroed once) -> loss-scaled gradients (fp16 operands): dx / dxb come out
+    multiplied by the power of two S the kernel picks from their largest magnitude; gscale receives {S, 1/S} for the LoRA-gradient
+    reductions, [2] is cleared for the overflow guard of this backward (layernorm_bwd(gmax=gscale[2:])) and [3] carries the exponent in use
+    (gsl_head_bwd). target_exp: 0 = the default 11."""
     _need(dlogits, demb, x, gamma, mean, rstd, emb, Wn, gscale)
+    if gscale is not None and (gscale.numel() < 4 or gscale.dtype != torch.float32):
+        raise RuntimeError("head_bwd: gscale must be a float32 tensor of 4 elements {S, 1/S, seen maximum, exponent}")
     amax_ws = torch.empty(B, device=x.device, dtype=torch.float32) if gscale is not None else None
     rows = B if compact else B * T
     dx = torch.empty(rows, D, device=x.device, dtype=stream_dtype)
@@ -395,7 +399,7 @@ def head_bwd(dlogits, demb, x, B, T, D, gamma, mean, rstd, emb, Wn, cos_s, dtype
     C = Wn.shape[0] if Wn is not None else 0
     L.check(L.load().gsl_head_bwd(_p(dlogits), _p(demb), _p(x), code(x.dtype), T, _p(gamma), _p(mean), _p(rstd), _p(emb), _p(Wn), _p(dx),
                                   _p(dxb), B, D, C, float(cos_s), code(dtype), code(stream_dtype), float(p_drop), int(seed), int(site),
-                                  1 if linear else 0, 1 if pool_mean else 0, 1 if compact else 0, _p(gscale), _p(amax_ws), _stream()),
+                                  1 if linear else 0, 1 if pool_mean else 0, 1 if compact else 0, _p(gscale), _p(amax_ws), int(target_exp), _stream()),
             "gsl_head_bwd")
     return dx, dxb
 
@@ -458,17 +462,18 @@ def group_norms_bwd(flat, toff, tnumel, tgroup, group_norm, coef, scale, gradfla
                                          float(scale), _p(gradflat), _stream()), "gsl_group_norms_bwd")
 
 
-def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step):
-    _need(p, g, m, v)
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, guard=None):
+    """guard: f32 device element (gscale[2:] of the backward that produced g): the update is skipped when it holds >= 65504 or a non-finite value."""
+    _need(p, g, m, v, guard)
     L.check(L.load().gsl_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                                    float(wd), int(step), _stream()), "gsl_adamw_flat")
+                                    float(wd), int(step), _p(guard), _stream()), "gsl_adamw_flat")
 
 
-def adamw_flat_dev(p, g, m, v, lr_dev, b1, b2, eps, wd, step_dev):
+def adamw_flat_dev(p, g, m, v, lr_dev, b1, b2, eps, wd, step_dev, guard=None):
     """Same update with the step count (int64) and learning rate (f32) read from device memory (HIP-graph replays)."""
-    _need(p, g, m, v, lr_dev, step_dev)
+    _need(p, g, m, v, lr_dev, step_dev, guard)
     L.check(L.load().gsl_adamw_flat_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), float(b1), float(b2), float(eps), float(wd),
-                                        _p(step_dev), _stream()), "gsl_adamw_flat_dev")
+                                        _p(step_dev), _p(guard), _stream()), "gsl_adamw_flat_dev")
 
 
 def cast(x, dtype):

@@ -20,6 +20,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = {}
         self.graph_mode = False     # set by gslora_hip.step.GraphedStep: step count / lr are read from device memory
+        # fp16 operands: a device float (ViTRunner.overflow_guard()) — step() leaves p / m / v untouched when it holds >= 65504 or a non-finite
+        # value (a gradient store of this step's loss-scaled backward saturated); armed per step by gslora_hip.step.gs_lora_step
+        self.overflow_guard = None
 
     # ---- HIP-graph support: a captured step() must not bake the step count (bias corrections) or the lr into the graph
     def graph_sync(self):
@@ -154,12 +157,12 @@ class FusedAdamW(torch.optim.Optimizer):
             if ent["ok"] and self.graph_mode:      # being captured: counters on the device, host bookkeeping in graph_replayed()
                 ent["step_dev"].add_(1)
                 ops.adamw_flat_dev(ent["p"], ent["g"], ent["m"], ent["v"], ent["lr_dev"], b1, b2, group["eps"],
-                                   group["weight_decay"], ent["step_dev"])
+                                   group["weight_decay"], ent["step_dev"], guard=self.overflow_guard)
                 continue
             if ent["ok"]:
                 ent["step"] += 1
                 ops.adamw_flat(ent["p"], ent["g"], ent["m"], ent["v"], group["lr"], b1, b2, group["eps"],
-                               group["weight_decay"], ent["step"])
+                               group["weight_decay"], ent["step"], guard=self.overflow_guard)
                 for p in ent["order"]:      # the kernel wrote through raw pointers: tell torch (and the
                     torch.autograd.graph.increment_version(p)   # runner's operand caches) the data changed
                 continue
@@ -173,7 +176,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         st["m"].copy_(ld["exp_avg"].to(p.device)); st["v"].copy_(ld["exp_avg_sq"].to(p.device))
                 st["step"] += 1
                 ops.adamw_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["m"].view(-1), st["v"].view(-1),
-                               group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
+                               group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"], guard=self.overflow_guard)
                 torch.autograd.graph.increment_version(p)
         return loss
 

@@ -178,6 +178,19 @@ class _EagerComm:
         return _OverlappedBucketReduce(net, backend, overlap)
 
 
+def _arm_overflow_guard(net, optimizer):
+    """fp16 operands: hand the optimizer the overflow guard of the backward that just ran (ViTRunner.overflow_guard(): the device float the
+    LayerNorm backwards raised to the largest scaled gradient they saw) — FusedAdamW then skips the update of a step in which a 16-bit gradient
+    store saturated (torch.cuda.amp.GradScaler.step semantics, no host sync); the next backward lowers its loss scale on the device. Under
+    data parallelism every rank keeps its own guard and scale, and a skip would have to be agreed on: there the update is NOT skipped (the
+    guard still lowers the rank's next scale, and ViTRunner.gscale shows it)."""
+    if not hasattr(optimizer, "overflow_guard"):
+        return
+    runner = getattr(net, "_runner", None)
+    g = runner.overflow_guard() if runner is not None and hasattr(runner, "overflow_guard") else None
+    optimizer.overflow_guard = None if _dp_active() else g
+
+
 def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
                  group_type="block", use_prototype=False, proto_table=None, w_f=0.0, w_r=0.0, BND_pro=0.0,
                  backend=HipBackend, fuse_batches=True, _comm=_EagerComm):
@@ -228,6 +241,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
             roots.append(structure)
             grads.append(coefs[4])
         torch.autograd.backward(roots, grads)
+        _arm_overflow_guard(net, optimizer)
         optimizer.step()
         return meters
     if split is not None:
@@ -255,6 +269,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
                                         w_f, w_r, BND_pro)
         optimizer.zero_grad()
         total.backward()
+        _arm_overflow_guard(net, optimizer)
         optimizer.step()
         return meters
     # data parallel: the eight batch sums travel in ONE packed all-reduce, so the hinges see the GLOBAL batch means. Every entry is
@@ -274,6 +289,7 @@ def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha
         reducer.cancel()
         raise
     reducer.finish()
+    _arm_overflow_guard(net, optimizer)
     optimizer.step()
     return meters
 

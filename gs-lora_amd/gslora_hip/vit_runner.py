@@ -54,6 +54,11 @@ INK_MIN_ROWS = 8192
 # the stream x itself with gamma folded into the weight and finishes the normalisation in its epilogue (EPI_STORE_LN); LayerNorm 1 shrinks to
 # its row statistics (one read of x, no LN(x) tensor). GSLORA_LN1_FOLD=0: the LayerNorm kernel + plain GEMM of rounds 1 - 4.
 LN1_FOLD = os.environ.get("GSLORA_LN1_FOLD", "1") != "0"
+# fp16 operands: exponent of the loss-scaled backward — gsl_head_bwd picks the power of two S with S * max|head gradient| in [2^(E-1), 2^E)
+# (0 = the library default 11: 32x headroom below 65504 at the head; the overflow guard lowers E on the device when a store saturates)
+GRAD_TARGET_EXP = int(os.environ.get("GSLORA_GRAD_TARGET_EXP", "0"))
+if GRAD_TARGET_EXP and not 4 <= GRAD_TARGET_EXP <= 15:
+    raise ValueError(f"GSLORA_GRAD_TARGET_EXP={GRAD_TARGET_EXP}: 0 (default) or 4 .. 15")
 INK_SMALL = True      # the in-kernel form on the small-tile kernel (few rows)
 # The LoRA-gradient reductions of a backward pass that do not ride in the FFN2-dX epilogue are collected and issued as ONE batched pair of
 # launches (gsl_lora_grad_batch) instead of two to three launches each; their operands stay alive until the end of the backward (or until
@@ -180,9 +185,30 @@ class ViTRunner:
         self.drop_seed = self._initial_drop_seed()
         self.drop_calls = 0
         self.grad_hook = None     # callable(layer) invoked when the LoRA gradients of `layer` are complete (data-parallel overlap, step.py)
+        # fp16 operands: {S, 1/S, largest scaled gradient the LayerNorm backwards of the last backward saw, exponent in use} — device-resident
+        # state of the loss scale and its overflow guard (gsl_head_bwd); persists across steps and HIP-graph replays
+        self.gscale = None
+        self._guard_on = False
 
     def __deepcopy__(self, memo):   # copies of the model build their own runner lazily
         return None
+
+    def _loss_scale_state(self, device):
+        if self.gscale is None or self.gscale.device != device:
+            self.gscale = torch.zeros(4, device=device, dtype=torch.float32)
+        return self.gscale
+
+    def overflow_guard(self):
+        """The device float FusedAdamW checks before it updates (None unless the last backward ran on loss-scaled fp16 gradients)."""
+        return self.gscale[2:] if (self._guard_on and self.gscale is not None) else None
+
+    def loss_scale_report(self):
+        """Host read (one sync) of the loss-scale state after a backward: S, the exponent in use, the largest scaled gradient the LayerNorm
+        backwards saw and the headroom 65504 / that (< = 1: a 16-bit store saturated, the optimizer skipped the step)."""
+        if self.gscale is None:
+            return None
+        S, _, seen, E = self.gscale.tolist()
+        return {"S": S, "exponent": int(E), "seen_max": seen, "headroom": (65504.0 / seen) if seen > 0 else float("inf"), "saturated": not seen < 65504.0}
 
     @staticmethod
     def _initial_drop_seed():
@@ -574,12 +600,14 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         # fp16 operands: the backward runs on loss-scaled gradients — gsl_head_bwd picks the power of two S on the device and writes
         # {S, 1/S} here; every LoRA-gradient reduction below multiplies by 1/S on the way out (bf16 / f32: no scaling)
-        gscale = torch.empty(2, device=saved["x_last"].device, dtype=torch.float32) if dt == torch.float16 else None
+        gscale = self._loss_scale_state(saved["x_last"].device) if dt == torch.float16 else None
+        self._guard_on = gscale is not None
+        gmax = gscale[2:] if gscale is not None else None      # the overflow guard: raised by every LayerNorm backward below
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
                                stream_dtype=dt if (dt in OP16 and GRAD_STREAM_BF16) else torch.float32,
-                               compact=(sp.pool == "cls"), gscale=gscale)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
+                               compact=(sp.pool == "cls"), gscale=gscale, target_exp=GRAD_TARGET_EXP)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         blocks = sp.blocks
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
@@ -667,10 +695,10 @@ class ViTRunner:
             if sparse and not tail:   # compact in, compact out: the cls rows of x1 are T*D apart, the dropout counters are those of the dense tensor
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
                                               cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx,
-                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D, gmax=gmax)
             else:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
-                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, gmax=gmax)
             del dxn2
             # ---- attention sub-layer: x1 = x + drop(Wo o + bo) -------------------------------------
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
@@ -696,7 +724,7 @@ class ViTRunner:
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
                                         p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag,
-                                        dres_cls_T=T if sparse else 0)      # after the cls-row-only block dx1 is compact [B, D]
+                                        dres_cls_T=T if sparse else 0, gmax=gmax)      # after the cls-row-only block dx1 is compact [B, D]
             saved["layers"][i] = None   # free this layer's activations
         if not torch.cuda.is_current_stream_capturing():
             self.build_pack_tables(dt)    # every pack of the step is registered now: the next forward refreshes them in one launch
@@ -722,12 +750,14 @@ class ViTRunner:
             raise RuntimeError("backward through logits requires a forward with labels")
         # fp16 operands: the backward runs on loss-scaled gradients — gsl_head_bwd picks the power of two S on the device and writes
         # {S, 1/S} here; every LoRA-gradient reduction below multiplies by 1/S on the way out (bf16 / f32: no scaling)
-        gscale = torch.empty(2, device=saved["x_last"].device, dtype=torch.float32) if dt == torch.float16 else None
+        gscale = self._loss_scale_state(saved["x_last"].device) if dt == torch.float16 else None
+        self._guard_on = gscale is not None
+        gmax = gscale[2:] if gscale is not None else None      # the overflow guard: raised by every LayerNorm backward below
         dx, dxb = ops.head_bwd(dlogits, demb, saved["x_last"], B, saved["Th"], D, hn.weight.detach(), saved["meanh"], saved["rstdh"],
                                saved["emb"], saved["Wn"], 1.0 if linear_head else sp.cos_s, dt, p_drop=p_drop, seed=seed,
                                site=(4 * (nl - 1) + 2) | sflag, linear=linear_head, pool_mean=(sp.pool == "mean"),
                                stream_dtype=dt if (dt in OP16 and GRAD_STREAM_BF16) else torch.float32,
-                               compact=(sp.pool == "cls"), gscale=gscale)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
+                               compact=(sp.pool == "cls"), gscale=gscale, target_exp=GRAD_TARGET_EXP)      # pool='cls': [B, D] cls-row gradients, nothing zero-filled
         gv = {id(p): g for p, g in zip(bucket.params, bucket.grad_views)}
         dev = dx.device
         cls_rows = lambda t, w: t.view(B, T, w)[:, 0].contiguous()
@@ -757,10 +787,10 @@ class ViTRunner:
             if sparse and not tail:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], T * D, n2.weight.detach(), cls_rows(st["mean2"].view(-1, 1), 1).view(-1),
                                               cls_rows(st["rstd2"].view(-1, 1), 1).view(-1), dx,
-                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, drop_row_stride=T * D, gmax=gmax)
             else:
                 dx1, dx1b = ops.layernorm_bwd(dxn2, st["x1"], D, n2.weight.detach(), st["mean2"], st["rstd2"], dx,
-                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag)
+                                              p_drop=p_drop, seed=seed, site=(4 * i) | sflag, gmax=gmax)
             del dxn2
             # ---- attention sub-layer with the q / k / v adapters
             d_o = torch.empty(Mrows, H * 64, device=dev, dtype=dt)
@@ -788,5 +818,5 @@ class ViTRunner:
             n1 = blk.ln1
             dx, dxb = ops.layernorm_bwd(dxn1, st["x"], D, n1.weight.detach(), st["mean1"], st["rstd1"], dx1,
                                         p_drop=p_drop, seed=seed, site=(4 * (i - 1) + 2) | sflag,
-                                        dres_cls_T=T if sparse else 0)      # after the cls-row-only block dx1 is compact [B, D]
+                                        dres_cls_T=T if sparse else 0, gmax=gmax)      # after the cls-row-only block dx1 is compact [B, D]
             saved["layers"][i] = None

@@ -149,11 +149,14 @@ GSL_API int gsl_layernorm_fwd_lora(const void* x, long x_row_stride, const float
  * row*drop_row_stride + d (0 -> D). dxb is always dense [M,D].
  * dres_cls_T > 0: dres is COMPACT — it holds only the rows of the cls tokens ([M / dres_cls_T] rows, io_row_stride apart); row m
  * receives dres[m / dres_cls_T] when m % dres_cls_T == 0 and nothing otherwise, and dx is written dense [M,D]. (The stream gradient
- * leaving the cls-row-only backward of the last block is exactly zero off the cls rows: no zero-filled tensor is written or read.) */
+ * leaving the cls-row-only backward of the last block is exactly zero off the cls rows: no zero-filled tensor is written or read.)
+ * gmax (nullable; the overflow guard of the loss-scaled fp16 backward, round 6): device f32, raised (atomic max) to the largest |value| this call
+ * read in dy or stored in dx — gscale + 2 of gsl_head_bwd. Every gradient of the chain passes a LayerNorm backward; a saturated 16-bit store
+ * anywhere upstream (an operand of +-65504) or in the stream shows here as gmax >= 65504. */
 GSL_API int gsl_layernorm_bwd(const void* dy, const void* x, long x_row_stride, const float* gamma,
                       const float* mean, const float* rstd, const void* dres,
                       void* dx, long io_row_stride, void* dxb, int M, int D, int dtype, int stream_dtype, int x_dtype,
-                      float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, int dres_cls_T, gsl_stream_t s);
+                      float p_drop, uint64_t seed, uint32_t site, long drop_row_stride, int dres_cls_T, float* gmax, gsl_stream_t s);
 
 /* ---- K4 attention, head_dim 64, no mask, softmax(QK^T*scale)V (vit_face.py:358-376).
  * qkv_layout (the INPUT qkv): 0 = token-major qkv[dtype] [B*T, 3*H*64] (q|k|v, each 'b n (h d)', as the reference's to_qkv output),
@@ -212,12 +215,18 @@ GSL_API int gsl_head_fwd(const void* x, int x_dtype, int T, const float* gamma, 
  * gscale != NULL (fp16 operands): LOSS-SCALED backward. The kernel runs twice: pass 1 writes max|d loss / d stream| of every image to
  * amax_ws [B], pass 2 picks the power of two S with S * max in [2^10, 2^11), stores dx / dxb multiplied by S and publishes
  * gscale[0..1] = {S, 1/S} on the device (no host sync; HIP-graph safe). Every kernel downstream is linear in the gradient; the
- * LoRA-gradient reductions take gscale and divide S out. */
+ * LoRA-gradient reductions take gscale and divide S out.
+ * Overflow guard (round 6; GradScaler semantics without a host sync). gscale is f32 [4] that PERSISTS across steps (zero it once):
+ *   [2] = the largest |scaled gradient| the LayerNorm backwards of this backward saw (gsl_layernorm_bwd's gmax; reset to 0 here),
+ *   [3] = the exponent E in use: S * max lands in [2^(E-1), 2^E).
+ * Pass 1 reads the PREVIOUS backward's [2]: >= 65504 (a 16-bit store saturated) or non-finite -> E drops by 2 (floor 4); below 2^9 with E
+ * under target_exp -> E grows by 1; an E outside [4, 15] (the zeroed buffer) -> target_exp. target_exp: 0 = the default 11 (32x headroom at the head;
+ * the largest gradient operand of a depth-6 chain measured 1.2x the head's). gsl_adamw_flat / _dev skip the update of a step whose [2] saturated. */
 GSL_API int gsl_head_bwd(const float* dlogits, const float* demb, const void* x, int x_dtype, int T, const float* gamma,
                  const float* mean, const float* rstd, const float* emb, const float* Wn,
                  void* dx, void* dxb, int B, int D, int C, float cos_s, int dtype, int stream_dtype,
                  float p_drop, uint64_t seed, uint32_t site, int linear_head, int pool_mean, int compact,
-                 float* gscale, float* amax_ws, gsl_stream_t s);
+                 float* gscale, float* amax_ws, int target_exp, gsl_stream_t s);
 
 /* ---- K11 cross entropy (mean) + top-1 (engine_cl.py:65-78, util/utils.py:354-368).
  * out2 f32 [2] = { sum_i CE_i , #correct }; row_ws f32 [2*B] scratch (per-row loss / hit, summed in a fixed order). */
@@ -276,11 +285,13 @@ GSL_API int gsl_group_norms_bwd(const float* flat, const int64_t* toff, const in
 /* ---- K14 fused AdamW over a flat buffer (torch.optim.AdamW as timm.create_optimizer builds it,
  * train_own_forget_cl.py:811-813): decoupled wd, bias correction, step >= 1. */
 GSL_API int gsl_adamw_flat(float* p, const float* g, float* m, float* v, long n,
-                   float lr, float beta1, float beta2, float eps, float wd, int step, gsl_stream_t s);
+                   float lr, float beta1, float beta2, float eps, float wd, int step, const float* guard, gsl_stream_t s);
+/* guard (nullable): device f32 — the overflow guard of a loss-scaled fp16 backward (gscale + 2 of gsl_head_bwd). The update is SKIPPED
+ * (p, m, v untouched; torch.cuda.amp.GradScaler.step semantics) when *guard >= 65504 or is not finite: a gradient of this step was clipped. */
 /* HIP-graph form of the same update: the step count t (>= 1, int64) and the learning rate (f32) are read from device memory,
  * so a captured graph of the whole forgetting step replays with fresh values (bias corrections 1 - beta^t in f64 in-kernel). */
 GSL_API int gsl_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
-                       float eps, float wd, const int64_t* step_dev, gsl_stream_t s);
+                       float eps, float wd, const int64_t* step_dev, const float* guard, gsl_stream_t s);
 
 /* ---- helpers: f32 -> dtype casts for the frozen-weight caches and padded LoRA operands. */
 GSL_API int gsl_cast(const float* in, void* out, long n, int dtype, gsl_stream_t s);

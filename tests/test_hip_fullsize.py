@@ -140,5 +140,10 @@ def test_speed_mode_gradient_vs_f32_mode_at_full_batch(full):
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
     print(f"[{mode} vs f32, B=512+512] loss {loss16.item():.5f}/{loss32.item():.5f} grad rel {rel:.5f} cos {cos:.7f}")
     assert torch.isfinite(g16).all()
+    if mode == "fp16":      # the overflow guard's view of this backward: the largest loss-scaled gradient a LayerNorm backward read or stored
+        rep = m.runner().loss_scale_report()
+        print(f"[fp16 loss scale, B=512+512] S = {rep['S']:g}, exponent {rep['exponent']}, largest scaled gradient {rep['seen_max']:.0f}, "
+              f"headroom {rep['headroom']:.1f}x")
+        assert rep["exponent"] == 11 and not rep["saturated"] and rep["headroom"] >= 8.0, rep
     assert rel < VS_F32_GRAD_BAND[mode] and cos > 0.9999, (mode, rel, cos)
     assert abs(loss16.item() - loss32.item()) < 5e-3 * max(1.0, abs(loss32.item()))

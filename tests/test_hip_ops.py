@@ -1489,3 +1489,85 @@ def test_gemm_o4_overlap_kernel_fused_ffn1(ops, dev_lib, monkeypatch, M, N, K1, 
     assert torch.equal(q0 == 26, qr == 26) or ((q0 == 26) != (qr == 26)).float().mean() < 1e-3      # (a kept element may also code to 26: GELU' = 0)
     assert ((q0.int() - qr.int()).abs() <= 1).all() and (q0 != qr).float().mean() < 0.02
     assert (h0 != h1).float().mean() < 0.05 and ((h0.float() - h1.float()).abs() <= 2 * eps * h0.float().abs() + 2 * tab).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------- fp16 overflow guard (round 6)
+def test_fp16_overflow_guard_ln_bwd_reports_the_largest_gradient_and_adamw_skips_a_saturated_step(ops):
+    """every fp16 store saturates in hardware, so a clipped gradient used to be silent. gsl_layernorm_bwd(gmax) raises a
+    device float to the largest |dy| it read / |dx| it stored (every gradient of the chain passes a LayerNorm backward); gsl_adamw_flat(guard)
+    leaves p / m / v untouched when the guard holds >= 65504 (a saturated store) or a non-finite value — GradScaler.step semantics, no host sync."""
+    M, D = 300, 512
+    dt = torch.float16
+    x = rnd(M, D, seed=1).cuda().to(dt)
+    gam = (1 + 0.1 * rnd(D, seed=2)).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, D, M, D, gam, torch.zeros(D).cuda(), 1e-5, dt)
+    dy = (rnd(M, D, seed=3) * 40).cuda().to(dt)
+    dres = (rnd(M, D, seed=4) * 300).cuda().to(dt)
+    gmax = torch.zeros(2, device="cuda")
+    dx, _ = ops.layernorm_bwd(dy, x, D, gam, mean, rstd, dres, want_copy=False, gmax=gmax[:1])
+    want = max(float(dy.float().abs().max()), float(dx.float().abs().max()))
+    seen = float(gmax[0])
+    assert gmax[1] == 0 and abs(seen - want) <= 2.0 ** -10 * want + 1e-6, (seen, want)      # (|dx| is taken on the f32 value, before its one rounding)
+    small = (rnd(M, D, seed=5)).cuda().to(dt)
+    ops.layernorm_bwd(small, x, D, gam, mean, rstd, small, want_copy=False, gmax=gmax[:1])      # a maximum, not the last value
+    assert float(gmax[0]) == seen
+    dy2 = dy.clone(); dy2[17, 5] = 65504.0                                                   # what a saturated GEMM store upstream leaves behind
+    ops.layernorm_bwd(dy2, x, D, gam, mean, rstd, dres, want_copy=False, gmax=gmax[:1])
+    assert float(gmax[0]) >= 65504.0
+    # the optimizer under the guard
+    n = 4096
+    p = rnd(n, seed=6).cuda(); g = rnd(n, seed=7).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+    p0 = p.clone()
+    ops.adamw_flat(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, 1, guard=gmax[:1])              # saturated: skipped
+    assert torch.equal(p, p0) and not m.any() and not v.any()
+    for bad in (float("inf"), float("nan")):
+        gmax[0] = bad
+        ops.adamw_flat(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, 1, guard=gmax[:1])
+        assert torch.equal(p, p0)
+    gmax[0] = 3000.0
+    ops.adamw_flat(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.05, 1, guard=gmax[:1])              # clean: the plain update
+    q = p0.clone(); mq = torch.zeros(n).cuda(); vq = torch.zeros(n).cuda()
+    ops.adamw_flat(q, g, mq, vq, 1e-2, 0.9, 0.999, 1e-8, 0.05, 1)
+    assert torch.equal(p, q) and torch.equal(m, mq) and torch.equal(v, vq) and not torch.equal(p, p0)
+    step_dev = torch.ones(1, device="cuda", dtype=torch.int64); lr_dev = torch.full((1,), 1e-2, device="cuda")
+    gmax[0] = 65504.0
+    p1 = p.clone()
+    ops.adamw_flat_dev(p, g, m, v, lr_dev, 0.9, 0.999, 1e-8, 0.05, step_dev, guard=gmax[:1])   # the HIP-graph form
+    assert torch.equal(p, p1)
+
+
+def test_fp16_loss_scale_backs_off_on_the_device_after_a_saturated_backward(ops):
+    """gsl_head_bwd keeps {S, 1/S, seen maximum, exponent E} in a persistent device buffer: S * max|head gradient| lands in [2^(E-1), 2^E); a
+    backward whose LayerNorm backwards saw >= 65504 lowers E by 2 for the next one (floor 4), a quiet one (< 2^9) raises it by 1 up to the
+    target (default 11, or target_exp). No host value enters: the same sequence under HIP-graph replay."""
+    B, T, D, C = 6, 9, 128, 10
+    dt = torch.float16
+    x = rnd(B * T, D, seed=1, scale=1.5).cuda().to(dt)
+    g, b = (1 + 0.1 * rnd(D, seed=2)).cuda(), (0.1 * rnd(D, seed=3)).cuda()
+    Wn = ops.cosface_prep(rnd(C, D, seed=4).cuda())
+    label = (torch.arange(B) % C).cuda()
+    _, emb, mean, rstd = ops.head_fwd(x, B, T, D, g, b, 1e-5, Wn, label, 64.0, 0.35)
+    dl, de = (rnd(B, C, seed=5) * 1e-3).cuda(), (rnd(B, D, seed=6) * 1e-3).cuda()
+    ref, _ = ops.head_bwd(dl, de, x.float(), B, T, D, g, mean, rstd, emb, Wn, 64.0, torch.float32, compact=True)      # unscaled f32 gradients
+    amax = float(ref.abs().max())
+    gs = torch.zeros(4, device="cuda")
+    call = lambda **kw: ops.head_bwd(dl, de, x, B, T, D, g, mean, rstd, emb, Wn, 64.0, dt, stream_dtype=dt, compact=True, gscale=gs, **kw)
+
+    def check(E):
+        S, inv, seen, e = gs.tolist()
+        assert e == E and seen == 0.0 and S * inv == 1.0 and 2.0 ** (E - 1) <= S * amax < 2.0 ** E, (gs.tolist(), amax, E)
+    dx, _ = call()
+    check(11)                                                     # the zeroed buffer starts at the default
+    assert (dx.float() - ref * gs[0]).abs().max() <= 2.0 ** -10 * float((ref * gs[0]).abs().max())
+    gs[2] = 65504.0; call(); check(9)                             # the previous backward saturated: two binades down
+    gs[2] = float("inf"); call(); check(7)
+    gs[2] = 3000.0; call(); check(7)                              # in range: stays
+    gs[2] = 100.0; call(); check(8)                               # quiet: one binade up per step ...
+    for E in (9, 10, 11, 11):
+        gs[2] = 100.0; call(); check(E)                           # ... up to the target, not beyond
+    gs.zero_(); call(target_exp=14); check(14)                    # a configured target (GSLORA_GRAD_TARGET_EXP)
+    for _ in range(8):
+        gs[2] = 7e4; call(target_exp=14)
+    check(4)                                                      # floor
+    with pytest.raises(RuntimeError):
+        call(target_exp=3)

@@ -322,3 +322,7 @@ def test_vit_b16_full_geometry_16bit_bands(dtype, lo_tol, em_tol, g_tol):
     print(f"[vit-b/16 full geometry {dtype}] logits {e_lo:.4f}, emb {e_em:.4f}, LoRA gradients: total rel. {float((a - r).norm() / r.norm()):.5f}, worst tensor {worst:.4f}")
     assert e_lo < lo_tol and e_em < em_tol, (e_lo, e_em)
     assert worst < g_tol, worst
+    if dtype == "fp16":      # the headroom of the loss-scaled backward at THIS geometry (depth 12), measured by the overflow guard
+        rep = m.runner().loss_scale_report()
+        print(f"[vit-b/16 fp16 loss scale] exponent {rep['exponent']}, largest scaled gradient {rep['seen_max']:.0f}, headroom {rep['headroom']:.1f}x")
+        assert rep["exponent"] == 11 and not rep["saturated"] and rep["headroom"] >= 8.0, rep

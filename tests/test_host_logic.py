@@ -222,7 +222,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     # argument validation happens before any launch: a bad call returns GSL_ERR_ARG and sets the message (no GPU needed)
-    rc = lib.gsl_adamw_flat(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 0, None)
+    rc = lib.gsl_adamw_flat(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 0, None, None)
     assert rc == -1 and b"gsl_adamw_flat" in lib.gsl_last_error()
     rc = lib.gsl_gemm_nt(None, 0, None, 0, 63, None, 0, None, 0, 0, 4, 4, 0, 0, 1.0, None, None, None, None, None, 0, None, None, 0,
                          0.0, 0, 0, None)
@@ -406,7 +406,7 @@ def test_fused_adamw_loading_an_empty_state_resets_a_stepped_optimizer_like_torc
     from gslora_hip import ops
     from gslora_hip.optim import FusedAdamW
 
-    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step):
+    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step, guard=None):
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         p.mul_(1 - lr * wd).addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
@@ -448,7 +448,7 @@ def test_fused_adamw_load_state_dict_keeps_the_buffers_captured_graphs_point_at(
     from gslora_hip import ops
     from gslora_hip.optim import FusedAdamW
 
-    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step):      # torch restatement of gsl_adamw_flat for the CPU
+    def adamw_flat(p, g, m, v, lr, b1, b2, eps, wd, step, guard=None):      # torch restatement of gsl_adamw_flat for the CPU
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         p.mul_(1 - lr * wd).addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
