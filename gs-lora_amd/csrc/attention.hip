@@ -310,12 +310,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
     const int li = (wave - NCW) * 64 + lane, col = (li & 7) * 8, row0 = li >> 3;
     u32x4_t dq[NST], dk[NST], dv[NST];
     int item = blockIdx.x;
-    const bf16_t* qb = item_base(item);
+    // Per-lane source offsets as 32-bit BYTE offsets from a wave-uniform panel base (an item's panels span < 2^31 bytes): one VGPR per row
+    // instead of a 64-bit address pair — with 108 data registers in flight the pairs cost this kernel 4 spilled VGPRs, and a scratch access
+    // rides the CU's in-order vector-memory pipe (code object: .vgpr_spill_count 0 now). The K / V panels are ko / 2 ko
+    // elements behind Q: added to the uniform base.
+    unsigned goff[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) goff[k] = (unsigned)(min(row0 + 24 * k, T - 1) * (int)ld + col) * 2u;
+    auto ld16 = [](const char* base, unsigned off) { return *reinterpret_cast<const u32x4_t*>(base + off); };
+    const char* qb = reinterpret_cast<const char*>(item_base(item));
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
-      const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
-      dq[k] = *reinterpret_cast<const u32x4_t*>(qb + g);
-      dk[k] = *reinterpret_cast<const u32x4_t*>(qb + g + ko);
+      dq[k] = ld16(qb, goff[k]);
+      dk[k] = ld16(qb + 2 * ko, goff[k]);
     }
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -325,20 +332,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * ko);
+    for (int k = 0; k < NST; ++k) dv[k] = ld16(qb + 4 * ko, goff[k]);
     wg_barrier_lds();                                   // Q, K of the first item are in LDS
     for (; item < nitems; item += gridDim.x) {
       const int nxt = (item + (int)gridDim.x < nitems) ? item + (int)gridDim.x : item;
-      const bf16_t* nb = item_base(nxt);
+      const char* nb = reinterpret_cast<const char*>(item_base(nxt));
       // phase 1 of `item`: V(item) -> LDS, request Q, K of the next item
 #pragma unroll
       for (int k = 0; k < NST; ++k) *reinterpret_cast<u32x4_t*>(Vs + lds_off(min(row0 + 24 * k, T - 1), col)) = dv[k];
       asm volatile("" ::: "memory");      // requests strictly after the deposit: the register sets never live together
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
-        const size_t g = (size_t)min(row0 + 24 * k, T - 1) * ld + col;
-        dq[k] = *reinterpret_cast<const u32x4_t*>(nb + g);
-        dk[k] = *reinterpret_cast<const u32x4_t*>(nb + g + ko);
+        dq[k] = ld16(nb, goff[k]);
+        dk[k] = ld16(nb + 2 * ko, goff[k]);
       }
       wg_barrier_lds();
       // phase 2 of `item`: Q, K of the next item -> LDS, request its V
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_bf16_pers_kernel(const bf16_t* 
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < NST; ++k) dv[k] = *reinterpret_cast<const u32x4_t*>(nb + (size_t)min(row0 + 24 * k, T - 1) * ld + col + 2 * ko);
+      for (int k = 0; k < NST; ++k) dv[k] = ld16(nb + 4 * ko, goff[k]);
       wg_barrier_lds();
     }
     return;

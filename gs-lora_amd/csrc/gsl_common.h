@@ -42,6 +42,15 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
+// Everything below up to the end of the operand-format section lives in an INLINE namespace named after the translation unit's 16-bit operand
+// format: gemm.hip / attention.hip are compiled twice (bf16 and, with -DGSL_OP_F16, fp16), and Elem<uint16_t>, pack2o, unpack2o, o2f, f2o then
+// have two different definitions under one name — distinct mangled names keep that legal under -fgpu-rdc / LTO or if one stops being inlined
+// (ADVICE r05). Source code is unaffected (inline namespace members are found in gsl::).
+#ifdef GSL_OP_F16
+inline namespace op_f16 {
+#else
+inline namespace op_bf16 {
+#endif
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -146,6 +155,7 @@ template <> struct Elem<op16_t> {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
   }
 };
+}  // inline namespace op_f16 / op_bf16
 
 // ------------------------------------------------------------------ wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -228,6 +228,13 @@ class ViTRunner:
             cache[key] = ent
         return ent[1]
 
+    def invalidate_operand_caches(self):
+        """Forget every cached operand-format copy of a frozen weight (they are rebuilt on the next forward). Captured HIP graphs hold the old
+        copies' addresses: the graph stepper re-captures when the parameter versions it recorded change; after a `.data` write bump them too
+        or drop the graphs (GraphedStep.graphs.clear())."""
+        self._wcache = {k: v for k, v in self._wcache.items() if k and k[0] == "zeros"}
+        self._lcache.clear()
+
     def w(self, name, param, dtype):
         """[N,K] operand in compute dtype."""
         if dtype == torch.float32:

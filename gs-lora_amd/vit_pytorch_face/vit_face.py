@@ -162,6 +162,18 @@ class HipModelMixin:
         """Flat f32 storage behind the LoRA parameters (created on first use on the GPU)."""
         return self.runner().ensure_bucket()
 
+    def invalidate_operand_caches(self):
+        """Drop the runner's operand-format copies of the frozen weights (16-bit [N,K] / [K,N] forms, the gamma-folded QKV weight with its c / d
+        vectors, the normalised CosFace weight). They are keyed on (data_ptr, _version) of their parameters, which in-place autograd-visible
+        updates (loralib merge / un-merge, load_state_dict's copy_) bump — writes through `.data` do not: call this after one."""
+        if self._runner is not None:
+            self._runner.invalidate_operand_caches()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_operand_caches()      # (copy_ bumps the versions anyway; explicit so that a custom loader writing through .data is covered too)
+        return out
+
     def _hip_call(self, img, label):
         runner = self.runner()
         spec = self.hip_spec()

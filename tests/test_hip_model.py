@@ -622,21 +622,24 @@ def test_bf16_step_under_every_remaining_runner_knob(monkeypatch, knob, value, e
     assert rel < (0.01 if schedule else 0.06) and cos > (0.9999 if schedule else 0.995)
 
 
-def test_fp16_step_with_layernorm1_folded_into_the_qkv_projection_equals_the_unfolded_form(monkeypatch):
-    """Round 5: in the fp16 mode (forward stream and operands both fp16) LayerNorm 1 is folded into the QKV GEMM (EPI_STORE_LN: the GEMM reads
-    the stream with gamma folded into the weight and finishes the normalisation in its epilogue; LayerNorm 1 shrinks to its row statistics).
-    Both forms compute the reference's ln1 -> to_qkv (vit_face.py:316-323, 358-360); they differ by rounding only (the folded form skips the
-    fp16 rounding of LN(x)): logits within 0.05 at scale 64, LoRA gradients within 1 % relative Frobenius — far inside the fp16 band —,
-    including the last block's Q-split form and dropout (same masks)."""
+@pytest.mark.parametrize("dtype,stream,dropout,tol_l,tol_g", [("fp16", "f16", 0.0, 0.05, 0.01), ("fp16", "f16", 0.1, 0.05, 0.01), ("bf16", "bf16", 0.1, 0.25, 0.06)])
+def test_fp16_step_with_layernorm1_folded_into_the_qkv_projection_equals_the_unfolded_form(monkeypatch, dtype, stream, dropout, tol_l, tol_g):
+    """Round 5: where the forward stream and the operands share one 16-bit format (fp16 mode; bf16 operands with GSLORA_FWD_STREAM=bf16)
+    LayerNorm 1 is folded into the QKV GEMM (EPI_STORE_LN: the GEMM reads the stream with gamma folded into the weight and finishes the
+    normalisation in its epilogue; LayerNorm 1 shrinks to its row statistics). Both forms compute the reference's ln1 -> to_qkv
+    (vit_face.py:316-323, 358-360); they differ by rounding only (the folded form skips the 16-bit rounding of LN(x)): fp16 logits within 0.05
+    at scale 64, LoRA gradients within 1 % relative Frobenius — far inside the fp16 band — (bf16: the declared bf16 band), including the last
+    block's Q-split form, and with dropout ON (p = 0.1, the same counter-hash masks in both forms)."""
     from gslora_hip import vit_runner
     cfg, b = recipe.cfg_small2(), 6
     proto = {c: torch.tensor(v) for c, v in enumerate(recipe.make_prototypes(cfg))}
     xr, yr, xf, yf = batches(cfg, b)
     res = {}
+    monkeypatch.setattr(vit_runner, "FWD_STREAM", stream)
     for fold in (True, False):
         monkeypatch.setattr(vit_runner, "LN1_FOLD", fold)
         torch.manual_seed(7)
-        m = build(cfg, "fp16", dropout=0.0).train()
+        m = build(cfg, dtype, dropout=dropout).train()
         total, aux = total_loss(m, xr, yr, xf, yf, HYPER, proto)
         total.backward()
         res[fold] = (aux["logits_r"].detach().float().clone(), total.detach().clone(), lora_grads(m))
@@ -644,6 +647,6 @@ def test_fp16_step_with_layernorm1_folded_into_the_qkv_projection_equals_the_unf
     g0 = np.concatenate([v.ravel() for v in res[False][2].values()]).astype(np.float64)
     g1 = np.concatenate([v.ravel() for v in res[True][2].values()]).astype(np.float64)
     rel = np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
-    print(f"[LN1 fold on / off, fp16] logits max|d| {dl:.4f}, LoRA-gradient rel. Frobenius {rel:.5f}")
-    assert dl <= 0.05 and rel < 0.01
+    print(f"[LN1 fold on / off, {dtype} operands, {stream} stream, dropout {dropout}] logits max|d| {dl:.4f}, LoRA-gradient rel. Frobenius {rel:.5f}")
+    assert dl <= tol_l and rel < tol_g
     assert not torch.equal(res[False][0], res[True][0])      # (the fold is live in this mode)
