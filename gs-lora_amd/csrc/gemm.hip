@@ -113,6 +113,11 @@ __device__ __attribute__((aligned(16))) const uint32_t GELU_G8_TAB[GT_N] = {
 };
 typedef __attribute__((address_space(3))) const uint32_t* lds_u32p_t;
 // tab_c4 = GT_C4 + LDS byte address of the table (exact in f32: < 2^24)
+// the same lookup from the pre-activation already multiplied by the dropout scale s = 1 / (1 - p): rs = R s, k4s = K4 / s
+__device__ __forceinline__ uint32_t gelu_tab_entry_scaled(float as, float rs, float k4s, float tab_c4) {
+  const float t = fmaf(__builtin_amdgcn_fmed3f(as, -rs, rs), k4s, tab_c4);
+  return *(lds_u32p_t)(uintptr_t)(((uint32_t)t) & ~3u);
+}
 __device__ __forceinline__ uint32_t gelu_tab_entry(float a, float tab_c4) {
   const float t = fmaf(__builtin_amdgcn_fmed3f(a, -GT_R, GT_R), GT_K4, tab_c4);
   return *(lds_u32p_t)(uintptr_t)(((uint32_t)t) & ~3u);
@@ -151,7 +156,7 @@ __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v
       }
     } else if (e.bias) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += e.bias[n + i];
+      for (int i = 0; i < 4; ++i) v[i] += bp ? bp[i] : e.bias[n + i];      // (bp: the staged epilogue's preloaded values — no global load per fragment)
     }
   } else if constexpr (EPI == GSL_EPI_BIAS_RES_F32) {
     float r[4], dm[4];
@@ -229,11 +234,26 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& e, int m, int n, float 
   }
 }
 
+// Store flavour of the staged epilogues. PRODUCT build: a compile-time constant — as a run-time EpiArgs field every one of the 16 - 24 stores of a
+// wave's epilogue sat behind a three-way uniform branch (plus s_waitcnt lgkmcnt(0) straight behind its ds_read_b128), and a staged epilogue of
+// ~400 instructions took 10 - 15 k cycles whether or not anything was stored (profiles/r06_k_epilogue_branches.md). Development build: the
+// GSL_STORE_MODE knob.
+#ifndef GSL_STMODE
+#define GSL_STMODE 1      // output stores of the staged epilogues: 0 plain, 1 non-temporal, 2 sc1 (store_stream16)
+#endif
+#if defined(GSL_DEV) && !defined(GSL_STMODE_FIXED)      // (-DGSL_STMODE_FIXED: a dev build with the product's compile-time store mode, for stamps)
+#define GSL_STMODE_OF(e) ((e).stmode)
+#else
+#define GSL_STMODE_OF(e) GSL_STMODE
+#endif
 // 16-byte output store. mode 0: plain (write-back, the line stays in the XCD's L2), 1: non-temporal hint, 2: sc1 (the line is dropped
 // from L2): the GEMM outputs are streamed once and are 4x larger than the operand panels they would otherwise evict.
 __device__ __forceinline__ void store_stream16(void* p, const uint4 v, int mode) {
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t w = {v.x, v.y, v.z, v.w};
+#ifdef GSL_DEV
+  if (mode == 3) return;      // development (GSL_STORE_MODE=3): no store at all — what an epilogue costs without its HBM writes
+#endif
   if (mode == 1) __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
   else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
   else *reinterpret_cast<u32x4_t*>(p) = w;
@@ -249,7 +269,10 @@ constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-
 // the second output waits in registers and is staged after the first was copied out (half the LDS: two workgroups per CU).
 // bias_lds: this wave's 64 bias values staged in LDS by the caller (the 128-register SEQ kernel cannot afford 16 more VGPRs), or
 // nullptr: the lane's 16 values are loaded into registers once.
-template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false>
+// SMODE (STORE only; chosen ONCE per wave by the wrapper from wave-uniform launch arguments — decided per fragment, the same flags cost two taken
+// branches and a dozen selects in front of each of the 32 fragments, ~9 k cycles of a 256x256 tile: profiles/r06_k_epilogue_branches.md):
+//   0 = the accumulator as it is (alpha 1, no bias, no LayerNorm), 1 = the consumer-side LayerNorm, 2 = the general form (alpha, bias)
+template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false, int SMODE = 2>
 __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
                                                           const float* bias_lds, uint32_t tab_lds = 0u) {
   static_assert(!TAB || EPI == GSL_EPI_BIAS_GELU_G8, "the GELU table serves the 8-bit-code epilogue");
@@ -289,6 +312,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   // rows in steps of 8, so (b, t) is divided out once and advanced incrementally
   int ht = 0;
   size_t hrow = 0, hwrap = 0;        // running element offset of the lane's current row inside [b][h][which]; what a wrap into the next image adds
+  const bool hm = (EPI == GSL_EPI_STORE) && e.hmT != 0;      // wave-uniform
   if constexpr (EPI == GSL_EPI_STORE) {
     if (e.hmT) {
       const int hb = (mw + crow) / e.hmT;
@@ -298,6 +322,22 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
       hrow = (size_t)hb * img + ((size_t)h * 3 + (size_t)which) * (size_t)e.hmT * 64 + (size_t)ht * 64 + (size_t)(cch * 8);
       hwrap = img - (size_t)e.hmT * 64;
     }
+  }
+  // table epilogue: lane bases of the two staging areas (LDS byte addresses, opaque to the optimiser so that they stay in registers), the bias
+  // pre-multiplied by the dropout scale, and the table constants for the scaled pre-activation a' = a / (1 - p): index = clamp(a') * (K4 / s) + C4
+  typedef __attribute__((address_space(3))) char* lds_cp_t;
+  lds_cp_t dbase_l = (lds_cp_t)(cst + fr * CLD + fc * 4), cbase_l = (lds_cp_t)(c8 + fr * 80 + fc * 4);
+  float bjs[4][4];
+  const float tscale = e.drop.scale, tab_rs = GT_R * e.drop.scale, tab_k4s = GT_K4 / e.drop.scale;
+  if constexpr (TAB) {
+    asm volatile("" : "+v"(dbase_l), "+v"(cbase_l));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bjs[j][i] = bj[j][i] * tscale;
+        asm volatile("" : "+v"(bjs[j][i]));      // (kept: the compiler would re-multiply bias * scale in front of every fragment)
+      }
   }
   constexpr bool DROPW = epi_is_gelu<EPI>();
   uint32_t wbase = 0u, rowstep = 0u;
@@ -328,6 +368,14 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         const int i = ib + ii;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, g[4] = {0.f, 0.f, 0.f, 0.f};
         const int m = mw + i * 16 + fr, n = nw + j * 16 + fc * 4;
+        if constexpr (EPI == GSL_EPI_STORE && SMODE != 2) {
+          if constexpr (SMODE == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], rsv[ii], fmaf(-rmv[ii], cj[j][q], bj[j][q]));
+          }
+          *reinterpret_cast<uint2*>(cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
+          continue;
+        }
         if constexpr (EPI == GSL_EPI_STORE) {
           if (ln) {
 #pragma unroll
@@ -338,8 +386,8 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           uint32_t ent[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            v[q] += bj[j][q];
-            ent[q] = gelu_tab_entry(v[q], tab_c4);
+            v[q] = fmaf(v[q], tscale, bjs[j][q]);      // (acc + bias) / (1 - p): the dropout scale rides in the bias add (bjs = bias * scale)
+            ent[q] = gelu_tab_entry_scaled(v[q], tab_rs, tab_k4s, tab_c4);
           }
           if (e.drop.thr) {
             const uint32_t w0 = wbase + ((uint32_t)i * rowstep + (uint32_t)(j * 8) * DROP_PHI);
@@ -350,11 +398,14 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
             ent[3] = ((h1 >> 16) < e.drop.thr) ? GT_DROPPED : ent[3];
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = (v[q] * e.drop.scale) * __uint_as_float(ent[q]);
-          bf16_t* d = cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4;
-          *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
+          for (int q = 0; q < 4; ++q) v[q] = v[q] * __uint_as_float(ent[q]);
+          // staging addresses = one lane base each (kept in a register: the compiler otherwise rebuilds it from three values per fragment,
+          // ~4 of the epilogue's ~59 VALU slots per fragment, and this epilogue is VALU-issue-bound) + a compile-time offset
+          typedef unsigned int u32x2_lds_t __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<__attribute__((address_space(3))) u32x2_lds_t*>(dbase_l + ((ii * 16) * CLD + j * 16) * 2) =
+              u32x2_lds_t{pack2o(v[0], v[1]), pack2o(v[2], v[3])};
           // the four code bytes: v_perm_b32 x 2 + v_or
-          *reinterpret_cast<uint32_t*>(c8 + (ii * 16 + fr) * 80 + j * 16 + fc * 4) =
+          *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(cbase_l + (ii * 16) * 80 + j * 16) =
               __builtin_amdgcn_perm(ent[1], ent[0], 0x0c0c0400u) | __builtin_amdgcn_perm(ent[3], ent[2], 0x04000c0cu);
           continue;
         }
@@ -379,6 +430,9 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
         }
       }
     // the wave's own DS operations execute in order: the reads below see the writes above (no barrier needed)
+    // Copy-out (round 6): all eight row reads of the chunk are issued first, then the eight stores — one LDS round trip per chunk instead of one
+    // per store —, the head-major row walk is branch-free (a step of 8 rows crosses at most one image boundary when T >= 8; the host checks),
+    // and nothing wave-uniform is decided per store.
 #pragma unroll
     for (int pass = 0; pass < (SEQ ? NOUT : 1); ++pass) {
       if (SEQ && pass == 1) {
@@ -387,41 +441,56 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
 #pragma unroll
           for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4) = held[ii][j];
       }
+      uint4 val[8], val2[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int row = r * 8 + crow;
-        const int m = mw + ib * 16 + row, n = nw + cch * 8;
-        if (FULL || (m < e.M && n < e.N)) {
-          const uint4 val = *reinterpret_cast<const uint4*>(cst + row * CLD + cch * 8);
-          bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
-          // element offset = this lane's first row + a wave-uniform row step (scalar multiply): no per-store 64-bit multiply
-          size_t off = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
-          if constexpr (EPI == GSL_EPI_STORE) {
-            if (e.hmT) off = hrow;
-          }
-          if (dst) store_stream16(dst + off, val, e.stmode);
-          if constexpr (NOUT == 2 && !SEQ && !G8) {
-            if (e.out2) {
-              const uint4 val2 = *reinterpret_cast<const uint4*>(cst + (64 + row) * CLD + cch * 8);
-              store_stream16(reinterpret_cast<bf16_t*>(e.out2) + off, val2, e.stmode);
-            }
+        val[r] = *reinterpret_cast<const uint4*>(cst + (r * 8 + crow) * CLD + cch * 8);
+        if constexpr (NOUT == 2 && !SEQ && !G8) val2[r] = *reinterpret_cast<const uint4*>(cst + (64 + r * 8 + crow) * CLD + cch * 8);
+      }
+      bf16_t* dst = reinterpret_cast<bf16_t*>((SEQ && pass == 1) ? e.out2 : e.out);
+      size_t offs[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        // element offset = this lane's first row + a wave-uniform row step (scalar multiply): no per-store 64-bit multiply
+        offs[r] = rowoff0 + (size_t)(ib * 16 + r * 8) * (size_t)e.ldo;
+        if constexpr (EPI == GSL_EPI_STORE) {
+          if (hm) {
+            offs[r] = hrow;
+            ht += 8; hrow += 8 * 64;
+            const bool wrap = ht >= e.hmT;
+            ht = wrap ? ht - e.hmT : ht;
+            hrow = wrap ? hrow + hwrap : hrow;
           }
         }
-        if constexpr (EPI == GSL_EPI_STORE) {
-          if (e.hmT) { ht += 8; hrow += 8 * 64; while (ht >= e.hmT) { ht -= e.hmT; hrow += hwrap; } }
+      }
+      if (dst) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int m = mw + ib * 16 + r * 8 + crow, n = nw + cch * 8;
+          if (FULL || (m < e.M && n < e.N)) store_stream16(dst + offs[r], val[r], GSL_STMODE_OF(e));
+        }
+      }
+      if constexpr (NOUT == 2 && !SEQ && !G8) {
+        if (e.out2) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int m = mw + ib * 16 + r * 8 + crow, n = nw + cch * 8;
+            if (FULL || (m < e.M && n < e.N)) store_stream16(reinterpret_cast<bf16_t*>(e.out2) + offs[r], val2[r], GSL_STMODE_OF(e));
+          }
         }
       }
     }
-    if constexpr (G8) {      // 64 rows x 64 code bytes: 4 lanes x 16 B per row, 16 rows per instruction
+    if constexpr (G8) {      // 64 rows x 64 code bytes: 4 lanes x 16 B per row, 16 rows per instruction; the four reads first, then the four stores
       if (e.out2) {
+        uint4 cv[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) cv[rr] = *reinterpret_cast<const uint4*>(c8 + (rr * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
+        // slab-major code tensor: the wave's 64 columns are one slab (nw % 64 == 0), its rows follow each other 64 bytes apart
+        uint8_t* cdst = reinterpret_cast<uint8_t*>(e.out2) + ((size_t)(nw >> 6) * (size_t)e.M + (size_t)(mw + ib * 16 + (lane >> 2))) * 64 + (size_t)((lane & 3) * 16);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const int row = rr * 16 + (lane >> 2), c16 = lane & 3;
-          const int m = mw + ib * 16 + row, n = nw + c16 * 16;
-          if (FULL || (m < e.M && n < e.N)) {
-            const uint4 val = *reinterpret_cast<const uint4*>(c8 + row * 80 + c16 * 16);
-            store_stream16(reinterpret_cast<uint8_t*>(e.out2) + g8_off(e.M, m, n), val, e.stmode);
-          }
+          const int m = mw + ib * 16 + rr * 16 + (lane >> 2), n = nw + (lane & 3) * 16;
+          if (FULL || (m < e.M && n < e.N)) store_stream16(cdst + rr * 16 * 64, cv[rr], GSL_STMODE_OF(e));
         }
       }
     }
@@ -434,7 +503,14 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
   if constexpr (SEQ) {      // the 128-register kernel: two inlined copies of the epilogue make the allocator spill (measured: 81 VGPRs)
     epilogue_staged_bf16_impl<EPI, NI, SEQ, false>(e, acc, cst, mw, nw, lane, bias_lds);
   } else {
-    if (mw + NI * 16 <= e.M && nw + 64 <= e.N) epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
+    const bool full = mw + NI * 16 <= e.M && nw + 64 <= e.N;
+    if constexpr (EPI == GSL_EPI_STORE) {
+      if (full && !bias_lds) {      // whole tiles (all of them at the step's shapes): the specialised forms
+        if (e.ln_rstd != nullptr) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 1>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
+        if (e.alpha == 1.0f && !e.bias) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 0>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
+      }
+    }
+    if (full) epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
     else epilogue_staged_bf16_impl<EPI, NI, SEQ, false, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
   }
 }
@@ -466,7 +542,7 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[ib + ii][j];
-        if (e.alpha != 1.0f) v *= e.alpha;
+        v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
         *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
 #pragma unroll
@@ -492,7 +568,7 @@ __device__ __forceinline__ void epilogue_staged_mul(const EpiArgs& e, f32x4_t (&
           o[k] = pack2o(c0 * a0, c1 * a1);
         }
       }
-      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), e.stmode);
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(o[0], o[1], o[2], o[3]), GSL_STMODE_OF(e));
     }
   }
 }
@@ -589,7 +665,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[ic * 2 + ii][j];
-        if (e.alpha != 1.0f) v *= e.alpha;
+        v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
         *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
     __builtin_amdgcn_sched_barrier(0);    // nothing that consumes the requested operands may be scheduled above the staging (it would drag their wait up)
@@ -617,7 +693,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
         }
       }
       const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, e.stmode);
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, GSL_STMODE_OF(e));
       *reinterpret_cast<uint4*>(yd + row * CLD + cch * 8) = ov;
       // rows past M contribute nothing to the reductions (their dZ is finite: clamped operands) — masked where the operand is consumed,
       // not where it was requested, so that no wait for the loads sits in front of the staging above
@@ -716,7 +792,7 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4_t v = acc[ib + ii][j];
-          if (e.alpha != 1.0f) v *= e.alpha;
+          v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
           *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
         }
     }
@@ -736,7 +812,7 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (c[k] + b4[k]) * dm[k] + rs[r][k];
       }
-      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), e.stmode);
+      if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])), GSL_STMODE_OF(e));
     }
   }
 }
@@ -782,7 +858,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[q * 4 + ii][j];
-        if (e.alpha != 1.0f) v *= e.alpha;
+        v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
         *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
 #pragma unroll
@@ -814,7 +890,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
         }
       }
       if (m < e.M && n < e.N)
-        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2s(o[0], o[1], e.f16), pack2s(o[2], o[3], e.f16), pack2s(o[4], o[5], e.f16), pack2s(o[6], o[7], e.f16)), e.stmode);
+        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2s(o[0], o[1], e.f16), pack2s(o[2], o[3], e.f16), pack2s(o[4], o[5], e.f16), pack2s(o[6], o[7], e.f16)), GSL_STMODE_OF(e));
     }
   }
 }
@@ -1819,9 +1895,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 // Launch knobs. The product library has none: block-id remap on, K rotation off, non-temporal output stores, no stamps, and the
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
-#ifndef GSL_STMODE
-#define GSL_STMODE 1      // output stores of the staged epilogues: 0 plain, 1 non-temporal, 2 sc1 (store_stream16)
-#endif
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
   e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0; e.o4_delay = 0;
   e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr; e.ln_rs = 1;
@@ -2081,7 +2154,7 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
       }
       [[fallthrough]];
     case GSL_EPI_STORE_QKV_HM:      // the STORE kernels with a permuting copy-out: out is [B][H][3][T][64], M = B * T rows, N = 3 * H * 64
-      GSL_CHECK_ARG(dtype == GSL_OP16 && T > 0 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T, N = 3*H*64, ldo = N");
+      GSL_CHECK_ARG(dtype == GSL_OP16 && T >= 8 && (M % T) == 0 && (N % 192) == 0 && ldo == N, "STORE_QKV_HM: bf16, M = B*T (T >= 8), N = 3*H*64, ldo = N");
       e.hmT = T; e.hmH = N / 192;
       return launch_gemm<GSL_EPI_STORE>(dtype, A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, e, st);
     case GSL_EPI_BIAS_RES_F32:
