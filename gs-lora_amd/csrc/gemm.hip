@@ -272,7 +272,11 @@ constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-
 // SMODE (STORE only; chosen ONCE per wave by the wrapper from wave-uniform launch arguments — decided per fragment, the same flags cost two taken
 // branches and a dozen selects in front of each of the 32 fragments, ~9 k cycles of a 256x256 tile: profiles/r06_k_epilogue_branches.md):
 //   0 = the accumulator as it is (alpha 1, no bias, no LayerNorm), 1 = the consumer-side LayerNorm, 2 = the general form (alpha, bias)
-template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false, int SMODE = 2>
+// DK (table epilogue): 1 = dropout on, 2 = off — decided once per wave like SMODE; 0 = tested where it is used. (Tried and dropped: the keep bits of
+// the wave's sub-tile precomputed under the prologue wait + v_bfe_i32 / v_bfi_b32 selects — 17 of ~47 issue slots per fragment less and the epilogue's
+// 13.0 k cycles did not move, while the prologue grew by 4 k: this epilogue is bound by its LDS traffic — 128 table gathers, 64 staging writes and 24
+// row reads per wave —, not by VALU issue: profiles/r06_k_epilogue_branches.md.)
+template <int EPI, int NI, bool SEQ, bool FULL, bool TAB = false, int SMODE = 2, int DK = 0>
 __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], bf16_t* cst, int mw, int nw, int lane,
                                                           const float* bias_lds, uint32_t tab_lds = 0u) {
   static_assert(!TAB || EPI == GSL_EPI_BIAS_GELU_G8, "the GELU table serves the 8-bit-code epilogue");
@@ -389,7 +393,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
             v[q] = fmaf(v[q], tscale, bjs[j][q]);      // (acc + bias) / (1 - p): the dropout scale rides in the bias add (bjs = bias * scale)
             ent[q] = gelu_tab_entry_scaled(v[q], tab_rs, tab_k4s, tab_c4);
           }
-          if (e.drop.thr) {
+          if (DK == 1 || (DK == 0 && e.drop.thr)) {
             const uint32_t w0 = wbase + ((uint32_t)i * rowstep + (uint32_t)(j * 8) * DROP_PHI);
             const uint32_t h0 = drop_finish(w0), h1 = drop_finish(w0 + DROP_PHI);
             ent[0] = ((h0 & 0xffffu) < e.drop.thr) ? GT_DROPPED : ent[0];
@@ -508,6 +512,13 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
       if (full && !bias_lds) {      // whole tiles (all of them at the step's shapes): the specialised forms
         if (e.ln_rstd != nullptr) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 1>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
         if (e.alpha == 1.0f && !e.bias) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 0>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
+      }
+    }
+    if constexpr (TAB) {
+      if (full) {
+        if (e.drop.thr) epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 2, 1>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
+        else epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 2, 2>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
+        return;
       }
     }
     if (full) epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds);
@@ -821,8 +832,15 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
 // staging as the f32-stream epilogue above; the residual is loaded and the result stored as full 128-byte rows (8 lanes x 16 B per
 // row, 8 rows per instruction): half the epilogue bytes of the f32 stream. 64 rows per round, the residual rows of round q + 1 are
 // requested before round q is processed. The dropout mask is the one of the f32-stream epilogue (same element index, same hash).
-template <int NI, int EPI>
-__device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+// F16 (the stream format) and DROP (a dropout mask applies) are wave-uniform launch arguments, decided ONCE by the dispatcher below: as run-time
+// tests inside pack2s / unpack2s / drop_mul4_w they were ~10 uniform branches (each with an s_waitcnt vmcnt(0) behind it) per output row.
+template <int NI, int EPI, bool F16, bool DROP>
+__device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  auto unpack = [](uint32_t u, float& lo, float& hi) {
+    if constexpr (F16) unpack2h(u, lo, hi);
+    else { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+  };
+  auto pack = [](float lo, float hi) -> uint32_t { if constexpr (F16) return pack2h(lo, hi); else return pack2bf(lo, hi); };
   const int fr = lane & 15, fc = lane >> 4;
   const int crow = lane >> 3, cch = lane & 7;
   const bf16_t* res = reinterpret_cast<const bf16_t*>(e.res);
@@ -847,8 +865,8 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
   };
   uint4 rsa[8], rsb[8];
   fetch(0, rsa);
-  const uint32_t rowstep = e.drop.thr ? (uint32_t)((4u * (uint32_t)e.N) * DROP_PHI) : 0u;      // 8 rows further = 4 N element pairs
-  uint32_t w0 = e.drop.thr ? drop_w0(e.drop.key, ((uint64_t)(mw + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
+  const uint32_t rowstep = DROP ? (uint32_t)((4u * (uint32_t)e.N) * DROP_PHI) : 0u;      // 8 rows further = 4 N element pairs
+  uint32_t w0 = DROP ? drop_w0(e.drop.key, ((uint64_t)(mw + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     uint4 (&rs)[8] = (q & 1) ? rsb : rsa;
@@ -869,9 +887,14 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
       const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
       const float c[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       float dm[8], o[8];
-      drop_mul4_w(e.drop, w0, dm);
-      drop_mul4_w(e.drop, w0 + 2u * DROP_PHI, dm + 4);
-      w0 += rowstep;
+      if constexpr (DROP) {
+        drop_mul4_on(e.drop, w0, dm);
+        drop_mul4_on(e.drop, w0 + 2u * DROP_PHI, dm + 4);
+        w0 += rowstep;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dm[k] = 1.0f;
+      }
       if constexpr (EPI == GSL_EPI_PATCH_BF16) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout (vit_face.py:531-537)
         const int tok = min(m, e.M - 1) % e.T;
         const float* pr = e.pos + (size_t)tok * e.N + ncl;
@@ -884,14 +907,24 @@ __device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float r0, r1;
-          unpack2s(a[k], e.f16, r0, r1);
+          unpack(a[k], r0, r1);
           o[2 * k] = (c[2 * k] + b8[2 * k]) * dm[2 * k] + r0;
           o[2 * k + 1] = (c[2 * k + 1] + b8[2 * k + 1]) * dm[2 * k + 1] + r1;
         }
       }
       if (m < e.M && n < e.N)
-        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack2s(o[0], o[1], e.f16), pack2s(o[2], o[3], e.f16), pack2s(o[4], o[5], e.f16), pack2s(o[6], o[7], e.f16)), GSL_STMODE_OF(e));
+        store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack(o[0], o[1]), pack(o[2], o[3]), pack(o[4], o[5]), pack(o[6], o[7])), GSL_STMODE_OF(e));
     }
+  }
+}
+template <int NI, int EPI>
+__device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+  if (e.f16) {
+    if (e.drop.thr) epilogue_staged_res_bf16_impl<NI, EPI, true, true>(e, acc, cst, mw, nw, lane);
+    else epilogue_staged_res_bf16_impl<NI, EPI, true, false>(e, acc, cst, mw, nw, lane);
+  } else {
+    if (e.drop.thr) epilogue_staged_res_bf16_impl<NI, EPI, false, true>(e, acc, cst, mw, nw, lane);
+    else epilogue_staged_res_bf16_impl<NI, EPI, false, false>(e, acc, cst, mw, nw, lane);
   }
 }
 constexpr int CST_WAVE = 2 * 64 * CLD;            // bf16 elements of staging per wave (two outputs)

@@ -253,6 +253,14 @@ __device__ __forceinline__ void drop_mul4_w(const DropCfg& d, uint32_t w0, float
   m[2] = ((h1 & 0xffffu) < d.thr) ? 0.0f : d.scale;
   m[3] = ((h1 >> 16) < d.thr) ? 0.0f : d.scale;
 }
+// the same without the "no dropout" test: for callers that decided it once, outside their loop
+__device__ __forceinline__ void drop_mul4_on(const DropCfg& d, uint32_t w0, float m[4]) {
+  const uint32_t h0 = drop_finish(w0), h1 = drop_finish(w0 + DROP_PHI);
+  m[0] = ((h0 & 0xffffu) < d.thr) ? 0.0f : d.scale;
+  m[1] = ((h0 >> 16) < d.thr) ? 0.0f : d.scale;
+  m[2] = ((h1 & 0xffffu) < d.thr) ? 0.0f : d.scale;
+  m[3] = ((h1 >> 16) < d.thr) ? 0.0f : d.scale;
+}
 __device__ __forceinline__ void drop_mul4(const DropCfg& d, uint64_t idx, float m[4]) {
   drop_mul4_w(d, d.thr ? drop_w0(d.key, idx >> 1) : 0u, m);
 }
