@@ -271,7 +271,7 @@ constexpr int CLD = 72;   // 144-byte rows: 16-byte aligned for ds_read_b128, 2-
 // nullptr: the lane's 16 values are loaded into registers once.
 // SMODE (STORE only; chosen ONCE per wave by the wrapper from wave-uniform launch arguments — decided per fragment, the same flags cost two taken
 // branches and a dozen selects in front of each of the 32 fragments, ~9 k cycles of a 256x256 tile: profiles/r06_k_epilogue_branches.md):
-//   0 = the accumulator as it is (alpha 1, no bias, no LayerNorm), 1 = the consumer-side LayerNorm, 2 = the general form (alpha, bias)
+//   0 = alpha * accumulator (no bias, no LayerNorm), 1 = the consumer-side LayerNorm, 2 = the general form (alpha, bias)
 // DK (table epilogue): 1 = dropout on, 2 = off — decided once per wave like SMODE; 0 = tested where it is used. (Tried and dropped: the keep bits of
 // the wave's sub-tile precomputed under the prologue wait + v_bfe_i32 / v_bfi_b32 selects — 17 of ~47 issue slots per fragment less and the epilogue's
 // 13.0 k cycles did not move, while the prologue grew by 4 k: this epilogue is bound by its LDS traffic — 128 table gathers, 64 staging writes and 24
@@ -376,6 +376,9 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
           if constexpr (SMODE == 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], rsv[ii], fmaf(-rmv[ii], cj[j][q], bj[j][q]));
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= e.alpha;      // (alpha = 1 for all but the LoRA down-projections; x * 1.0f is exact)
           }
           *reinterpret_cast<uint2*>(cst + (ii * 16 + fr) * CLD + j * 16 + fc * 4) = make_uint2(pack2o(v[0], v[1]), pack2o(v[2], v[3]));
           continue;
@@ -511,7 +514,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const EpiArgs& e, f32x4_t (
     if constexpr (EPI == GSL_EPI_STORE) {
       if (full && !bias_lds) {      // whole tiles (all of them at the step's shapes): the specialised forms
         if (e.ln_rstd != nullptr) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 1>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
-        if (e.alpha == 1.0f && !e.bias) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 0>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
+        if (!e.bias) { epilogue_staged_bf16_impl<EPI, NI, SEQ, true, TAB, 0>(e, acc, cst, mw, nw, lane, bias_lds, tab_lds); return; }
       }
     }
     if constexpr (TAB) {
