@@ -351,20 +351,26 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
       rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
     }
   }
+  // consumer-side LayerNorm: rstd and rstd * mean of ALL of this lane's rows, loaded before the first chunk — loaded per chunk, the wait for the
+  // second chunk's statistics (s_waitcnt vmcnt(0): loads and stores retire through one counter) also waited for the first chunk's eight stores to
+  // reach memory
+  float rsa[NI], rma[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) rsa[i] = rma[i] = 0.f;
+  if constexpr (EPI == GSL_EPI_STORE) {
+    if (ln) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int mr = min(mw + i * 16 + fr, e.M - 1);
+        rsa[i] = e.ln_rstd[(size_t)mr * e.ln_rs];
+        rma[i] = rsa[i] * e.ln_mean[(size_t)mr * e.ln_rs];
+      }
+    }
+  }
 #pragma unroll
   for (int ib = 0; ib < NI; ib += 4) {
     uint2 held[4][4];   // second output, packed, when SEQ
-    float rsv[4] = {0.f, 0.f, 0.f, 0.f}, rmv[4] = {0.f, 0.f, 0.f, 0.f};      // consumer-side LayerNorm: rstd and rstd * mean of this lane's 4 rows of the chunk
-    if constexpr (EPI == GSL_EPI_STORE) {
-      if (ln) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int mr = min(mw + (ib + ii) * 16 + fr, e.M - 1);
-          rsv[ii] = e.ln_rstd[(size_t)mr * e.ln_rs];
-          rmv[ii] = rsv[ii] * e.ln_mean[(size_t)mr * e.ln_rs];
-        }
-      }
-    }
+    const float rsv[4] = {rsa[ib], rsa[ib + 1], rsa[ib + 2], rsa[ib + 3]}, rmv[4] = {rma[ib], rma[ib + 1], rma[ib + 2], rma[ib + 3]};
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
