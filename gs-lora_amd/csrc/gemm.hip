@@ -879,15 +879,15 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     uint4 (&rs)[8] = (q & 1) ? rsb : rsa;
-    if (q + 1 < NQ) fetch(q + 1, (q & 1) ? rsa : rsb);
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[q * 4 + ii][j];
-        v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
-        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;      // (alpha is 1 for this epilogue: the host rejects anything else)
       }
+    __builtin_amdgcn_sched_barrier(0);      // the next round's rows are requested AFTER this round's 64 accumulator registers are staged (free)
+    if (q + 1 < NQ) fetch(q + 1, (q & 1) ? rsa : rsb);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = r * 8 + crow;
@@ -923,6 +923,10 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
       }
       if (m < e.M && n < e.N)
         store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack(o[0], o[1]), pack(o[2], o[3]), pack(o[4], o[5]), pack(o[6], o[7])), GSL_STMODE_OF(e));
+      // rows stay in program order: without the branches that used to separate them the scheduler hoisted the masks and unpacked residuals of
+      // several rows above each other, next to 128 accumulators and two sets of prefetched rows — 22 - 29 spilled dwords, +91 MB of scratch traffic
+      // per FFN2-forward launch (PMC WRITE_SIZE 232 -> 323 MB) on the in-order memory pipe
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
