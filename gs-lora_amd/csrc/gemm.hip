@@ -41,6 +41,7 @@ struct EpiArgs {
   int T;
   DropCfg drop;
   int M, N;
+  int mbase;   // rows in front of this launch's row 0 in the caller's tensor (tail split, see launch_tail_split): enters the dropout counters only
   int remap;   // block-id -> tile mapping (development knob GSL_XCD_REMAP; 1 = XCD-contiguous)
   int pf;      // 8-phase kernel: after its K loop a workgroup touches the first A lines of the tile that takes a slot of its XCD next (see the kernel)
   int mrev;    // 8-phase kernel: tiles in reverse order (the consumer starts on the rows its producer wrote last: still in the 256 MB Infinity Cache)
@@ -134,7 +135,7 @@ __device__ __forceinline__ uint32_t gelu_tab_entry(float a, float tab_c4) {
 template <int EPI, typename T, bool HASW = false>
 __device__ __forceinline__ void epi_math(const EpiArgs& e, int m, int n, float v[4], float g[4], const float* bp = nullptr, uint32_t w0 = 0u) {
   const size_t off = (size_t)m * e.ldo + n;
-  const uint64_t lin = (uint64_t)m * (uint64_t)e.N + (uint64_t)n;
+  const uint64_t lin = (uint64_t)(m + e.mbase) * (uint64_t)e.N + (uint64_t)n;
   if constexpr (EPI == GSL_EPI_STORE || EPI == GSL_EPI_STORE_F32 || epi_is_mul<EPI>()) {
     if (e.alpha != 1.0f) {
 #pragma unroll
@@ -347,7 +348,7 @@ __device__ __forceinline__ void epilogue_staged_bf16_impl(const EpiArgs& e, f32x
   uint32_t wbase = 0u, rowstep = 0u;
   if constexpr (DROPW) {
     if (e.drop.thr) {
-      wbase = drop_w0(e.drop.key, ((uint64_t)(mw + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1);
+      wbase = drop_w0(e.drop.key, ((uint64_t)(mw + e.mbase + fr) * (uint64_t)e.N + (uint64_t)(nw + fc * 4)) >> 1);
       rowstep = (8u * (uint32_t)e.N) * DROP_PHI;
     }
   }
@@ -822,7 +823,7 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
       const int m = mw + ib * 16 + row;
       const f32x4_t c = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cq * 4);
       float dm[4];
-      drop_mul4(e.drop, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, dm);
+      drop_mul4(e.drop, (uint64_t)(m + e.mbase) * (uint64_t)e.N + (uint64_t)n, dm);
       f32x4_t o;
       if constexpr (EPI == GSL_EPI_PATCH) {       // (tok == 0 ? cls : acc + bias) + pos, then dropout
         const bool is_cls = (m % e.T) == 0;
@@ -875,7 +876,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
   uint4 rsa[8], rsb[8];
   fetch(0, rsa);
   const uint32_t rowstep = DROP ? (uint32_t)((4u * (uint32_t)e.N) * DROP_PHI) : 0u;      // 8 rows further = 4 N element pairs
-  uint32_t w0 = DROP ? drop_w0(e.drop.key, ((uint64_t)(mw + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
+  uint32_t w0 = DROP ? drop_w0(e.drop.key, ((uint64_t)(mw + e.mbase + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     uint4 (&rs)[8] = (q & 1) ? rsb : rsa;
@@ -1942,7 +1943,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 // tile is chosen from the shape alone. The development build (-DGSL_DEV -> libgslora_hip_dev.so, selected with GSLORA_HIP_LIB) reads
 // the ablation / variant knobs of tools/bench_gemm*.py and tools/probes/ from the environment.
 static inline void set_launch_knobs(EpiArgs& e, bool allow_krot) {
-  e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0; e.o4_delay = 0;
+  e.mbase = 0; e.remap = 1; e.krot = 0; e.stmode = GSL_STMODE; e.f16 = 0; e.stamps = nullptr; e.stamps_all = 0; e.mrev = 0; e.pf = 0; e.o4_delay = 0;
   e.ln_mean = nullptr; e.ln_rstd = nullptr; e.ln_c = nullptr; e.ln_d = nullptr; e.ln_rs = 1;
 #ifdef GSL_DEV
   { const char* rm = getenv("GSL_XCD_REMAP"); if (rm) e.remap = atoi(rm); }
@@ -2164,6 +2165,45 @@ static int launch_gemm(int dtype, const void* A1, int lda1, const void* W1, int 
   return check_launch("gsl_gemm_nt");
 }
 
+// ---- tail split (round 6). The 8-phase kernel runs one 256 x 256 tile per CU at a time, so a launch takes ceil(tiles / CUs) tile times: the
+// N = 512 GEMMs of the step (out-proj forward and dX, QKV dX, FFN1-dX, FFN2 forward: 1 576 tiles on 256 CUs = 6.16 rounds) pay SEVEN — 12 % of
+// five GEMMs per layer. When the last round would be at most 30 % full, the launch is split by rows: whole rounds of 256 x 256 tiles, then the
+// remaining row panels as a second launch, which the tile rule puts on the 64 x 64 ring kernel (640 small workgroups, three per CU: ~0.25 tile
+// times instead of one). Same MFMA instruction, same k order, same epilogue arithmetic: the rows of the tail are bit-identical to what the
+// 8-phase kernel writes (tests/test_hip_ops.py::test_gemm_tail_split_*); their dropout counters continue at row `mbase` (EpiArgs::mbase).
+static inline int gemm_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+#ifndef GSL_TAIL_SPLIT
+#define GSL_TAIL_SPLIT 1
+#endif
+// rows of the tail launch (0: no split): 16-bit operands on the 8-phase class, whole tiles, a last round of at most 30 % of the CUs
+static inline int tail_split_rows(int M, int N, int dtype) {
+  bool on = GSL_TAIL_SPLIT != 0;
+#ifdef GSL_DEV
+  { const char* t = getenv("GSL_TAIL_SPLIT"); if (t) on = atoi(t) != 0; }
+#endif
+  if (!on || dtype != GSL_OP16 || (M % 256) || (N % 256) || N < 512) return 0;
+  const long nt = N / 256, tiles = (long)(M / 256) * nt, ncu = gemm_num_cus();
+  if (tiles <= ncu) return 0;
+  const long r = tiles % ncu;
+  if (r == 0 || r * 10 > ncu * 3 || (r % nt)) return 0;
+  return (int)(r / nt) * 256;
+}
+static inline const void* rows_after(const void* p, long rows, long ld, int esize) { return p ? static_cast<const char*>(p) + rows * ld * esize : nullptr; }
+static inline void* rows_after(void* p, long rows, long ld, int esize) { return p ? static_cast<char*>(p) + rows * ld * esize : nullptr; }
+
+static int gemm_nt_rows(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
+                        const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
+                        const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
+                        const float* pos, const float* cls, int T, float p_drop, uint64_t seed, uint32_t site,
+                        gsl_stream_t s, int mbase);
+
 extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
                            const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
                            const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
@@ -2171,6 +2211,27 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
                            gsl_stream_t s) {
   GSL_FORWARD_H16(dtype, h16_gsl_gemm_nt(A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, M, N, dtype, epilogue, alpha, bias, res, aux, out, out2,
                                          ldo, pos, cls, T, p_drop, seed, site, s));
+  // plain STORE and the 16-bit residual epilogues split (operands, residual and output are 2-byte row-major tensors: the tail is a pointer offset)
+  const bool splittable = (epilogue == GSL_EPI_STORE && !out2) || epilogue == GSL_EPI_BIAS_RES_BF16 || epilogue == GSL_EPI_BIAS_RES_F16;
+  const int tail = (splittable && A1 && W1 && out && M >= 1024) ? tail_split_rows(M, N, dtype) : 0;
+  if (tail > 0) {
+    const int head = M - tail;
+    const int rc = gemm_nt_rows(A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, head, N, dtype, epilogue, alpha, bias, res, aux, out, out2, ldo, pos, cls,
+                                T, p_drop, seed, site, s, 0);
+    if (rc) return rc;
+    return gemm_nt_rows(rows_after(A1, head, lda1, 2), lda1, W1, ldw1, K1, K2 ? rows_after(A2, head, lda2, 2) : A2, lda2, W2, ldw2, K2, tail, N, dtype,
+                        epilogue, alpha, bias, rows_after(res, head, ldo, 2), aux, rows_after(out, head, ldo, 2), out2, ldo, pos, cls, T, p_drop, seed, site, s,
+                        head);
+  }
+  return gemm_nt_rows(A1, lda1, W1, ldw1, K1, A2, lda2, W2, ldw2, K2, M, N, dtype, epilogue, alpha, bias, res, aux, out, out2, ldo, pos, cls, T, p_drop, seed,
+                      site, s, 0);
+}
+
+static int gemm_nt_rows(const void* A1, int lda1, const void* W1, int ldw1, int K1, const void* A2, int lda2,
+                        const void* W2, int ldw2, int K2, int M, int N, int dtype, int epilogue, float alpha,
+                        const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
+                        const float* pos, const float* cls, int T, float p_drop, uint64_t seed, uint32_t site,
+                        gsl_stream_t s, int mbase) {
   GSL_CHECK_ARG((GSL_HAS_F32 && dtype == GSL_F32) || dtype == GSL_OP16, "dtype");
   GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0, "M>0, N>0, N%4==0");
   GSL_CHECK_ARG(K1 > 0 && (K1 % 64) == 0 && K2 >= 0 && (K2 % 64) == 0, "K1,K2 multiples of 64");
@@ -2182,6 +2243,7 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
   e.alpha = alpha; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = pos; e.cls = cls; e.T = T; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   set_launch_knobs(e, true);
+  e.mbase = mbase;
   e.hmT = 0; e.hmH = 0;
   hipStream_t st = as_stream(s);
   switch (epilogue) {
@@ -2237,12 +2299,36 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt)(const void* A1, int lda1, const void* W1, 
   }
 }
 
+static int gemm_nt_lora_rows(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+                             int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
+                             const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
+                             float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s, int mbase);
+
 extern "C" int GSL_ENTRY(gsl_gemm_nt_lora)(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
                                 int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
                                 const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
                                 float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s) {
   GSL_FORWARD_H16(dtype, h16_gsl_gemm_nt_lora(A, lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, tout, ldt, M, N, dtype, epilogue, bias, res, aux, out,
                                               out2, ldo, p_drop, seed, site, s));
+  // tail split (see gsl_gemm_nt): the in-kernel-LoRA form exists on the 64 x 64 ring kernel too; t = s A P^T of the tail rows goes to tout's tail rows
+  const bool splittable = (epilogue == GSL_EPI_STORE && !out2) || epilogue == GSL_EPI_BIAS_RES_BF16 || epilogue == GSL_EPI_BIAS_RES_F16;
+  const int tail = (splittable && A && W && out && M >= 1024) ? tail_split_rows(M, N, dtype) : 0;
+  if (tail > 0) {
+    const int head = M - tail;
+    const int rc = gemm_nt_lora_rows(A, lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, tout, ldt, head, N, dtype, epilogue, bias, res, aux, out, out2, ldo,
+                                     p_drop, seed, site, s, 0);
+    if (rc) return rc;
+    return gemm_nt_lora_rows(rows_after(A, head, lda, 2), lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, rows_after(tout, head, ldt, 2), ldt, tail, N, dtype,
+                             epilogue, bias, rows_after(res, head, ldo, 2), aux, rows_after(out, head, ldo, 2), out2, ldo, p_drop, seed, site, s, head);
+  }
+  return gemm_nt_lora_rows(A, lda, W, ldw, K, P, ldp, Q, ldq, lora_scale, tout, ldt, M, N, dtype, epilogue, bias, res, aux, out, out2, ldo, p_drop, seed,
+                           site, s, 0);
+}
+
+static int gemm_nt_lora_rows(const void* A, int lda, const void* W, int ldw, int K, const void* P, int ldp, const void* Q,
+                             int ldq, float lora_scale, void* tout, int ldt, int M, int N, int dtype, int epilogue,
+                             const float* bias, const void* res, const void* aux, void* out, void* out2, int ldo,
+                             float p_drop, uint64_t seed, uint32_t site, gsl_stream_t s, int mbase) {
   if (dtype != GSL_OP16) return fail(GSL_ERR_UNSUPPORTED, "gsl_gemm_nt_lora: bf16 / fp16 operands only (f32 parity mode uses gsl_gemm_nt with a K segment)%s %ld", "", dtype);
   GSL_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && (K % 64) == 0, "M,N>0, N%4==0, K%64==0");
   GSL_CHECK_ARG(A && W && P && Q && out, "null operand");
@@ -2253,6 +2339,7 @@ extern "C" int GSL_ENTRY(gsl_gemm_nt_lora)(const void* A, int lda, const void* W
   e.alpha = 1.0f; e.bias = bias; e.res = res; e.aux = aux; e.out = out; e.out2 = out2; e.ldo = ldo;
   e.pos = nullptr; e.cls = nullptr; e.T = 0; e.drop = make_drop(p_drop, seed, site); e.M = M; e.N = N;
   set_launch_knobs(e, true);
+  e.mbase = mbase;
   e.hmT = 0; e.hmH = 0;
   LoraInk lk;
   lk.P = (const bf16_t*)P; lk.ldp = ldp; lk.Q = (const bf16_t*)Q; lk.ldq = ldq; lk.s = lora_scale; lk.tout = (bf16_t*)tout; lk.ldt = ldt;

@@ -1571,3 +1571,57 @@ def test_fp16_loss_scale_backs_off_on_the_device_after_a_saturated_backward(ops)
     check(4)                                                      # floor
     with pytest.raises(RuntimeError):
         call(target_exp=3)
+
+
+# ---------------------------------------------------------------------------------------------------------------- tail split (round 6)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,lora", [(512, False), (1536, False), (2048, True), (512, True)])
+def test_gemm_tail_split_bit_identical_to_the_single_launch(ops, dev_lib, monkeypatch, dt, K, lora):
+    """Round 6: a GEMM of the 8-phase class whose last round of 256 x 256 tiles would be at most 30 % full (M = 201 728, N = 512: 1 576 tiles on
+    256 CUs = 6.16 rounds) is launched as whole rounds + a tail of 64 x 64 tiles for the remaining row panels (csrc/gemm.hip: tail_split_rows). The
+    tail rows must be BIT-IDENTICAL to what the single 8-phase launch writes (same MFMA instruction, k order and epilogue arithmetic) — the fused
+    two-batch forward has to equal two forwards bit for bit —, including the dropout mask of the residual epilogue (the tail's counters continue
+    at its first row) and the in-kernel-LoRA form with its t = s A P^T output. Single launch = dev build with GSL_TAIL_SPLIT=0."""
+    from gslora_hip import _lib as L
+    M, N, r = 201728, 512, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.float16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    P = torch.zeros(16, K, device="cuda"); P[:r] = torch.randn(r, K, device="cuda", generator=g) * K ** -0.5
+    Q = torch.zeros(N, 32, device="cuda"); Q[:, :r] = torch.randn(N, r, device="cuda", generator=g) * 0.3
+    P, Q = P.to(dt), Q.to(dt)
+
+    def run():
+        o1 = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+        o2 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+        t1 = torch.full((M, 64), float("nan"), device="cuda", dtype=dt) if lora else None
+        t2 = torch.full((M, 64), float("nan"), device="cuda", dtype=dt) if lora else None
+        if lora:
+            ops.gemm_nt_lora(A, W, P, Q, 1.0 / r, t1, o1)
+            ops.gemm_nt_lora(A, W, P, Q, 1.0 / r, t2, o2, epilogue=L.EPI_BIAS_RES_F16, bias=bias, res=res, p_drop=0.1, seed=77, site=6)
+        else:
+            ops.gemm_nt(A, W, o1)
+            ops.gemm_nt(A, W, o2, epilogue=L.EPI_BIAS_RES_F16, bias=bias, res=res, p_drop=0.1, seed=77, site=6)
+        return o1, o2, t1, t2
+    split = run()                                   # product library: 196 608 rows on the 8-phase kernel + 5 120 rows on the 64 x 64 ring
+    dev_lib(L)
+    monkeypatch.setenv("GSL_TAIL_SPLIT", "0")
+    single = run()
+    for a, b in zip(split, single):
+        if a is not None:
+            assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    # and the split does happen in the product build: the dev build with the split ON agrees with it as well (same code path)
+    monkeypatch.setenv("GSL_TAIL_SPLIT", "1")
+    again = run()
+    assert torch.equal(again[1], split[1])
+    # the mask really covers the tail with its own counters: keep rate of the tail rows
+    ref_nodrop = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    if not lora:
+        ops.gemm_nt(A, W, ref_nodrop, epilogue=L.EPI_BIAS_RES_F16, bias=bias, res=res)
+        keep = ops.dropout_mask(M * N, 0.1, 77, 6, "cuda").reshape(M, N)
+        tail = slice(M - 5120, M)
+        dropped = (split[1][tail] == res[tail])     # a dropped element is exactly the residual
+        assert torch.equal(dropped | (keep[tail] != 0), torch.ones_like(dropped)) and abs(float((keep[tail] == 0).float().mean()) - 0.1) < 5e-3
+        assert (dropped & (keep[tail] != 0)).float().mean() < 1e-3      # (a kept element equals the residual only when the sum rounds away)

@@ -511,3 +511,40 @@ def test_gelu_table_is_the_generated_one_and_as_accurate_as_declared():
     assert np.abs(phi[idx] - Phix).max() <= 4.5e-4
     assert np.abs(x * (phi[idx] - Phix)).max() <= 2.8e-4          # error of h = a * Phi
     assert np.abs((code[idx] - 26) / 200.0 - gpx).max() <= 0.0025 + 9e-4
+
+
+def test_no_kernel_of_the_product_library_spills_registers():
+    """Round 6: a spilled register is a scratch access on the CU's in-order vector-memory pipe (the attention forward's 4 spilled VGPRs, VERDICT r05
+    #5; the de-branched residual epilogue's 22 - 29 spilled dwords cost the FFN2 forward +91 MB of writes per launch until it was re-ordered). The code
+    objects embedded in libgslora_hip.so (gfx950) must declare .vgpr_spill_count 0 and no private segment for every kernel."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    from gslora_hip import build as B
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not in this image")
+    data = open(B.OUT, "rb").read()
+    kernels, bad = 0, []
+    with tempfile.TemporaryDirectory() as d:
+        for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+            base = m.start()
+            off = base + 32
+            for _ in range(struct.unpack_from("<Q", data, base + 24)[0]):
+                o, sz, tl = struct.unpack_from("<QQQ", data, off); off += 24
+                triple = data[off:off + tl].decode(); off += tl
+                if "gfx950" not in triple or not sz:
+                    continue
+                fn = os.path.join(d, "co.elf")
+                open(fn, "wb").write(data[base + o:base + o + sz])
+                notes = subprocess.run([readelf, "--notes", fn], capture_output=True, text=True, check=True).stdout
+                for blk in notes.split("- .agpr_count")[1:]:
+                    kernels += 1
+                    name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                    spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+                    priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+                    if spill or priv:
+                        bad.append((name, spill, priv))
+    assert kernels > 300, kernels
+    assert not bad, bad
