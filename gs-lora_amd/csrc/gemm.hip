@@ -690,12 +690,19 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
         *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
     __builtin_amdgcn_sched_barrier(0);    // nothing that consumes the requested operands may be scheduled above the staging (it would drag their wait up)
+    // the round's four staged rows are read back at once (round 6: one LDS round trip per round instead of one per row)
+    f32x4_t slo[4], shi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      slo[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8);
+      shi[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8 + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r * 8 + crow;
       const int m = mw + ic * 32 + row, n = nw + cch * 8;
-      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8);
-      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cst + row * CLF + cch * 8 + 4);
+      const f32x4_t lo = slo[r], hi = shi[r];
       uint32_t o[4];
       if constexpr (G8) {
         float ga[4], gb[4];
@@ -1528,6 +1535,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   constexpr unsigned long long* dbg8 = nullptr;
 #endif
   if (dbg8) dbg8[0] = __builtin_readcyclecounter();
+  // Every kernel argument the K loop's requests read is consumed once HERE: the compiler loads kernel arguments lazily (s_load) and waits for them at
+  // their first use — inside the loop that was an s_waitcnt lgkmcnt(0) in phase q0 of every K tile, i.e. a wait for the eight fragment reads just issued
+  // in front of the LDS-DMA request (scalar loads and LDS reads share the counter).
+  asm volatile("" ::"s"(A1), "s"(W1), "s"(A2), "s"(W2), "s"(lda1), "s"(ldw1), "s"(lda2), "s"(ldw2), "s"(K1), "s"(K2), "s"(e.M), "s"(e.N));
   // prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
   stage(0, P0{}); stage(0, P1{}); stage(0, P2{}); stage(0, P3{});
   stage(1, P0{}); stage(1, P1{}); stage(1, P2{});
