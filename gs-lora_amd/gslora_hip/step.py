@@ -97,6 +97,23 @@ def _bucket_messages(net, backend):
     return [flat[split:], flat[:split]]      # blocks 1 .. L-1 (final once the backward reaches block 0), then block 0
 
 
+def _guard_message(net):
+    """fp16 operands under data parallelism: the overflow guard of the backward that just ran (ViTRunner.overflow_guard(), one device float)
+    as the int32 word every rank MAX-reduces after its gradient messages — non-negative floats, +inf and NaN order as their bit patterns, so
+    an integer MAX agrees on "some rank saturated" whatever the backend does with a floating NaN. All ranks then skip (or take) the update
+    together and settle the same next loss-scale exponent from the same value. None when the backward did not run on loss-scaled gradients
+    (every rank of a job computes in the same format, so either all ranks post this message or none does)."""
+    runner = getattr(net, "_runner", None)
+    g = runner.overflow_guard() if runner is not None and hasattr(runner, "overflow_guard") else None
+    return None if g is None else g[:1].view(torch.int32)
+
+
+def _post_guard(net):
+    gm = _guard_message(net)
+    if gm is not None:
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+
+
 class _OverlappedBucketReduce:
     """Gradient all-reduce in two messages: blocks 1..L-1 on a side stream as soon as block 1's gradients are written (it runs
     under block 0's FFN backward), block 0 afterwards. The structure-loss gradient is parameter-only and pre-scaled by 1/world; its
@@ -139,8 +156,10 @@ class _OverlappedBucketReduce:
         if self.work is None:        # no overlap (single block, two backwards, or a hook that never fired): the same messages, in order
             for m in (self.msgs if self.msgs is not None else _bucket_messages(self.net, self.backend)):
                 dist.all_reduce(m)
+            _post_guard(self.net)
             return
         dist.all_reduce(self.msgs[1])
+        _post_guard(self.net)
         self.work.wait()
         if self.msgs[0].is_cuda:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -182,13 +201,13 @@ def _arm_overflow_guard(net, optimizer):
     """fp16 operands: hand the optimizer the overflow guard of the backward that just ran (ViTRunner.overflow_guard(): the device float the
     LayerNorm backwards raised to the largest scaled gradient they saw) — FusedAdamW then skips the update of a step in which a 16-bit gradient
     store saturated (torch.cuda.amp.GradScaler.step semantics, no host sync); the next backward lowers its loss scale on the device. Under
-    data parallelism every rank keeps its own guard and scale, and a skip would have to be agreed on: there the update is NOT skipped (the
-    guard still lowers the rank's next scale, and ViTRunner.gscale shows it)."""
+    data parallelism the ranks have agreed on the guard by then (one 4-byte MAX all-reduce behind the gradient messages, _guard_message):
+    they skip together, and they lower their scales together."""
     if not hasattr(optimizer, "overflow_guard"):
         return
     runner = getattr(net, "_runner", None)
     g = runner.overflow_guard() if runner is not None and hasattr(runner, "overflow_guard") else None
-    optimizer.overflow_guard = None if _dp_active() else g
+    optimizer.overflow_guard = g
 
 
 def gs_lora_step(model, optimizer, criterion, x_r, y_r, x_f, y_f, *, beta, alpha, BND, use_structure=True,
@@ -316,12 +335,12 @@ class _SegmentedCapture:
         if ctx is not None:
             ctx.__exit__(*exc)
 
-    def _cut(self, tensors):
-        """Close the current segment; `tensors` are all-reduced, in order, between it and the next one at every replay. Nothing is sent
+    def _cut(self, tensors, maxed=()):
+        """Close the current segment; `tensors` are all-reduced (sum), then `maxed` (max), in order, between it and the next one at every replay. Nothing is sent
         during the capture pass itself (no kernel runs while capturing, the buffers hold no values yet): a rank that captures posts
         exactly one step's worth of collectives — those of the replay that follows — like a rank that runs the same step eagerly."""
         self.end()
-        self.colls.append(list(tensors))
+        self.colls.append([(t, dist.ReduceOp.SUM) for t in tensors] + [(t, dist.ReduceOp.MAX) for t in maxed])
         self.begin()
 
     def all_reduce_scalars(self, pack):
@@ -332,7 +351,8 @@ class _SegmentedCapture:
 
         class _R:
             def finish(self_inner):
-                cap._cut(_bucket_messages(net, backend))      # the eager step's messages, in its order
+                gm = _guard_message(net)
+                cap._cut(_bucket_messages(net, backend), [] if gm is None else [gm])      # the eager step's messages, in its order
 
             def cancel(self_inner):
                 pass
@@ -342,8 +362,8 @@ class _SegmentedCapture:
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.colls):
-                for t in self.colls[i]:
-                    dist.all_reduce(t)
+                for t, op in self.colls[i]:
+                    dist.all_reduce(t, op=op)
 
 
 class GraphedStep:

@@ -2,7 +2,9 @@
 one GPU the box has; the process group is gloo (RCCL refuses two ranks on one device), so what is exercised is everything of the N > 1
 path except RCCL's transport: the real HIP kernels on half the batch, the packed scalar all-reduce in front of the hinges, the two-message
 gradient all-reduce overlapped on a side stream, and the three-segment graph replay with eager collectives in between.
-argv: rank world port dtype out.npz"""
+argv: rank world port dtype out.npz [overflow]
+With `overflow` (fp16 only): three eager steps; in the second one rank 1 alone reports a saturated backward — the ranks must agree (skip
+together, lower their loss scales together, keep identical replicas)."""
 import copy
 import os
 import sys
@@ -31,12 +33,49 @@ def whole_batch(cfg, world, s):
     return batch(cfg, B * world, s)
 
 
+def overflow_run(rank, world, out):
+    from gslora_hip import step as S
+    from gslora_hip.optim import FusedAdamW
+    cfg = recipe.cfg_small2()
+    m = build(cfg, "fp16", 0.0)
+    opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    crit = torch.nn.CrossEntropyLoss()
+    kw = hyper(cfg)
+    train = [p for p in m.parameters() if p.requires_grad]
+    sl = slice(rank * B, (rank + 1) * B)
+    post, hit = S._post_guard, {"on": False}
+
+    def poked(net):          # what a saturated 16-bit gradient store on THIS rank leaves in its guard before the ranks compare notes
+        if hit["on"]:
+            net._runner.gscale[2] = float("inf")
+        post(net)
+    S._post_guard = poked
+    exps, seen, moved = [], [], []
+    for s in range(3):
+        hit["on"] = (s == 1 and rank == 1)
+        before = [p.detach().clone() for p in train]
+        S.gs_lora_step(m, opt, crit, *(t[sl].contiguous() for t in whole_batch(cfg, world, s)), **kw)
+        torch.cuda.synchronize()
+        rep = m._runner.loss_scale_report()
+        exps.append(rep["exponent"]); seen.append(rep["seen_max"])
+        moved.append(any(not torch.equal(a, b) for a, b in zip(before, train)))
+    res = {"exps": np.array(exps), "seen": np.array(seen), "moved": np.array(moved)}
+    for n, a in m.named_parameters():
+        if a.requires_grad:
+            res[n] = a.detach().float().cpu().numpy()
+    np.savez(out, **res)
+
+
 def main():
     rank, world, port, dtype, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     from gslora_hip import step as S
     from gslora_hip.optim import FusedAdamW
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
+        if len(sys.argv) > 6 and sys.argv[6] == "overflow":
+            overflow_run(rank, world, out)
+            print("DP-GLOO-GPU-OK", flush=True)
+            return
         cfg = recipe.cfg_small2()
         m1 = build(cfg, dtype, 0.0)
         m2 = copy.deepcopy(m1)

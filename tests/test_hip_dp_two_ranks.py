@@ -17,6 +17,31 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _run_ranks(tmp_path, dtype, *extra):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_gloo_gpu_child.py"), str(r), "2", str(port), dtype, outs[r], *extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 and "DP-GLOO-GPU-OK" in lg[0] for p, lg in zip(procs, logs)), [(p.returncode, lg[0][-500:], lg[1][-3000:]) for p, lg in zip(procs, logs)]
+    return [dict(np.load(o)) for o in outs]
+
+
+def test_two_ranks_agree_on_a_saturated_fp16_step(tmp_path):
+    """fp16 operands under data parallelism: the overflow guard is MAX-reduced behind the gradient messages (step._guard_message), so a
+    backward that saturated on ONE rank makes BOTH ranks skip that update and lower their loss-scale exponents by two binades for the next
+    backward — replicas stay identical, no rank applies a gradient sum that holds another rank's clipped values."""
+    r0, r1 = _run_ranks(tmp_path, "fp16", "overflow")
+    for k in r0:
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), (k, r0[k], r1[k])
+    assert r0["moved"].tolist() == [True, False, True], r0["moved"]
+    assert np.isinf(r0["seen"][1]) and np.isfinite(r0["seen"][[0, 2]]).all(), r0["seen"]
+    e = r0["exps"]
+    assert e[1] == e[0] and e[2] == e[0] - 2, e
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2), ("fp16", 4e-3)])
 def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, dtype, tol):
     sys.path.insert(0, HERE)
@@ -24,15 +49,7 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, dtype, tol
     from test_hip_graph import build
     from gslora_hip.optim import FusedAdamW
     from gslora_hip.step import gs_lora_step
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_gloo_gpu_child.py"), str(r), "2", str(port), dtype, outs[r]],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    logs = [p.communicate(timeout=900) for p in procs]
-    assert all(p.returncode == 0 and "DP-GLOO-GPU-OK" in lg[0] for p, lg in zip(procs, logs)), [(p.returncode, lg[0][-500:], lg[1][-3000:]) for p, lg in zip(procs, logs)]
-    r0, r1 = (dict(np.load(o)) for o in outs)
+    r0, r1 = _run_ranks(tmp_path, dtype)
     for k in r0:      # identical replicas and identical global meters on both ranks, bit for bit
         assert np.array_equal(r0[k], r1[k]), k
     # single process, whole batch

@@ -327,14 +327,19 @@ def test_data_parallel_gradient_messages_do_not_depend_on_the_mode(monkeypatch):
     The capture pass itself must post nothing."""
     from gslora_hip import step as st
     sent = []
-    monkeypatch.setattr(st.dist, "all_reduce", lambda t, async_op=False: (sent.append(t.numel()), type("W", (), {"wait": lambda self: None})())[1])
+    monkeypatch.setattr(st.dist, "all_reduce", lambda t, op=None, async_op=False: (sent.append(t.numel() if op in (None, st.dist.ReduceOp.SUM) else ("max", t.dtype)),
+                                                                                  type("W", (), {"wait": lambda self: None})())[1])
     flat = torch.zeros(100)
 
     class Runner:
         grad_hook = None
+        guard = None
+
+        def overflow_guard(self):
+            return self.guard
 
     class Net:
-        r = Runner()
+        r = _runner = Runner()
 
         def runner(self):
             return self.r
@@ -383,6 +388,24 @@ def test_data_parallel_gradient_messages_do_not_depend_on_the_mode(monkeypatch):
     one = type("B1", (), {"grad_bucket": staticmethod(lambda n: flat)})
     st._OverlappedBucketReduce(net, one).finish()
     assert sent == [100]
+    # fp16 operands: the overflow guard follows the gradient messages as one int32 MAX word, in every mode
+    Runner.guard = torch.zeros(2)
+    G = ("max", torch.int32)
+    for overlap in (True, False):
+        sent.clear()
+        red = st._OverlappedBucketReduce(net, Backend, overlap=overlap)
+        if overlap:
+            net.r.grad_hook(1)
+        red.finish()
+        assert sent == [70, 30, G], sent
+    sent.clear()
+    cap.graphs, cap.colls = [], []
+    cap.begin()
+    cap.all_reduce_scalars(pack)
+    cap.bucket_reducer(net, Backend).finish()
+    assert sent == []
+    cap.replay()
+    assert sent == [8, 70, 30, G], sent
 
 
 def test_meter_queue_stops_on_non_finite_meters():
