@@ -625,11 +625,19 @@ template <typename V> __device__ __forceinline__ V gf_ld(const void* p) {      /
 }
 // global operands of one 32-row round of the gradient-fused epilogue: g' and h (4 x 16 B per lane each), U1 (2 x 16 B for lanes 0..31's rows)
 struct GfOperands { uint4 ax[4], hx[4], u1; };
+// development ablations of the gradient-fused epilogue (build variant -DGSL_MG_ABL=1, mask in GSL_O4_DELAY; results are WRONG by design):
+// 2 = no g' / h / U1 loads, 4 = no transposed reads / reduction MFMAs, 8 = no dZ / h / U1 LDS hand-over (with 4), 16 = no f32 staging round trip
+#if defined(GSL_DEV) && defined(GSL_MG_ABL)
+#define GSL_MG_ON(e, bit) (!((e).o4_delay & (bit)))
+#else
+#define GSL_MG_ON(e, bit) true
+#endif
 template <bool G8>
 __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int mw, int nw, int ic, int lane) {
   const int crow = lane >> 3, cch = lane & 7;
   const int ncl = min(nw + cch * 8, e.N - 8);
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.aux);
+  if (!GSL_MG_ON(e, 2)) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = min(mw + ic * 32 + r * 8 + crow, e.M - 1);
@@ -687,15 +695,17 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[ic * 2 + ii][j];
         v *= e.alpha;      // (x * 1.0f is exact: cheaper than a wave-uniform branch in front of every fragment)
-        *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
+        if (GSL_MG_ON(e, 16)) *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
     __builtin_amdgcn_sched_barrier(0);    // nothing that consumes the requested operands may be scheduled above the staging (it would drag their wait up)
     // the round's four staged rows are read back at once (round 6: one LDS round trip per round instead of one per row)
     f32x4_t slo[4], shi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      slo[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8);
-      shi[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8 + 4);
+      if (GSL_MG_ON(e, 16)) {
+        slo[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8);
+        shi[r] = *reinterpret_cast<const f32x4_t*>(cst + (r * 8 + crow) * CLF + cch * 8 + 4);
+      } else { slo[r] = acc[ic * 2][r]; shi[r] = acc[ic * 2 + 1][r]; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -722,12 +732,12 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       }
       const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
       if (m < e.M && n < e.N) store_stream16(out + (size_t)m * e.ldo + n, ov, GSL_STMODE_OF(e));
-      *reinterpret_cast<uint4*>(yd + row * CLD + cch * 8) = ov;
+      if (GSL_MG_ON(e, 8)) *reinterpret_cast<uint4*>(yd + row * CLD + cch * 8) = ov;
       // rows past M contribute nothing to the reductions (their dZ is finite: clamped operands) — masked where the operand is consumed,
       // not where it was requested, so that no wait for the loads sits in front of the staging above
-      *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = (m < e.M) ? hx[r] : make_uint4(0u, 0u, 0u, 0u);
+      if (GSL_MG_ON(e, 8)) *reinterpret_cast<uint4*>(yh + row * CLD + cch * 8) = (m < e.M) ? hx[r] : make_uint4(0u, 0u, 0u, 0u);
     }
-    {
+    if (GSL_MG_ON(e, 8)) {
       const bool in = mw + ic * 32 + (lane >> 1) < e.M;
       *reinterpret_cast<uint4*>(ub + lane * 8) = in ? u1 : make_uint4(0u, 0u, 0u, 0u);      // row lane / 2, half lane % 2: 16 bytes per lane, contiguous
     }
@@ -735,6 +745,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
     // this round's set is consumed: refill it for the round that uses it next
     if (ic + 2 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 2, lane);
     asm volatile("" ::: "memory");
+    if (!GSL_MG_ON(e, 4)) continue;
     GfFrag b1, b2;
     b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
     b1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + (trow + 16) * 16 + tcol));
@@ -755,33 +766,44 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
     }
     asm volatile("" ::: "memory");
   }
-  // g?[t][r] = G?[n = nw + t*16 + 4*fc + r][j = fr]: add the two wave rows (wm = 1 hands over through its own region), then one
-  // [64 cols][R] partial per wave column of the M tile
-  __syncthreads();
-  if (wm == 1) {
+  // g?[t][r] = G?[n = nw + t*16 + 4*fc + r][j = fr]. The two wave rows of a wave column are summed through LDS and every M tile writes one
+  // [64 cols][R] partial per wave column and gradient — 64 * R CONSECUTIVE floats of gpart, so the hand-over also serves as the transpose into
+  // full-line stores (round 6: from the fragment layout each lane stored 32 single floats as 32-byte pieces 128 bytes apart — 32 store
+  // instructions per wave, ~4.9 k cycles of the CU's in-order memory pipe per tile; now R / 4 sixteen-byte stores per wave). Every wave parks
+  // its two partials in its own region as [64][GF_XS] (G1 in columns 0..15, G2 in 16..31; GF_XS = 36: the fragment writes are conflict-free),
+  // one barrier, then the wm = 0 wave of the column sums and stores G1's partial and the wm = 1 wave G2's (wm 0's value + wm 1's: as before).
+  if (!GSL_MG_ON(e, 128)) return;
+  constexpr int GF_XS = 36;
+  {
     float* x = reinterpret_cast<float*>(wreg);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        x[(t * 16 + 4 * fc + r) * 32 + fr] = g1[t][r];
-        x[(t * 16 + 4 * fc + r) * 32 + 16 + fr] = g2[t][r];
+        x[(t * 16 + 4 * fc + r) * GF_XS + fr] = g1[t][r];
+        x[(t * 16 + 4 * fc + r) * GF_XS + 16 + fr] = g2[t][r];
       }
   }
   __syncthreads();
-  if (wm == 0 && fr < e.gR) {
-    const float* x = reinterpret_cast<const float*>(partner);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nl = t * 16 + 4 * fc + r, n = nw + nl;
-        if (n < e.N) {
-          const size_t o = ((size_t)mtile * e.N + n) * e.gR + fr;
-          e.gpart1[o] = g1[t][r] + x[nl * 32 + fr];
-          e.gpart2[o] = g2[t][r] + x[nl * 32 + 16 + fr];
-        }
+  {
+    const float* x0 = reinterpret_cast<const float*>(wm == 0 ? wreg : partner) + wm * 16;      // the column's wm = 0 wave ...
+    const float* x1 = reinterpret_cast<const float*>(wm == 0 ? partner : wreg) + wm * 16;      // ... and its wm = 1 wave; this wave's gradient
+    float* dst = (wm == 0 ? e.gpart1 : e.gpart2) + ((size_t)mtile * e.N + nw) * e.gR;
+    const int R = e.gR;
+    if ((R & 3) == 0 && nw + 64 <= e.N) {
+      for (int q = lane * 4; q < 64 * R; q += 256) {
+        const int nl = q / R, j = q - nl * R;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x0 + nl * GF_XS + j);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x1 + nl * GF_XS + j);
+        *reinterpret_cast<f32x4_t*>(dst + q) = a + b;
       }
+    } else {
+      const int cols = min(64, e.N - nw);
+      for (int q = lane; q < cols * R; q += 64) {
+        const int nl = q / R, j = q - nl * R;
+        dst[q] = x0[nl * GF_XS + j] + x1[nl * GF_XS + j];
+      }
+    }
   }
 }
 // BIAS_RES_F32 epilogue (out-proj / FFN2 forward: x + drop(acc + bias), f32 stream): same staging, the residual is loaded and the
@@ -1681,13 +1703,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   if constexpr (LORA && GRAD) {
     // same as below with t kept as [256][16] behind the staging regions (the K-loop stages end before it: no barrier needed first)
     bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
+    // the Q fragments of the rank-r tail are requested FIRST: their round trip passes under the t hand-over and its barrier (requested behind
+    // the barrier they cost the tail ~2 k exposed cycles per tile; the K loop's operand-fragment registers are dead from here on)
+    bf16x8_t qf[4];
+    if (GSL_MG_ON(e, 32))
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       bf16_t* d = t16 + (wm * 128 + GSL_P8_TFRAG(t) * 16 + fr) * 16 + fc * 4;
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[t][0], lk.s * accp[t][1]), pack2o(lk.s * accp[t][2], lk.s * accp[t][3]));
     }
     __syncthreads();
-    if (n0 == 0 && lk.tout) {
+    if (n0 == 0 && lk.tout && GSL_MG_ON(e, 64)) {
       const int row = tid >> 1, half = tid & 1;
       if (m0 + row < e.M) {
         bf16_t* dst = lk.tout + (size_t)(m0 + row) * lk.ldt + half * 32;
@@ -1698,18 +1730,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         }
       }
     }
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
-      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
-    }
     // round 0 of the epilogue's global operands flies under the rank-r tail (the operand-fragment registers of the K loop are dead).
     // Placement: behind the t16 hand-over (the compiler closes the K loop's LDS-DMA stream with s_waitcnt vmcnt(0) in front of the
-    // first LDS store) and behind the Q fragments (vmcnt retires in order: the MFMAs below must not wait for these ten loads).
+    // first LDS store) and behind the Q fragments (vmcnt retires in order: the MFMAs below must not wait for these loads).
     asm volatile("" ::: "memory");
     GfOperands go;
     gf_request<EPI == GSL_EPI_MUL_G8>(e, go, m0 + wm * 128, n0 + wn * 64, 0, lane);
+    if (GSL_MG_ON(e, 32))
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(t16 + (wm * 128 + i * 16 + fr) * 16 + (fc & 1) * 8);
@@ -1719,12 +1746,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
         acc[i][j] = GSL_MFMA16(qf[j], tf, acc[i][j], 0, 0, 0);
     }
     __syncthreads();            // every wave is done with the stages: reuse them for the staging regions
-    epilogue_staged_mulgrad<8, EPI == GSL_EPI_MUL_G8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave + 4) * GF_WAVE_B,
+    epilogue_staged_mulgrad<8, EPI == GSL_EPI_MUL_G8>(e, acc, reinterpret_cast<char*>(smem) + wave * GF_WAVE_B, reinterpret_cast<char*>(smem) + (wave ^ 4) * GF_WAVE_B,
                                t16 + wm * 128 * 16, m0 + wm * 128, n0 + wn * 64, lane, wm, m0 / BM4, go);
     if (dbg8) dbg8[3] = __builtin_readcyclecounter();
     return;
   } else if constexpr (LORA) {
     // t = s * (A P^T): accp[t][reg] = T[row = wm*128 + GSL_P8_TFRAG(t)*16 + fr][j = fc*4 + reg] -> LDS [256][32] bf16 (cols 16..31 = 0)
+    bf16x8_t qf[4];                                    // rank-r update: one more k-step (k = 32: r live columns); its Q fragments are requested
+#pragma unroll                                         // here, so that their round trip passes under the two barriers of the t hand-over
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
+      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
+    }
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // stages are free
     bf16_t* tbuf = smem;
 #pragma unroll
@@ -1744,12 +1778,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
           *reinterpret_cast<uint4*>(dst + c * 8) = v;
         }
       }
-    }
-    bf16x8_t qf[4];                                    // rank-r update: one more k-step (k = 32: r live columns)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = min(n0 + wn * 64 + j * 16 + fr, e.N - 1);
-      qf[j] = *reinterpret_cast<const bf16x8_t*>(lk.Q + (size_t)n * lk.ldq + fc * 8);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

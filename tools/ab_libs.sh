@@ -6,7 +6,7 @@ for i in $(seq 1 $n); do
   k=0
   for lib in "$@"; do
     k=$((k+1))
-    GSLORA_HIP_LIB=$lib python bench.py --no-cpu-baseline --no-eval --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/L${k}_$i.json
+    GSLORA_HIP_LIB=$lib python bench.py --no-cpu-baseline --no-eval --no-secondary --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/L${k}_$i.json
   done
 done
 python - "$out" "$@" <<'PY'

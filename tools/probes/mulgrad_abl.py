@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""The gradient-fused FFN2-dX GEMM (gsl_gemm_nt_lora_mulgrad) with and without its HBM writes (dev build, GSL_STORE_MODE=3): kernel time and stamps."""
+"""The gradient-fused FFN2-dX GEMM (gsl_gemm_nt_lora_mulgrad), kernel time and stamps, with parts of its epilogue removed: the HBM writes
+(dev build, GSL_STORE_MODE=3) and — with the ablation variant (python -m gslora_hip.build --dev --variant mgabl -DGSL_MG_ABL=1, GSLORA_HIP_LIB
+pointing at it, MG_ABL=1) — the operand loads (2), the transposed reads + reduction MFMAs (4), the dZ / h / U1 LDS hand-over (8) and the f32
+staging round trip (16), the rank-r tail's Q loads + MFMAs (32), the t store of the first N tile (64), the final hand-over and partial stores (128). Ablated results are wrong by design; only the times mean something."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gs-lora_amd")]
@@ -18,16 +21,20 @@ aux = torch.randint(0, 250, (M, N), device="cuda", dtype=torch.uint8)
 U1 = torch.randn(M, 16, device="cuda").to(dt); Y2 = torch.randn(M, N, device="cuda").to(dt)
 G1 = torch.zeros(N, r, device="cuda"); G2 = torch.zeros(r, N, device="cuda")
 call = lambda: ops.gemm_nt_lora_mulgrad(A, W, P, Q, 1.0 / r, tout, out, aux, U1, G1, (r, 1), Y2, G2, (1, N), r, p_drop=0.1)
-for mode in ("1", "3", "1", "3"):
+cases = [("1", 0), ("3", 0), ("1", 0), ("3", 0)]
+if os.environ.get("MG_ABL"):
+    cases = [("1", 0), ("1", 0), ("1", 32), ("1", 64), ("1", 128), ("1", 2), ("1", 16), ("1", 12), ("3", 30), ("3", 30 + 32), ("3", 30 + 32 + 64), ("3", 254), ("1", 0)]
+for mode, mask in cases:
     os.environ["GSL_STORE_MODE"] = mode
+    os.environ["GSL_O4_DELAY"] = str(mask)
     for _ in range(2):
         dbg.zero_(); call()
     torch.cuda.synchronize()
     st = dbg.cpu().view(-1, 4); st = st[(st != 0).all(1)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(10):
         call()
     e1.record(); torch.cuda.synchronize()
     d_ = (st[:, 1:] - st[:, :-1]).double(); tot = (st[:, 3] - st[:, 0]).double()
-    print(f"| FFN2-dX gradient-fused | store mode {mode} | {e0.elapsed_time(e1) / 5 * 1e3:.0f} us (incl. the two reduce launches) | prologue {d_[:, 0].median():.0f}, K loop + rank-r tail {d_[:, 1].median():.0f}, epilogue {d_[:, 2].median():.0f}, total {tot.median():.0f} |", flush=True)
+    print(f"| FFN2-dX gradient-fused | store mode {mode}, ablation mask {mask} | {e0.elapsed_time(e1) / 10 * 1e3:.0f} us (incl. the two reduce launches) | prologue {d_[:, 0].median():.0f}, K loop + rank-r tail {d_[:, 1].median():.0f}, epilogue {d_[:, 2].median():.0f}, total {tot.median():.0f} |", flush=True)
