@@ -679,9 +679,25 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
   // cycles when all CUs stream. The second set costs no registers at the kernel level: the K loop's operand fragments (72 VGPRs) are
   // dead here and every round frees 32 accumulator registers.
   GfOperands gob;
+#if defined(GSL_DEV) && defined(GSL_MG_ABL)
+  // ablation 0x100 / 0x200 / 0x300: every second wave starts ~1 k / 2 k / 3 k cycles late (are the eight waves of a tile fighting in lockstep?)
+  if (((nw >> 6) & 1) && (e.o4_delay & 0x300)) {
+    const int d = (e.o4_delay >> 8) & 3;
+    if (d == 1) __builtin_amdgcn_s_sleep(16); else if (d == 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(48);
+  }
+#endif
+#if defined(GSL_DEV) && defined(GSL_MG_ABL)
+  // phase clocks of one wave (the stamping workgroup's wave 0): staging round trip / rows (multiply, stores, LDS hand-over) / requests /
+  // reductions / final hand-over, summed over the four rounds, written behind the 256 x 4 stamp table
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define GSL_MG_PHASE(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - pt; pt = now_; }
+#else
+#define GSL_MG_PHASE(i)
+#endif
   asm volatile("" ::: "memory");
   if (NI / 2 > 1) gf_request<G8>(e, gob, mw, nw, 1, lane);
   asm volatile("" ::: "memory");
+  GSL_MG_PHASE(2)
   const float sq8 = e.drop.scale / G8_K;
 #pragma unroll
   for (int ic = 0; ic < NI / 2; ++ic) {
@@ -698,7 +714,8 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
         if (GSL_MG_ON(e, 16)) *reinterpret_cast<f32x4_t*>(cst + (ii * 16 + fr) * CLF + j * 16 + fc * 4) = v;
       }
     __builtin_amdgcn_sched_barrier(0);    // nothing that consumes the requested operands may be scheduled above the staging (it would drag their wait up)
-    // the round's four staged rows are read back at once (round 6: one LDS round trip per round instead of one per row)
+    // the round's four staged rows are read back at once (round 6: one LDS round trip per round instead of one per row; staging round q + 1
+    // right behind these reads, so that its round trip passes under round q's rows, changes nothing: measured, tools/probes/mulgrad_abl.py)
     f32x4_t slo[4], shi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -708,6 +725,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       } else { slo[r] = acc[ic * 2][r]; shi[r] = acc[ic * 2 + 1][r]; }
     }
     __builtin_amdgcn_sched_barrier(0);
+    GSL_MG_PHASE(0)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r * 8 + crow;
@@ -742,9 +760,11 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       *reinterpret_cast<uint4*>(ub + lane * 8) = in ? u1 : make_uint4(0u, 0u, 0u, 0u);      // row lane / 2, half lane % 2: 16 bytes per lane, contiguous
     }
     asm volatile("" ::: "memory");      // the wave's DS operations execute in order; this only pins the compiler's order
+    GSL_MG_PHASE(1)
     // this round's set is consumed: refill it for the round that uses it next
     if (ic + 2 < NI / 2) gf_request<G8>(e, op, mw, nw, ic + 2, lane);
     asm volatile("" ::: "memory");
+    GSL_MG_PHASE(2)
     if (!GSL_MG_ON(e, 4)) continue;
     GfFrag b1, b2;
     b1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_v4s_p)(ub + trow * 16 + tcol));
@@ -765,6 +785,7 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       g2[t] = GSL_MFMA16(a2.v, b2.v, g2[t], 0, 0, 0);
     }
     asm volatile("" ::: "memory");
+    GSL_MG_PHASE(3)
   }
   // g?[t][r] = G?[n = nw + t*16 + 4*fc + r][j = fr]. The two wave rows of a wave column are summed through LDS and every M tile writes one
   // [64 cols][R] partial per wave column and gradient — 64 * R CONSECUTIVE floats of gpart, so the hand-over also serves as the transpose into
@@ -805,6 +826,14 @@ __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_
       }
     }
   }
+#if defined(GSL_DEV) && defined(GSL_MG_ABL)
+  GSL_MG_PHASE(4)
+  if (e.stamps && !e.stamps_all && blockIdx.x < 64 * 256 && (blockIdx.x % 64) == 0 && threadIdx.x == 0) {
+    unsigned long long* d = e.stamps + 1024 + (blockIdx.x / 64) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = ph[i];
+  }
+#endif
+#undef GSL_MG_PHASE
 }
 // BIAS_RES_F32 epilogue (out-proj / FFN2 forward: x + drop(acc + bias), f32 stream): same staging, the residual is loaded and the
 // result stored as full 256-byte rows (16 lanes x 16 B per row, 4 rows per instruction) instead of 64-byte fragment rows.
