@@ -902,8 +902,26 @@ __device__ __forceinline__ void epilogue_staged_res_f32(const EpiArgs& e, f32x4_
 // requested before round q is processed. The dropout mask is the one of the f32-stream epilogue (same element index, same hash).
 // F16 (the stream format) and DROP (a dropout mask applies) are wave-uniform launch arguments, decided ONCE by the dispatcher below: as run-time
 // tests inside pack2s / unpack2s / drop_mul4_w they were ~10 uniform branches (each with an s_waitcnt vmcnt(0) behind it) per output row.
-template <int NI, int EPI, bool F16, bool DROP>
-__device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+// Round 0's residual rows (64 rows x 128 B of the wave's piece) are requested by the KERNEL right after its K loop — in front of the LoRA tail and the
+// barrier(s) that separate the K loop from the epilogue — so that their HBM round trip passes under those instead of in front of the first row (the K
+// loop's operand-fragment registers are dead by then). Clamped addresses: the piece may be ragged.
+struct ResRows { uint4 r[8]; };
+__device__ __forceinline__ void res_rows_request0(const EpiArgs& e, ResRows& rs, int mw, int nw, int lane) {
+  const int crow = lane >> 3, cch = lane & 7;
+  const int ncl = min(nw + cch * 8, e.N - 8);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(e.res);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = min(mw + r * 8 + crow, e.M - 1);
+    rs.r[r] = gf_ld<uint4>(res + (size_t)m * e.ldo + ncl);
+  }
+}
+// FULL (the wave's 128 x 64 piece lies inside M x N — every tile of the step's shapes): no row predicate, so the rows are straight-line code. With
+// the `if (m < M && n < N)` around every row's store each row was its own basic block, and the compiler's wait insertion gave up on counting across
+// them: every row opened with s_waitcnt vmcnt(0) — it waited for the NEXT round's eight row requests (issued just before, to fly under this
+// round) and for the previous row's store, 16 times per wave.
+template <int NI, int EPI, bool F16, bool DROP, bool FULL>
+__device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane, ResRows& rs0) {
   auto unpack = [](uint32_t u, float& lo, float& hi) {
     if constexpr (F16) unpack2h(u, lo, hi);
     else { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
@@ -913,7 +931,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
   const int crow = lane >> 3, cch = lane & 7;
   const bf16_t* res = reinterpret_cast<const bf16_t*>(e.res);
   bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
-  const int n = nw + cch * 8, ncl = min(n, e.N - 8);
+  const int n = nw + cch * 8, ncl = FULL ? n : min(n, e.N - 8);
   float b8[8], c8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { b8[k] = e.bias[ncl + k]; c8[k] = 0.f; }
@@ -926,13 +944,13 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
     if constexpr (EPI == GSL_EPI_BIAS_RES_BF16) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int m = min(mw + q * 64 + r * 8 + crow, e.M - 1);
+        const int m = FULL ? mw + q * 64 + r * 8 + crow : min(mw + q * 64 + r * 8 + crow, e.M - 1);
         rs[r] = gf_ld<uint4>(res + (size_t)m * e.ldo + ncl);      // the residual stream is read once, by this workgroup (see gf_request)
       }
     }
   };
-  uint4 rsa[8], rsb[8];
-  fetch(0, rsa);
+  uint4 (&rsa)[8] = rs0.r;      // round 0: requested by the kernel (res_rows_request0)
+  uint4 rsb[8];
   const uint32_t rowstep = DROP ? (uint32_t)((4u * (uint32_t)e.N) * DROP_PHI) : 0u;      // 8 rows further = 4 N element pairs
   uint32_t w0 = DROP ? drop_w0(e.drop.key, ((uint64_t)(mw + e.mbase + crow) * (uint64_t)e.N + (uint64_t)n) >> 1) : 0u;
 #pragma unroll
@@ -980,7 +998,7 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
           o[2 * k + 1] = (c[2 * k + 1] + b8[2 * k + 1]) * dm[2 * k + 1] + r1;
         }
       }
-      if (m < e.M && n < e.N)
+      if (FULL || (m < e.M && n < e.N))
         store_stream16(out + (size_t)m * e.ldo + n, make_uint4(pack(o[0], o[1]), pack(o[2], o[3]), pack(o[4], o[5]), pack(o[6], o[7])), GSL_STMODE_OF(e));
       // rows stay in program order: without the branches that used to separate them the scheduler hoisted the masks and unpacked residuals of
       // several rows above each other, next to 128 accumulators and two sets of prefetched rows — 22 - 29 spilled dwords, +91 MB of scratch traffic
@@ -990,13 +1008,18 @@ __device__ __forceinline__ void epilogue_staged_res_bf16_impl(const EpiArgs& e, 
   }
 }
 template <int NI, int EPI>
-__device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane) {
+__device__ __forceinline__ void epilogue_staged_res_bf16(const EpiArgs& e, f32x4_t (&acc)[NI][4], float* cst, int mw, int nw, int lane, ResRows& rs0) {
+  const bool full = mw + NI * 16 <= e.M && nw + 64 <= e.N;      // wave-uniform
+  auto go = [&](auto f16, auto drop) {
+    if (full) epilogue_staged_res_bf16_impl<NI, EPI, decltype(f16)::value, decltype(drop)::value, true>(e, acc, cst, mw, nw, lane, rs0);
+    else epilogue_staged_res_bf16_impl<NI, EPI, decltype(f16)::value, decltype(drop)::value, false>(e, acc, cst, mw, nw, lane, rs0);
+  };
   if (e.f16) {
-    if (e.drop.thr) epilogue_staged_res_bf16_impl<NI, EPI, true, true>(e, acc, cst, mw, nw, lane);
-    else epilogue_staged_res_bf16_impl<NI, EPI, true, false>(e, acc, cst, mw, nw, lane);
+    if (e.drop.thr) go(std::true_type{}, std::true_type{});
+    else go(std::true_type{}, std::false_type{});
   } else {
-    if (e.drop.thr) epilogue_staged_res_bf16_impl<NI, EPI, false, true>(e, acc, cst, mw, nw, lane);
-    else epilogue_staged_res_bf16_impl<NI, EPI, false, false>(e, acc, cst, mw, nw, lane);
+    if (e.drop.thr) go(std::false_type{}, std::true_type{});
+    else go(std::false_type{}, std::false_type{});
   }
 }
 constexpr int CST_WAVE = 2 * 64 * CLD;            // bf16 elements of staging per wave (two outputs)
@@ -1726,6 +1749,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
 #undef GSL_P8_PEXTRA
   if (wm == 0) __builtin_amdgcn_s_barrier();     // re-balance the barrier count of the stagger
   if (dbg8) dbg8[2] = __builtin_readcyclecounter();
+  ResRows rs0;
+  constexpr bool RES16 = EPI == GSL_EPI_BIAS_RES_BF16;
+  const bool res16_staged = RES16 && (e.N % 8) == 0 && (e.ldo % 8) == 0 && e.N >= 8;      // (the condition of the staged epilogue below)
+  if constexpr (RES16) {
+    if (res16_staged) res_rows_request0(e, rs0, m0 + wm * 128, n0 + wn * 64, lane);
+    asm volatile("" ::: "memory");
+  }
 #ifdef GSL_DEV
   if (e.pf == 1) warm_next();
 #endif
@@ -1827,7 +1857,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   if constexpr (EPI == GSL_EPI_BIAS_RES_BF16 || EPI == GSL_EPI_PATCH_BF16) {
     if ((e.N % 8) == 0 && (e.ldo % 8) == 0 && e.N >= 8 && (EPI != GSL_EPI_PATCH_BF16 || e.ldo == e.N)) {
       __builtin_amdgcn_s_barrier();            // every wave is done with the stages (and tbuf): reuse them for C staging
-      epilogue_staged_res_bf16<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane);
+      epilogue_staged_res_bf16<8, EPI>(e, acc, reinterpret_cast<float*>(smem + wave * CST_WAVE), m0 + wm * 128, n0 + wn * 64, lane, rs0);
       if (dbg8) dbg8[3] = __builtin_readcyclecounter();
       return;
     }
