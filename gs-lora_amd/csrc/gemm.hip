@@ -1675,25 +1675,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
   __builtin_amdgcn_s_barrier();                                                                             \
   __builtin_amdgcn_sched_barrier(0);
 
-  // (development, measured useless: profiles/r03_notes.md) L2 warm-up for the NEXT round: block b + 256 is dispatched to this block's XCD (b % 8) when one of its 32 slots frees. Its prologue
-  // waits on A rows nobody has read yet (2.5 - 6 k cycles, profiles/r03_h_wg_timeline.md); touching one dword per 128-byte line of its
-  // first two K tiles pulls them into this XCD's L2 ahead of time. The loads land in a 2 KB LDS dump (LDS-DMA: no VGPR is written behind
-  // the compiler's back) and are never read. Issue point (e.pf): 1 after the K loop, 2 in K-loop step 0, 3 in step nk - 3 — inside the
-  // loop right behind the counted wait, so that the next step's wait (which retires it, in order) comes a whole K tile later.
-#ifdef GSL_DEV
-  __shared__ uint32_t pf_dump[512];
-  auto warm_next = [&]() {
-    const int nb = (int)blockIdx.x + 256;
-    if (nb < (int)gridDim.x) {
-      const int t0 = e.remap ? xcd_remap(nb, gridDim.x) : nb;
-      const int t2 = e.mrev ? (int)gridDim.x - 1 - t0 : t0;
-      const int prow = min((t2 / nbn) * BM4 + (tid >> 1), e.M - 1);
-      int pk = (krot + (tid & 1)) * BK;                // its loop steps 0 and 1 (K rotation included)
-      if (pk >= K1) pk = 0;
-      __builtin_amdgcn_global_load_lds((gptr_t)(A1 + (size_t)prow * lda1 + pk), (lptr_t)(pf_dump + wave * 64), 4, 0, 0);
-    }
-  };
-#endif
+  // (an L2 warm-up for the NEXT round's first two K tiles, issued from inside this loop, was measured useless: profiles/r03_notes.md; the code left with commit 15030e9)
   // (a 4-phase cut of this loop — two phases of 32 MFMAs per K tile, half the barriers — is bit-identical and 0.7 % slower per step:
   //  profiles/r04_notes.md; commit 52d4782 has the code)
   for (int kt = 0; kt < nk; ++kt) {
@@ -1740,9 +1722,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (LORA && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
-#ifdef GSL_DEV
-    if ((e.pf == 2 && kt == 0) || (e.pf == 3 && kt == nk - 3)) warm_next();
-#endif
     GSL_P8_MFMA(1, 0, bf0, 3)
   }
 #undef GSL_P8_MFMA
@@ -1756,9 +1735,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
     if (res16_staged) res_rows_request0(e, rs0, m0 + wm * 128, n0 + wn * 64, lane);
     asm volatile("" ::: "memory");
   }
-#ifdef GSL_DEV
-  if (e.pf == 1) warm_next();
-#endif
   if constexpr (LORA && GRAD) {
     // same as below with t kept as [256][16] behind the staging regions (the K-loop stages end before it: no barrier needed first)
     bf16_t* t16 = smem + (8 * GF_WAVE_B) / 2;
