@@ -63,6 +63,37 @@ def overflow_run(rank, world, out):
     for n, a in m.named_parameters():
         if a.requires_grad:
             res[n] = a.detach().float().cpu().numpy()
+    # the same under graph replay: step 0 runs eagerly, step 1 captures and replays, steps 2 .. 4 replay the three segments with the collectives in between; rank 1
+    # reports a saturated backward in step 3 — poked into the guard word right before ITS all-reduce (the only MAX message of a step)
+    S._post_guard = post
+    m2 = build(cfg, "fp16", 0.0)
+    opt2 = FusedAdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05, eps=1e-8)
+    train2 = [p for p in m2.parameters() if p.requires_grad]
+    g = S.GraphedStep(m2, opt2, crit)
+    real_ar = dist.all_reduce
+
+    def poking_ar(t, op=dist.ReduceOp.SUM, **kw):
+        if hit["on"] and op == dist.ReduceOp.MAX:
+            t.fill_(0x7f800000)            # +inf, as the int32 word the ranks compare
+        return real_ar(t, op=op, **kw)
+    S.dist.all_reduce = poking_ar
+    gexps, gseen, gmoved = [], [], []
+    try:
+        for s in range(5):
+            hit["on"] = (s == 3 and rank == 1)
+            before = [p.detach().clone() for p in train2]
+            g(*(t[sl].contiguous() for t in whole_batch(cfg, world, s)), **kw)
+            torch.cuda.synchronize()
+            rep = m2._runner.loss_scale_report()
+            gexps.append(rep["exponent"]); gseen.append(rep["seen_max"])
+            gmoved.append(any(not torch.equal(a, b) for a, b in zip(before, train2)))
+    finally:
+        S.dist.all_reduce = real_ar
+    assert (g.eager_steps, g.captures, g.replays) == (1, 1, 4), (g.eager_steps, g.captures, g.replays)
+    res.update(gexps=np.array(gexps), gseen=np.array(gseen), gmoved=np.array(gmoved))
+    for n, a in m2.named_parameters():
+        if a.requires_grad:
+            res["g." + n] = a.detach().float().cpu().numpy()
     np.savez(out, **res)
 
 

@@ -40,6 +40,11 @@ def test_two_ranks_agree_on_a_saturated_fp16_step(tmp_path):
     assert np.isinf(r0["seen"][1]) and np.isfinite(r0["seen"][[0, 2]]).all(), r0["seen"]
     e = r0["exps"]
     assert e[1] == e[0] and e[2] == e[0] - 2, e
+    # ... and under graph replay (eager, capture + replay, replay x 3; the saturated one is a replay)
+    assert r0["gmoved"].tolist() == [True, True, True, False, True], r0["gmoved"]
+    assert np.isinf(r0["gseen"][3]) and np.isfinite(r0["gseen"][[0, 1, 2, 4]]).all(), r0["gseen"]
+    ge = r0["gexps"]
+    assert (ge[:4] == ge[0]).all() and ge[4] == ge[0] - 2, ge
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2), ("fp16", 4e-3)])
