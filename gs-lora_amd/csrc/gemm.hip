@@ -1145,6 +1145,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 #ifndef GSL_SMALL_NSTS
 #define GSL_SMALL_NSTS 3      // stages of the 64x64 ring kernel: 3 x 16 KB = three workgroups per CU (4: two; measured, r03_notes.md)
 #endif
+// Workgroup barrier that PUBLISHES this wave's LDS stores: s_barrier alone only lines the waves up — a ds_write issued in front of it may still be
+// in the LDS queue when another wave, past the barrier, reads the location (gfx950 has the back-off barrier: the compiler inserts no wait in front of a
+// raw s_barrier, and the raw builtin carries no fence). The K loops use the raw barrier on purpose (their LDS-DMA stream must stay in flight; what they
+// publish is retired by a counted vmcnt wait); every hand-over through plain LDS stores uses this one (or __syncthreads()).
+__device__ __forceinline__ void wg_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 struct LoraInk {
   const bf16_t* P; int ldp;
   const bf16_t* Q; int ldq;
@@ -1325,7 +1335,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_bf16_small_kernel(const bf16_t*
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[0], lk.s * accp[1]), pack2o(lk.s * accp[2], lk.s * accp[3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
-    __builtin_amdgcn_s_barrier();
+    wg_barrier_lds();      // (a raw s_barrier here let a wave read t rows whose ds_write was still queued: a wrong 16-row fragment once in ~10 process runs)
     if (lead && n0 == 0 && lk.tout) {                  // 64 rows x 64 columns = 512 16-byte pieces, two per thread of group 0
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1802,7 +1812,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const bf16_t* __restr
       *reinterpret_cast<uint2*>(d) = make_uint2(pack2o(lk.s * accp[t][0], lk.s * accp[t][1]), pack2o(lk.s * accp[t][2], lk.s * accp[t][3]));
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(0u, 0u);
     }
-    __builtin_amdgcn_s_barrier();
+    wg_barrier_lds();
     if (n0 == 0 && lk.tout) {                          // one N-tile stores t for the gradient reductions: [M, 64], zero padded
       const int row = tid >> 1, half = tid & 1;
       if (m0 + row < e.M) {
