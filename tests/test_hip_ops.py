@@ -1573,6 +1573,40 @@ def test_fp16_loss_scale_backs_off_on_the_device_after_a_saturated_backward(ops)
         call(target_exp=3)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_in_kernel_lora_gemms_are_run_to_run_identical(ops, dt):
+    """The kernels that hand t = s A P^T over between waves through LDS (8-phase LoRA tail, its gradient-fused form, the 64 x 64 kernel's tail — the
+    tail split sends 5 120 rows of every in-kernel-LoRA residual GEMM of the step through the latter), repeated: every repetition must reproduce the
+    first one bit for bit (round 6: a raw barrier behind the t stores let one wave read a row early, about once in ten process runs; the ISA lint in
+    tests/test_host_logic.py is the deterministic guard, this is the empirical one)."""
+    from gslora_hip import _lib as L
+    M, N, K, r = 201728, 512, 512, 8
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.float16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    P = torch.zeros(16, K, device="cuda"); P[:r] = torch.randn(r, K, device="cuda", generator=g) * K ** -0.5
+    Q = torch.zeros(N, 32, device="cuda"); Q[:, :r] = torch.randn(N, r, device="cuda", generator=g) * 0.3
+    P, Q = P.to(dt), Q.to(dt)
+    small = slice(0, 1576)                      # the 64 x 64 kernel on its own (few-shot row count)
+    first = None
+    for _ in range(12):
+        o1 = torch.empty(M, N, device="cuda", dtype=dt); t1 = torch.empty(M, 64, device="cuda", dtype=dt)
+        o2 = torch.empty(M, N, device="cuda", dtype=torch.float16); t2 = torch.empty(M, 64, device="cuda", dtype=dt)
+        o3 = torch.empty(1576, N, device="cuda", dtype=dt); t3 = torch.empty(1576, 64, device="cuda", dtype=dt)
+        ops.gemm_nt_lora(A, W, P, Q, 1.0 / r, t1, o1)
+        ops.gemm_nt_lora(A, W, P, Q, 1.0 / r, t2, o2, epilogue=L.EPI_BIAS_RES_F16, bias=bias, res=res, p_drop=0.1, seed=77, site=6)
+        ops.gemm_nt_lora(A[small], W, P, Q, 1.0 / r, t3, o3)
+        cur = (o1, t1, o2, t2, o3, t3)
+        if first is None:
+            first = cur
+            assert all(torch.isfinite(x.float()).all() for x in cur)
+        else:
+            for a, b in zip(cur, first):
+                assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------------------------- tail split (round 6)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("K,lora", [(512, False), (1536, False), (2048, True), (512, True)])
