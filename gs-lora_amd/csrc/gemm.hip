@@ -657,7 +657,8 @@ __device__ __forceinline__ void gf_request(const EpiArgs& e, GfOperands& g, int 
   // lanes 32..63 duplicating lanes 0..31 touched the same 32 lines twice (FFN2-dX 0.814 -> 0.80 ms; with a compact [M, 16] U1: 0.79)
   g.u1 = *reinterpret_cast<const uint4*>(e.gu1 + (size_t)min(mw + ic * 32 + (lane >> 1), e.M - 1) * e.ldgu1 + (lane & 1) * 8);
 }
-// go: the operands of round 0, requested by the caller (right after the K loop, in front of the rank-r tail)
+// go: the operands of round 0, requested by the caller (right after the K loop, in front of the rank-r tail); wreg: this wave's staging region,
+// partner: the region of the wave of the OTHER wave row in the same wave column (wave ^ 4) — read only in the final hand-over, behind a barrier
 template <int NI, bool G8>
 __device__ __forceinline__ void epilogue_staged_mulgrad(const EpiArgs& e, f32x4_t (&acc)[NI][4], char* wreg, char* partner,
                                                         const bf16_t* t16w, int mw, int nw, int lane, int wm, int mtile, GfOperands& go) {
